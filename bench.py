@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- rendered views/sec of the MI355X rasterizer on BASELINE.json's metric config.
+
+  python bench.py [--gpus N --steps K --warmup W]            (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W    (N>1, one rank per GPU)
+
+A "step" renders `--views` target views (default 4) of the synthetic 1.0 M-Gaussian scene at
+968x1296 on every rank (weak scaling, view-sharded: rank r renders its own block of the N*views
+target cameras) and, for N>1, all-gathers the rendered colour+depth images over RCCL on a side
+stream, overlapped with the next step.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line with `roofline` (render kernel, HIP-event timed inside the timed
+region through the library's fs_profile_* hooks) and `cpu_baseline` (the CPU oracle, OpenMP, on
+ONE view of the same workload, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=4, help="target views per step per GPU")
+    ap.add_argument("--workload", default="c3_968x1296_1M",
+                    help="c3_968x1296_1M (metric config) | c2_640x480_300k | c1_256x256_plumbing")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
+                    help="fwd: forward rendering (the metric); train: fwd + bwd (+ grad all-reduce)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image all-gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (see module docstring)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from freesplat_amd import _lib, synthetic
+    from freesplat_amd.decoder import render_views
+    from freesplat_amd.view_sharding import AsyncViewGather, allreduce_gaussian_grads, shard_range
+
+    H, W, N = synthetic.WORKLOADS[args.workload]
+    scene = synthetic.make_scene(N)
+    n_total_views = args.views * world
+    cams_all = synthetic.target_cameras(n_total_views)
+    mine = shard_range(n_total_views, rank, world)
+    sl = slice(mine.start, mine.stop)
+    cams = {k: v[sl].to(dev) for k, v in cams_all.items()}
+    g = {k: scene[k].to(dev) for k in ("means", "covariances", "harmonics", "opacities")}
+    bg = torch.zeros(len(mine), 3, device=dev)
+    train = args.mode == "train"
+    if train:
+        for t in g.values():
+            t.requires_grad_(True)
+        target = torch.rand(len(mine), 3, H, W, device=dev)
+    gather = AsyncViewGather(n_total_views, device=dev) if (world > 1 and not args.no_gather) else None
+
+    def step():
+        if train:
+            for t in g.values():
+                t.grad = None
+            color, depth = render_views(cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"],
+                                        (H, W), bg, g["means"], g["covariances"], g["harmonics"], g["opacities"])
+            loss = ((color - target) ** 2).mean()
+            loss.backward()
+            if world > 1:
+                allreduce_gaussian_grads([t.grad for t in g.values()])
+            return color, depth
+        with torch.no_grad():
+            color, depth = render_views(cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"],
+                                        (H, W), bg, g["means"], g["covariances"], g["harmonics"], g["opacities"])
+            if gather is not None:
+                gather.wait()  # previous step's gather must be done before its buffers are dropped
+                gather.launch(torch.cat([color, depth], dim=1))
+        return color, depth
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        color, depth = step()
+    if gather is not None:
+        gather.wait()
+    barrier()
+    profile = not args.no_profile
+    if profile:
+        _lib.profile_collect()
+        _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        color, depth = step()
+    if gather is not None:
+        gather.wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = {}
+    if profile:
+        _lib.profile_enable(False)
+        stages = _lib.profile_collect()
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        from freesplat_amd.rasterizer import _state
+        n_inst = _state(dev).last_instances
+        views = n_total_views * args.steps
+        # algorithmic bytes per rendered view: N*(12+24+4+12*d_sh) + P*(12+4)
+        alg_fwd = N * 148 + H * W * 16
+        alg_bwd = 2 * N * 148 + H * W * 20
+        out = {
+            "metric": f"rendered views/sec @ {H}x{W}, {N / 1e6:.1f}M Gaussians" + (" (fwd+bwd)" if train else ""),
+            "value": views / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "mode": args.mode, "image_hw": [H, W], "gaussians": N,
+                       "sh_degree": 2, "views_per_step_per_gpu": args.views,
+                       "instances_per_view": int(n_inst),
+                       "parallelism": f"view-sharded x{world}" + (" + all_gather(color,depth)" if gather else "")},
+        }
+        if stages:
+            key = "render_bwd" if train else "render"
+            ms, cnt = stages.get(key, (0.0, 0))
+            per = ms / max(cnt, 1) * 1e-3
+            alg = alg_bwd if train else alg_fwd
+            ach = alg / per / 1e9 if per > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": key + "_kernel", "achieved": ach, "peak": 8000.0,
+                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": per * 1e3,
+                               "launches": cnt}
+            out["kernel_ms_per_view"] = {k: v[0] / max(v[1], 1) for k, v in stages.items() if v[1]}
+        if world == 1 and not args.no_cpu_baseline:
+            out.update(cpu_baseline_and_parity(scene, cams_all, H, W, color[0], args.workload))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload):
+    """Times the CPU oracle (kind "port": OpenMP restatement of the reference algorithm, all host
+    cores) on a bounded sample -- whole views of the same workload until >= 10 s of CPU work or 3
+    views -- and checks the GPU image of view 0 against it (max-abs, PSNR)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util_raster import oracle_forward, view_inputs
+    cores = os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    vi = view_inputs(scene, cams_all, 0, H, W)
+    oracle_forward(vi) if H * W <= 640 * 480 else None  # warm small workloads only
+    n, t_tot, st0 = 0, 0.0, None
+    while n < 3 and t_tot < 10.0:
+        vi_n = view_inputs(scene, cams_all, n % cams_all["extrinsics"].shape[0], H, W)
+        t = time.perf_counter()
+        st = oracle_forward(vi_n)
+        t_tot += time.perf_counter() - t
+        if n == 0:
+            st0 = st
+        n += 1
+    g = gpu_color0.detach().cpu().numpy()
+    err = float(np.abs(g - st0["color"]).max())
+    mse = float(((g.clip(0, 1) - st0["color"].clip(0, 1)) ** 2).mean())
+    psnr = None if mse == 0 else float(-10 * np.log10(mse))
+    return {
+        "cpu_baseline": {"value": n / t_tot, "unit": "views/s", "cores": cores, "kind": "port",
+                         "sample": f"{n} forward view(s) of {workload} through oracle/raster_oracle.c (OpenMP)"},
+        "parity": {"max_abs_err_vs_oracle": err, "psnr_db_vs_oracle": psnr if psnr is not None else "inf",
+                   "bit_exact": bool((g == st0["color"]).all())},
+    }
+
+
+if __name__ == "__main__":
+    main()

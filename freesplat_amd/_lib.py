@@ -1,0 +1,105 @@
+"""ctypes binding of libfreesplat_hip.so (C ABI: include/freesplat_amd.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails this module
+raises.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfreesplat_hip.so")
+_lib = None
+
+
+class FreeSplatHipError(RuntimeError):
+    pass
+
+
+class RasterDims(C.Structure):
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("sh_degree", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float)]
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP translation unit under csrc/ for gfx950 into libfreesplat_hip.so."""
+    csrc = os.path.join(_PKG, "csrc")
+    args = ["make", "-C", csrc, "-j8"]
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_VP = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/freesplat_amd.h declares
+SIGNATURES = {
+    "fs_version": (C.c_char_p, []),
+    "fs_last_error": (C.c_char_p, []),
+    "fs_profile_enable": (C.c_int, [C.c_int]),
+    "fs_profile_collect": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "fs_profile_stage_name": (C.c_char_p, [C.c_int]),
+    "fs_raster_buffer_sizes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_size_t)]),
+    "fs_raster_forward": (C.c_int, [C.POINTER(RasterDims)] + [_VP] * 13 + [C.c_int64] + [_VP] * 6),
+    "fs_raster_backward": (C.c_int, [C.POINTER(RasterDims)] + [_VP] * 20 + [C.c_int, _VP]),
+    "fs_raster_tile_ranges": (_VP, [_VP, C.c_int32, C.c_int32]),
+    "fs_raster_point_list": (_VP, [_VP, C.c_int32, C.c_int32]),
+    "fs_raster_geom_records": (_VP, [_VP]),
+    "fs_raster_final_T": (_VP, [_VP]),
+    "fs_raster_n_contrib": (_VP, [_VP, C.c_int32, C.c_int32]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FreeSplatHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). freesplat_amd has no CPU / eager fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().fs_last_error().decode(errors="replace")
+        raise FreeSplatHipError(f"{what} failed with status {status} {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().fs_profile_enable(1 if on else 0), "fs_profile_enable")
+
+
+def profile_collect() -> dict:
+    """{stage name: (total ms, launches)} of the launches recorded since the last collect."""
+    L = lib()
+    names = []
+    while True:
+        s = L.fs_profile_stage_name(len(names))
+        if s is None:
+            break
+        names.append(s.decode())
+    n = len(names)
+    ms = (C.c_float * n)()
+    cnt = (C.c_int32 * n)()
+    check(L.fs_profile_collect(n, ms, cnt), "fs_profile_collect")
+    return {names[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}

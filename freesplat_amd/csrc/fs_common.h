@@ -1,0 +1,193 @@
+// fs_common.h -- shared device/host helpers of libfreesplat_hip.so (gfx950 only).
+//
+// Arithmetic contract for the rasterizer forward (see DESIGN.md "bit-reproducible forward"):
+// the translation units are compiled with -ffp-contract=off, every fused multiply-add is an
+// explicit fmaf(), exp() is fs_exp() (IEEE mul/sub/fma + v_rndne + v_ldexp only), sqrt and
+// division are the correctly rounded forms hipcc emits by default.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/freesplat_amd.h"
+
+#define FS_API extern "C" __attribute__((visibility("default")))
+
+namespace fs {
+
+constexpr int kTile = FS_TILE;       // 16x16 px
+constexpr int kTilePix = kTile * kTile;  // 256 threads = 4 wavefronts
+constexpr int kWave = 64;
+
+void set_last_error(const char* what, hipError_t e);
+
+#define FS_CHECK_LAUNCH(what)                                   \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) {                                \
+            fs::set_last_error(what, e__);                      \
+            return FS_ERR_LAUNCH;                               \
+        }                                                       \
+    } while (0)
+
+// ---- optional per-kernel event timing (fs_profile_*; off by default, zero cost when off) ------
+enum Stage {
+    kStPreprocess = 0, kStTileScan, kStEmit, kStTileSort, kStRender, kStRenderBwd, kStPreprocessBwd,
+    kStCostVolume, kStPtf, kNumStages
+};
+struct ScopedStage {
+    ScopedStage(Stage s, hipStream_t st);
+    ~ScopedStage();
+    int slot_;
+    hipStream_t st_;
+};
+
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- deterministic exp (x <= 0 on the hot path) ---------------------------------------------
+__device__ __forceinline__ float fs_exp(float x)
+{
+    if (x < -80.0f) return 0.0f;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);       // Cody-Waite: ln2 = hi + lo
+    r = fmaf(n, -1.42860676533018e-6f, r);
+    float p = fmaf(r, 1.0f / 720.0f, 1.0f / 120.0f);
+    p = fmaf(r, p, 1.0f / 24.0f);
+    p = fmaf(r, p, 1.0f / 6.0f);
+    p = fmaf(r, p, 0.5f);
+    p = fmaf(r, p, 1.0f);
+    p = fmaf(r, p, 1.0f);
+    return ldexpf(p, (int)n);
+}
+
+// ---- camera transforms: torch hands the matrices over transposed => column-major here -------
+__device__ __forceinline__ float3 xform43(const float* __restrict__ m, float3 p)
+{
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform44(const float* __restrict__ m, float3 p)
+{
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
+                       m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+
+// ---- real SH basis up to degree 3 ------------------------------------------------------------
+constexpr float kSH0 = 0.28209479177387814f;
+constexpr float kSH1 = 0.4886025119029199f;
+__device__ constexpr float kSH2[5] = {1.0925484305920792f, -1.0925484305920792f,
+                                      0.31539156525252005f, -1.0925484305920792f,
+                                      0.5462742152960396f};
+__device__ constexpr float kSH3[7] = {-0.5900435899266435f, 2.890611442640554f,
+                                      -0.4570457994644658f, 0.3731763325901154f,
+                                      -0.4570457994644658f, 1.445305721320277f,
+                                      -0.5900435899266435f};
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b)
+{
+    b[0] = kSH0;
+    if constexpr (DEG > 0) {
+        b[1] = -kSH1 * y;
+        b[2] = kSH1 * z;
+        b[3] = -kSH1 * x;
+    }
+    if constexpr (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = kSH2[0] * xy;
+        b[5] = kSH2[1] * yz;
+        b[6] = kSH2[2] * (2.0f * zz - xx - yy);
+        b[7] = kSH2[3] * xz;
+        b[8] = kSH2[4] * (xx - yy);
+        if constexpr (DEG > 2) {
+            b[9] = kSH3[0] * y * (3.0f * xx - yy);
+            b[10] = kSH3[1] * xy * z;
+            b[11] = kSH3[2] * y * (4.0f * zz - xx - yy);
+            b[12] = kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+            b[13] = kSH3[4] * x * (4.0f * zz - xx - yy);
+            b[14] = kSH3[5] * z * (xx - yy);
+            b[15] = kSH3[6] * x * (xx - 3.0f * yy);
+        }
+    }
+}
+
+// EWA projection of the 3D covariance: M = J*R (2x3), cov2D = M Sigma M^T (+0.3 px^2 on the
+// diagonal).  Shared by the forward preprocess and the per-Gaussian backward.
+struct Cov2D {
+    float a, b, c;       // dilated 2D covariance
+    float m0[3], m1[3];  // rows of M
+    float tx, ty, tz;    // clamped view-space position
+    float gmx, gmy;      // 0 where the tan-fov clamp is active
+};
+__device__ __forceinline__ Cov2D project_cov(const float* __restrict__ V, float3 mean,
+                                             const float* c3, float fx, float fy, float tanfovx,
+                                             float tanfovy)
+{
+    Cov2D o;
+    float3 t = xform43(V, mean);
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float txtz = t.x / t.z, tytz = t.y / t.z;
+    o.gmx = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+    o.gmy = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    const float j00 = fx / t.z, j02 = -(fx * t.x) / (t.z * t.z);
+    const float j11 = fy / t.z, j12 = -(fy * t.y) / (t.z * t.z);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o.m0[i] = j00 * V[0 + 4 * i] + j02 * V[2 + 4 * i];
+        o.m1[i] = j11 * V[1 + 4 * i] + j12 * V[2 + 4 * i];
+    }
+    const float s00 = c3[0], s01 = c3[1], s02 = c3[2], s11 = c3[3], s12 = c3[4], s22 = c3[5];
+    const float u00 = o.m0[0] * s00 + o.m0[1] * s01 + o.m0[2] * s02;
+    const float u01 = o.m0[0] * s01 + o.m0[1] * s11 + o.m0[2] * s12;
+    const float u02 = o.m0[0] * s02 + o.m0[1] * s12 + o.m0[2] * s22;
+    const float u10 = o.m1[0] * s00 + o.m1[1] * s01 + o.m1[2] * s02;
+    const float u11 = o.m1[0] * s01 + o.m1[1] * s11 + o.m1[2] * s12;
+    const float u12 = o.m1[0] * s02 + o.m1[1] * s12 + o.m1[2] * s22;
+    o.a = (u00 * o.m0[0] + u01 * o.m0[1] + u02 * o.m0[2]) + 0.3f;
+    o.b = u00 * o.m1[0] + u01 * o.m1[1] + u02 * o.m1[2];
+    o.c = (u10 * o.m1[0] + u11 * o.m1[1] + u12 * o.m1[2]) + 0.3f;
+    o.tx = t.x; o.ty = t.y; o.tz = t.z;
+    return o;
+}
+
+// ---- rasterizer buffer layouts (opaque to the caller; see fs_raster_buffer_sizes) ------------
+// geom: [N] x 3 float4 screen-space records, then [N] ushort4 tile rects, then [N] u8 clamp bits.
+//   r0 = {px, py, -A/2, -C/2}   r1 = {-B, opacity, power_skip_threshold, view_z}
+//   r2 = {r, g, b, 0}           (A,B,C) = conic (inverse dilated 2D covariance)
+struct GeomView {
+    float4* rec;
+    ushort4* rect;
+    uint8_t* clamp;
+};
+__host__ __device__ inline size_t geom_bytes(int N)
+{
+    return align_up((size_t)N * 48, 256) + align_up((size_t)N * 8, 256) + align_up((size_t)N, 256);
+}
+__host__ __device__ inline GeomView geom_view(void* base, int N)
+{
+    char* p = (char*)base;
+    GeomView g;
+    g.rec = (float4*)p;
+    p += align_up((size_t)N * 48, 256);
+    g.rect = (ushort4*)p;
+    p += align_up((size_t)N * 8, 256);
+    g.clamp = (uint8_t*)p;
+    return g;
+}
+// binning: [T+1] u32 tile offsets (exclusive scan of per-tile counts), then [cap] u32 ids.
+__host__ __device__ inline int num_tiles(int H, int W)
+{
+    return ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+}
+__host__ __device__ inline size_t binning_offsets_bytes(int H, int W)
+{
+    return align_up((size_t)(num_tiles(H, W) + 1) * 4, 256);
+}
+// image: [P] f32 final_T, [P] i32 n_contrib
+// scratch: [T] u32 counts, [T] u32 cursors, [cap] u64 keys
+
+}  // namespace fs

@@ -1,0 +1,478 @@
+// raster_fwd.hip -- forward of the tile-based 3D-Gaussian rasterizer for MI355X (gfx950).
+//
+// Replaces the CUDA extension FreeSplat calls at src/model/decoder/cuda_splatting.py:114-127
+// (semantics: SURVEY.md Appendix A.1-A.4).  Pipeline, all on one stream, no host sync:
+//
+//   preprocess   1 thread / Gaussian   project, cull, EWA conic, SH->RGB, tile rect,
+//                                      atomic per-tile instance count
+//   tile_scan    1 workgroup           exclusive scan of the T tile counts -> tile ranges
+//   emit         1 thread / Gaussian   scatter (depth_bits<<32 | id) keys into the tile ranges
+//   tile_sort    1 workgroup / tile    LDS bitonic sort of the tile's keys -> id list
+//   render       1 workgroup / tile    16x16 px = 4 wavefronts, LDS-staged batches of 256
+//                                      Gaussian records, front-to-back alpha compositing
+//
+// Design notes (MI355X-first, not the CUDA layout):
+//   * no global 64-bit radix sort over all instances: instances are binned per tile with
+//     atomics (order irrelevant) and each tile is sorted independently in LDS by the unique
+//     key (depth bits, gaussian id), which yields exactly the order a stable global sort of
+//     (tile, depth) keys emitted in Gaussian order would give -- "identical tile/depth ordering";
+//   * nothing on the path needs the instance count on the host;
+//   * per-Gaussian screen-space state is one 48-byte record (3 x dwordx4 gather per instance);
+//   * tile -> workgroup mapping is XCD-aware: workgroup b runs on XCD b%8, so each XCD gets a
+//     contiguous band of tiles and neighbouring tiles share their Gaussians' records in one L2.
+#include "fs_common.h"
+
+namespace fs {
+
+// ------------------------------------------------------------------------------------------
+// preprocess
+// ------------------------------------------------------------------------------------------
+template <int DEG>
+__device__ __forceinline__ void eval_sh(const float* __restrict__ sh, float3 dir, float* rgb,
+                                        uint8_t& clampbits)
+{
+    float b[16];
+    sh_basis<DEG>(dir.x, dir.y, dir.z, b);
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    clampbits = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc = b[0] * sh[c];
+#pragma unroll
+        for (int k = 1; k < NB; ++k) acc = acc + b[k] * sh[3 * k + c];
+        acc = acc + 0.5f;
+        if (acc < 0.0f) clampbits |= (uint8_t)(1u << c);
+        rgb[c] = fmaxf(acc, 0.0f);
+    }
+}
+
+// Stage `per` floats for each of the workgroup's `cnt` Gaussians through LDS with coalesced
+// loads (the [N, per] rows are contiguous, so the block's slab is one contiguous range).
+__device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__ src, size_t base,
+                                           int cnt, int per)
+{
+    const float* s = src + base * per;
+    const int total = cnt * per;
+    if ((((uintptr_t)s) & 15) == 0) {
+        const int nv = total >> 2;
+        for (int k = threadIdx.x; k < nv; k += blockDim.x)
+            ((float4*)lds)[k] = ((const float4*)s)[k];
+        for (int k = (nv << 2) + threadIdx.x; k < total; k += blockDim.x) lds[k] = s[k];
+    } else {
+        for (int k = threadIdx.x; k < total; k += blockDim.x) lds[k] = s[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    fs_raster_dims d, const float* __restrict__ means3D, const float* __restrict__ cov3D,
+    const float* __restrict__ shs, const float* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ campos, GeomView g,
+    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_counts)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int base = blockIdx.x * 256;
+    const int cnt = min(256, d.N - base);
+    const int per_sh = d.M * 3;
+    float* l_sh = lds;                                   // [256 * per_sh] (+pad to 4)
+    float* l_cov = l_sh + ((256 * per_sh + 3) & ~3);     // [256 * 6]
+    float* l_mean = l_cov + 256 * 6;                     // [256 * 3]
+    if (shs) stage_rows(l_sh, shs, base, cnt, per_sh);
+    stage_rows(l_cov, cov3D, base, cnt, 6);
+    stage_rows(l_mean, means3D, base, cnt, 3);
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= cnt) return;
+    const int i = base + t;
+
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    ushort4 rect = make_ushort4(0, 0, 0, 0);
+    uint8_t cb = 0;
+    int rad = 0;
+
+    const float3 p = make_float3(l_mean[3 * t], l_mean[3 * t + 1], l_mean[3 * t + 2]);
+    const float3 pv = xform43(view, p);
+    if (pv.z > 0.2f) {
+        const float4 ph = xform44(proj, p);
+        const float pw = 1.0f / (ph.w + 0.0000001f);
+        const float ndcx = ph.x * pw, ndcy = ph.y * pw;
+        const float fx = (float)d.W / (2.0f * d.tanfovx), fy = (float)d.H / (2.0f * d.tanfovy);
+        float c3[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c3[k] = l_cov[6 * t + k];
+        const Cov2D cv = project_cov(view, p, c3, fx, fy, d.tanfovx, d.tanfovy);
+        const float det = cv.a * cv.c - cv.b * cv.b;
+        if (det != 0.0f) {
+            const float det_inv = 1.0f / det;
+            const float cA = cv.c * det_inv, cB = -cv.b * det_inv, cC = cv.a * det_inv;
+            const float mid = 0.5f * (cv.a + cv.c);
+            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float l1 = mid + sq, l2 = mid - sq;
+            const float my_radius = ceilf(3.0f * sqrtf(fmaxf(l1, l2)));
+            const float px = ((ndcx + 1.0f) * (float)d.W - 1.0f) * 0.5f;
+            const float py = ((ndcy + 1.0f) * (float)d.H - 1.0f) * 0.5f;
+            const int r = (int)my_radius;
+            const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
+            const int x0 = min(gx, max(0, (int)((px - (float)r) / (float)kTile)));
+            const int y0 = min(gy, max(0, (int)((py - (float)r) / (float)kTile)));
+            const int x1 = min(gx, max(0, (int)((px + (float)r + (float)(kTile - 1)) / (float)kTile)));
+            const int y1 = min(gy, max(0, (int)((py + (float)r + (float)(kTile - 1)) / (float)kTile)));
+            if ((x1 - x0) * (y1 - y0) > 0) {
+                float rgb[3];
+                if (colors) {
+                    rgb[0] = colors[3 * (size_t)i];
+                    rgb[1] = colors[3 * (size_t)i + 1];
+                    rgb[2] = colors[3 * (size_t)i + 2];
+                } else {
+                    float3 dir = make_float3(p.x - campos[0], p.y - campos[1], p.z - campos[2]);
+                    const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+                    dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+                    const float* sh = l_sh + (size_t)t * per_sh;
+                    switch (d.sh_degree) {
+                        case 0: eval_sh<0>(sh, dir, rgb, cb); break;
+                        case 1: eval_sh<1>(sh, dir, rgb, cb); break;
+                        case 2: eval_sh<2>(sh, dir, rgb, cb); break;
+                        default: eval_sh<3>(sh, dir, rgb, cb); break;
+                    }
+                }
+                const float op = opacities[i];
+                // Conservative skip threshold for the blend loop: alpha = op*exp(power) < 1/255
+                // whenever power < log(1/(255 op)) - margin.  Pure optimisation: pairs inside the
+                // margin are evaluated exactly, so the result never depends on this value.
+                float thr;
+                if (op > 0.0f) {
+                    const float l = -logf(255.0f * op);
+                    thr = l - (0.001f + 1e-5f * fabsf(l));
+                } else {
+                    thr = 1.0f;  // power <= 0 < thr: never contributes
+                }
+                r0 = make_float4(px, py, -0.5f * cA, -0.5f * cC);
+                r1 = make_float4(-cB, op, thr, pv.z);
+                r2 = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+                rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1,
+                                    (unsigned short)y1);
+                rad = r;
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) atomicAdd(&tile_counts[y * gx + x], 1u);
+            }
+        }
+    }
+    g.rec[3 * (size_t)i + 0] = r0;
+    g.rec[3 * (size_t)i + 1] = r1;
+    g.rec[3 * (size_t)i + 2] = r2;
+    g.rect[i] = rect;
+    g.clamp[i] = cb;
+    radii[i] = rad;
+}
+
+// ------------------------------------------------------------------------------------------
+// tile_scan: exclusive scan over T tile counts (T ~ 5e3; one workgroup of 1024)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ counts,
+                                                         uint32_t* __restrict__ offsets,
+                                                         uint32_t* __restrict__ cursors, int T,
+                                                         uint32_t* __restrict__ counters,
+                                                         unsigned long long cap)
+{
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (T + 1023) / 1024;
+    const int lo = min(T, t * per), hi = min(T, lo + per);
+    uint32_t s = 0;
+    for (int k = lo; k < hi; ++k) s += counts[k];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (t >= off) ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int k = lo; k < hi; ++k) {
+        offsets[k] = run;
+        cursors[k] = 0;
+        run += counts[k];
+    }
+    if (t == 1023) {
+        offsets[T] = part[1023];
+        counters[0] = part[1023];
+        counters[1] = ((unsigned long long)part[1023] > cap) ? 1u : 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// emit: one key per (gaussian, tile) instance
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emit_kernel(int N, int gx, GeomView g,
+                                                   const uint32_t* __restrict__ offsets,
+                                                   uint32_t* __restrict__ cursors,
+                                                   unsigned long long* __restrict__ keys,
+                                                   unsigned long long cap)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const ushort4 rc = g.rect[i];
+    if (rc.z <= rc.x || rc.w <= rc.y) return;
+    const float z = g.rec[3 * (size_t)i + 1].w;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (uint32_t)i;
+    for (int y = rc.y; y < rc.w; ++y)
+        for (int x = rc.x; x < rc.z; ++x) {
+            const int t = y * gx + x;
+            const unsigned long long slot = (unsigned long long)offsets[t] + atomicAdd(&cursors[t], 1u);
+            if (slot < cap) keys[slot] = key;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// tile_sort: per-tile sort by (depth bits, id).  Bitonic network in its "flip" form -- every
+// compare-exchange is ascending, so an arbitrary length n works in place: partners >= n are
+// virtual +inf and never move.
+// ------------------------------------------------------------------------------------------
+constexpr int kSortLds = 4096;  // keys per tile kept in LDS (32 KiB); longer lists sort in HBM
+
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort_any(Ptr a, uint32_t n)
+{
+    uint32_t P = 1;
+    while (P < n) P <<= 1;
+    const uint32_t half = P >> 1;
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
+            const uint32_t blk = t / hk, off = t % hk;
+            const uint32_t i = blk * k + off, j = blk * k + (k - 1 - off);
+            if (j < n) {
+                const unsigned long long x = a[i], y = a[j];
+                if (x > y) { a[i] = y; a[j] = x; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = k >> 2; s >= 1; s >>= 1) {
+            for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
+                const uint32_t i = (t / s) * 2 * s + (t % s), j = i + s;
+                if (j < n) {
+                    const unsigned long long x = a[i], y = a[j];
+                    if (x > y) { a[i] = y; a[j] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint32_t* __restrict__ offsets,
+                                                        unsigned long long* __restrict__ keys,
+                                                        uint32_t* __restrict__ point_list,
+                                                        const uint32_t* __restrict__ counters)
+{
+    __shared__ unsigned long long sk[kSortLds];
+    if (counters[1]) return;  // overflowed capacity: ranges are not backed by memory
+    // XCD-aware: workgroup b -> XCD b%8 gets the contiguous tile band [xcd*chunk, (xcd+1)*chunk)
+    const int chunk = (T + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+    const uint32_t a = offsets[tile], b = offsets[tile + 1];
+    const uint32_t n = b - a;
+    if (n == 0) return;
+    if (n <= (uint32_t)kSortLds) {
+        for (uint32_t k = threadIdx.x; k < n; k += 256) sk[k] = keys[a + k];
+        __syncthreads();
+        bitonic_sort_any(sk, n);
+        for (uint32_t k = threadIdx.x; k < n; k += 256) point_list[a + k] = (uint32_t)sk[k];
+    } else {
+        // rare: very long tile lists sort in place in global memory (same network)
+        __syncthreads();
+        bitonic_sort_any(keys + a, n);
+        for (uint32_t k = threadIdx.x; k < n; k += 256) point_list[a + k] = (uint32_t)keys[a + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// render: front-to-back alpha compositing, one 16x16 tile per workgroup
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void render_kernel(
+    int H, int W, int T, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+    const float* __restrict__ bg, const uint32_t* __restrict__ counters,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, int32_t* __restrict__ n_contrib)
+{
+    __shared__ float4 s0[256], s1[256], s2[256];
+    if (counters[1]) return;
+    const int chunk = (T + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+    const int gx = (W + kTile - 1) / kTile;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x;
+    const int px = tx * kTile + (tid & 15), py = ty * kTile + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const float pfx = (float)px, pfy = (float)py;
+
+    const uint32_t a = offsets[tile], b = offsets[tile + 1];
+    const int n = (int)(b - a);
+    const int rounds = (n + 255) >> 8;
+
+    float T_ = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, D = 0.0f;
+    int last = 0;
+    bool done = !inside;
+
+    for (int r = 0; r < rounds; ++r) {
+        if (__syncthreads_and(done)) break;
+        const int idx = (r << 8) + tid;
+        if (idx < n) {
+            const uint32_t gid = point_list[a + idx];
+            const float4* q = rec + 3 * (size_t)gid;
+            s0[tid] = q[0];
+            s1[tid] = q[1];
+            s2[tid] = q[2];
+        }
+        __syncthreads();
+        const int m = min(256, n - (r << 8));
+        for (int j = 0; j < m; ++j) {
+            if (__all(done)) break;  // wave-uniform
+            const float4 g0 = s0[j], g1 = s1[j];
+            const float dx = g0.x - pfx, dy = g0.y - pfy;
+            const float power = fmaf(g0.z * dx, dx, fmaf(g0.w * dy, dy, (g1.x * dx) * dy));
+            // wave-uniform early-out: nobody in this wave can reach alpha >= 1/255
+            const bool cand = !done && power <= 0.0f && power >= g1.z;
+            if (!__any(cand)) continue;
+            if (!cand) continue;
+            const float alpha = fminf(0.99f, g1.y * fs_exp(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T_ * (1.0f - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            const float4 g2 = s2[j];
+            const float w = alpha * T_;
+            C0 = fmaf(g2.x, w, C0);
+            C1 = fmaf(g2.y, w, C1);
+            C2 = fmaf(g2.z, w, C2);
+            D = fmaf(g1.w, w, D);
+            T_ = test_T;
+            last = (r << 8) + j + 1;
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        final_T[pix] = T_;
+        n_contrib[pix] = last;
+        out_color[pix] = fmaf(T_, bg[0], C0);
+        out_color[HW + pix] = fmaf(T_, bg[1], C1);
+        out_color[2 * HW + pix] = fmaf(T_, bg[2], C2);
+        out_depth[pix] = D;
+        out_alpha[pix] = 1.0f - T_;
+    }
+}
+
+}  // namespace fs
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+using namespace fs;
+
+FS_API int fs_raster_buffer_sizes(int32_t N, int32_t H, int32_t W, int64_t cap, size_t out[4])
+{
+    if (N < 0 || H <= 0 || W <= 0 || cap < 0 || !out) return FS_ERR_INVALID_ARG;
+    const size_t T = (size_t)num_tiles(H, W), P = (size_t)H * W;
+    out[0] = geom_bytes(N > 0 ? N : 1);
+    out[1] = binning_offsets_bytes(H, W) + align_up((size_t)(cap > 0 ? cap : 1) * 4, 256);
+    out[2] = align_up(P * 4, 256) * 2;
+    out[3] = align_up(T * 4, 256) * 2 + align_up((size_t)(cap > 0 ? cap : 1) * 8, 256);
+    return FS_OK;
+}
+
+FS_API const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t, int32_t)
+{
+    return (const uint32_t*)binning;
+}
+FS_API const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W)
+{
+    return (const uint32_t*)((const char*)binning + binning_offsets_bytes(H, W));
+}
+FS_API const float* fs_raster_geom_records(const void* geom) { return (const float*)geom; }
+FS_API const float* fs_raster_final_T(const void* image) { return (const float*)image; }
+FS_API const int32_t* fs_raster_n_contrib(const void* image, int32_t H, int32_t W)
+{
+    return (const int32_t*)((const char*)image + align_up((size_t)H * W * 4, 256));
+}
+
+FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
+                             const float* shs, const float* colors_precomp, const float* opacities,
+                             const float* bg, const float* viewmatrix, const float* projmatrix,
+                             const float* campos, void* geom, void* binning, void* image,
+                             void* scratch, int64_t cap, float* out_color, float* out_depth,
+                             float* out_alpha, int32_t* radii, uint32_t* counters, void* stream_)
+{
+    if (!dims || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
+        !scratch || !out_color || !out_depth || !out_alpha || !counters)
+        return FS_ERR_INVALID_ARG;
+    const fs_raster_dims d = *dims;
+    if (d.N < 0 || d.H <= 0 || d.W <= 0 || cap < 1) return FS_ERR_INVALID_ARG;
+    if (d.N > 0) {  // an empty Gaussian set renders the background; its arrays may be NULL
+        if (!means3D || !cov3D || !opacities || !radii) return FS_ERR_INVALID_ARG;
+        if ((shs == nullptr) == (colors_precomp == nullptr)) return FS_ERR_INVALID_ARG;
+    }
+    if (shs && (d.sh_degree < 0 || d.sh_degree > 3 || (d.sh_degree + 1) * (d.sh_degree + 1) > d.M))
+        return FS_ERR_UNSUPPORTED;
+    const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
+    if (gx > 65535 || gy > 65535) return FS_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream_;
+    const int T = gx * gy;
+    const size_t P = (size_t)d.H * d.W;
+
+    GeomView g = geom_view(geom, d.N > 0 ? d.N : 1);
+    uint32_t* offsets = (uint32_t*)binning;
+    uint32_t* point_list = (uint32_t*)((char*)binning + binning_offsets_bytes(d.H, d.W));
+    float* final_T = (float*)image;
+    int32_t* n_contrib = (int32_t*)((char*)image + align_up(P * 4, 256));
+    uint32_t* counts = (uint32_t*)scratch;
+    uint32_t* cursors = (uint32_t*)((char*)scratch + align_up((size_t)T * 4, 256));
+    unsigned long long* keys = (unsigned long long*)((char*)scratch + 2 * align_up((size_t)T * 4, 256));
+
+    if (hipMemsetAsync(counts, 0, (size_t)T * 4, st) != hipSuccess) {
+        set_last_error("memset tile counts", hipGetLastError());
+        return FS_ERR_LAUNCH;
+    }
+    const int M = shs ? d.M : 0;
+    if (d.N > 0) {
+        const size_t lds = (size_t)(((256 * M * 3 + 3) & ~3) + 256 * 6 + 256 * 3) * sizeof(float);
+        {
+            ScopedStage prof_(kStPreprocess, st);
+            hipLaunchKernelGGL(preprocess_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, means3D,
+                               cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, g,
+                               radii, counts);
+        }
+        FS_CHECK_LAUNCH("preprocess");
+    }
+    {
+        ScopedStage prof_(kStTileScan, st);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, cursors, T,
+                           counters, (unsigned long long)cap);
+    }
+    FS_CHECK_LAUNCH("tile_scan");
+    if (d.N > 0) {
+        {
+            ScopedStage prof_(kStEmit, st);
+            hipLaunchKernelGGL(emit_kernel, dim3((d.N + 255) / 256), dim3(256), 0, st, d.N, gx, g, offsets,
+                               cursors, keys, (unsigned long long)cap);
+        }
+        FS_CHECK_LAUNCH("emit");
+    }
+    const int chunk = (T + 7) / 8;
+    {
+        ScopedStage prof_(kStTileSort, st);
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(8 * chunk), dim3(256), 0, st, T, offsets, keys,
+                           point_list, counters);
+    }
+    FS_CHECK_LAUNCH("tile_sort");
+    {
+        ScopedStage prof_(kStRender, st);
+        hipLaunchKernelGGL(render_kernel, dim3(8 * chunk), dim3(256), 0, st, d.H, d.W, T, offsets,
+                           point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T,
+                           n_contrib);
+    }
+    FS_CHECK_LAUNCH("render");
+    return FS_OK;
+}

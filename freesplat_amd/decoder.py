@@ -1,0 +1,250 @@
+"""Decoder boundary: camera framing + per-view rasterizer calls.
+
+Host-side mirror of the reference's
+  /root/reference/src/model/decoder/cuda_splatting.py:17-132  (get_projection_matrix, render_cuda)
+  /root/reference/src/geometry/projection.py:233-247          (get_fov)
+  /root/reference/src/model/decoder/decoder_splatting_cuda.py:35-75 (DecoderSplattingCUDA.forward)
+with the same names, argument meaning and results, so that a caller of `render_cuda` /
+`DecoderSplattingCUDA` can switch over unchanged.  Everything here is plumbing in torch; the
+compute is libfreesplat_hip.so via freesplat_amd.rasterizer.
+
+Beyond the reference: `render_views` renders v target views of ONE shared Gaussian set without
+materialising v copies of it (decoder_splatting_cuda.py:55-58 `repeat`) and with a single host
+sync per call instead of three per view; gradients of the shared set are accumulated on device.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from math import isqrt
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import rasterizer as R
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def get_fov(intrinsics: Tensor) -> Tensor:
+    """[B,3,3] normalised intrinsics -> [B,2] (fov_x, fov_y): angle between the unit rays through the
+    image-edge midpoints (projection.py:233-247)."""
+    inv = intrinsics.inverse()
+
+    def ray(v):
+        v = torch.tensor(v, dtype=torch.float32, device=intrinsics.device)
+        r = torch.einsum("bij,j->bi", inv, v)
+        return r / r.norm(dim=-1, keepdim=True)
+
+    left, right = ray([0, 0.5, 1]), ray([1, 0.5, 1])
+    top, bottom = ray([0.5, 0, 1]), ray([0.5, 1, 1])
+    fov_x = (left * right).sum(dim=-1).acos()
+    fov_y = (top * bottom).sum(dim=-1).acos()
+    return torch.stack((fov_x, fov_y), dim=-1)
+
+
+def get_projection_matrix(near: Tensor, far: Tensor, fov_x: Tensor, fov_y: Tensor) -> Tensor:
+    """Symmetric frustum, x/y -> (-1,1), z -> (0,1), w = z (cuda_splatting.py:17-44)."""
+    tan_x = (0.5 * fov_x).tan()
+    tan_y = (0.5 * fov_y).tan()
+    top = tan_y * near
+    bottom = -top
+    right = tan_x * near
+    left = -right
+    (b,) = near.shape
+    P = torch.zeros((b, 4, 4), dtype=torch.float32, device=near.device)
+    P[:, 0, 0] = 2 * near / (right - left)
+    P[:, 1, 1] = 2 * near / (top - bottom)
+    P[:, 0, 2] = (right + left) / (right - left)
+    P[:, 1, 2] = (top + bottom) / (top - bottom)
+    P[:, 3, 2] = 1
+    P[:, 2, 2] = far / (far - near)
+    P[:, 2, 3] = -(far * near) / (far - near)
+    return P
+
+
+def _frame(extrinsics, intrinsics, near, far, scale_invariant: bool):
+    """Per-view matrices exactly as cuda_splatting.py:64-87 builds them."""
+    scale = None
+    if scale_invariant:
+        scale = 1 / near
+        extrinsics = extrinsics.clone()
+        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
+        near = near * scale
+        far = far * scale
+    fov_x, fov_y = get_fov(intrinsics).unbind(dim=-1)
+    tan_fov_x = (0.5 * fov_x).tan()
+    tan_fov_y = (0.5 * fov_y).tan()
+    projection = get_projection_matrix(near, far, fov_x, fov_y).transpose(1, 2)
+    view = extrinsics.inverse().transpose(1, 2)
+    full = view @ projection
+    return extrinsics, scale, tan_fov_x, tan_fov_y, view.contiguous(), full.contiguous()
+
+
+def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                image_shape: tuple[int, int], background_color: Tensor, gaussian_means: Tensor,
+                gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
+                gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True):
+    """Drop-in for cuda_splatting.py:47-132 (name kept for the drop-in).  One rasterizer call per
+    batch element, each with its own copy of the Gaussians, like the reference.  Returns
+    (color [B,3,H,W], depth [B,1,H,W])."""
+    assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
+    extr, scale, tan_x, tan_y, view, full = _frame(extrinsics, intrinsics, near, far, scale_invariant)
+    if scale_invariant:
+        gaussian_covariances = gaussian_covariances * (scale[:, None, None, None] ** 2)
+        gaussian_means = gaussian_means * scale[:, None, None]
+    n = gaussian_sh_coefficients.shape[-1]
+    degree = isqrt(n) - 1
+    shs = gaussian_sh_coefficients.transpose(-1, -2).contiguous()  # b g xyz n -> b g n xyz
+    b = extr.shape[0]
+    h, w = image_shape
+    tan_x_h, tan_y_h = tan_x.tolist(), tan_y.tolist()  # one sync for all views (reference: 2 per view)
+    row, col = torch.triu_indices(3, 3)
+    images, depths = [], []
+    for i in range(b):
+        mean_gradients = torch.zeros_like(gaussian_means[i], requires_grad=True)
+        settings = GaussianRasterizationSettings(
+            image_height=h, image_width=w, tanfovx=tan_x_h[i], tanfovy=tan_y_h[i],
+            bg=background_color[i], scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i],
+            sh_degree=degree, campos=extr[i, :3, 3], prefiltered=False, debug=False)
+        rasterizer = GaussianRasterizer(settings)
+        image, radii, depth, _ = rasterizer(
+            means3D=gaussian_means[i], means2D=mean_gradients,
+            shs=shs[i] if use_sh else None,
+            colors_precomp=None if use_sh else shs[i, :, 0, :],
+            opacities=gaussian_opacities[i, ..., None],
+            cov3D_precomp=gaussian_covariances[i, :, row, col])
+        images.append(image)
+        depths.append(depth.unsqueeze(0))
+    return torch.stack(images), torch.stack(depths)
+
+
+# ---------------------------------------------------------------------------------------------
+# Batched multi-view path: one shared Gaussian set, v views, one sync.
+# ---------------------------------------------------------------------------------------------
+class _RenderViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, cov6, shs, opac, views, fulls, campos, bgs, tan_x, tan_y, h, w, degree):
+        v = views.shape[0]
+        N = means.shape[0]
+        dev = means.device
+        st = R._state(dev)
+        states, colors, depths = [], [], []
+        cap = R.default_capacity(N, st)
+        for i in range(v):
+            s = GaussianRasterizationSettings(h, w, tan_x[i], tan_y[i], bgs[i], 1.0, views[i], fulls[i],
+                                              degree, campos[i], False, False)
+            dims = R.make_dims(N, shs.shape[1], s)
+            rs, c, d, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i], fulls[i],
+                                            campos[i], cap)
+            states.append(rs); colors.append(c); depths.append(d)
+        counters = torch.stack([rs.counters for rs in states]).tolist()  # the single sync
+        for i, (n_inst, overflow) in enumerate(counters):
+            n_inst &= 0xFFFFFFFF
+            if overflow:
+                s = GaussianRasterizationSettings(h, w, tan_x[i], tan_y[i], bgs[i], 1.0, views[i], fulls[i],
+                                                  degree, campos[i], False, False)
+                dims = R.make_dims(N, shs.shape[1], s)
+                rs, c, d, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i],
+                                                fulls[i], campos[i], n_inst + 1024)
+                states[i], colors[i], depths[i] = rs, c, d
+            states[i].num_rendered = n_inst
+            st.last_instances = max(st.last_instances if i else 0, n_inst)
+        ctx.states = states
+        ctx.save_for_backward(means, cov6, shs)
+        ctx.set_materialize_grads(False)
+        return torch.stack(colors), torch.stack(depths)
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth):
+        means, cov6, shs = ctx.saved_tensors
+        if g_color is None and g_depth is None:
+            return (None,) * 13
+        out = None
+        for i, rs in enumerate(ctx.states):
+            gc = None if g_color is None else g_color[i]
+            gd = None if g_depth is None else g_depth[i]
+            out = R.rasterize_backward(rs, means, cov6, shs, None, gc, gd, out=out, accumulate=i > 0)
+        return (out["means3D"], out["cov3D"], out["shs"], out["opacities"]) + (None,) * 9
+
+
+def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                 image_shape: tuple[int, int], background_color: Tensor, means: Tensor,
+                 covariances: Tensor, sh_coefficients: Tensor, opacities: Tensor,
+                 scale_invariant: bool = True):
+    """v views [v,...] of ONE Gaussian set (means [G,3], covariances [G,3,3], sh [G,3,d_sh],
+    opacities [G]).  Same numbers as render_cuda on v repeated copies; requires a common `near`
+    across the views when scale_invariant (true for every shipped config: near = 0.5)."""
+    extr, scale, tan_x, tan_y, view, full = _frame(extrinsics, intrinsics, near, far, scale_invariant)
+    host = torch.stack([tan_x, tan_y, near]).tolist()  # one small sync for the scalar settings
+    tan_x_h, tan_y_h, near_h = host
+    if scale_invariant:
+        if any(n != near_h[0] for n in near_h):
+            raise ValueError("render_views needs one `near` for all views; use render_cuda otherwise")
+        s0 = scale[0]
+        means = means * s0
+        covariances = covariances * (s0 * s0)
+    degree = isqrt(sh_coefficients.shape[-1]) - 1
+    shs = sh_coefficients.transpose(-1, -2).contiguous()
+    row, col = torch.triu_indices(3, 3)
+    cov6 = covariances[:, row, col].contiguous()
+    h, w = image_shape
+    color, depth = _RenderViews.apply(means.contiguous(), cov6, shs, opacities.contiguous(), view, full,
+                                      extr[:, :3, 3].contiguous(), background_color.contiguous(),
+                                      tan_x_h, tan_y_h, h, w, degree)
+    return color, depth.unsqueeze(1)
+
+
+@dataclass
+class DecoderOutput:
+    color: Optional[Tensor]  # [b, v, 3, h, w]
+    depth: Optional[Tensor]  # [b, v, h, w]
+
+
+@dataclass
+class Gaussians:
+    """src/model/types.py:7-12"""
+    means: Tensor        # [b, g, 3]
+    covariances: Tensor  # [b, g, 3, 3]
+    harmonics: Tensor    # [b, g, 3, d_sh]
+    opacities: Tensor    # [b, g]
+
+
+class DecoderSplattingCUDA(nn.Module):
+    """Mirror of decoder_splatting_cuda.py:20-75 (registry key "splatting_cuda").  `batched=True`
+    (default) renders through `render_views`; `batched=False` reproduces the reference's
+    repeat-per-view call pattern through `render_cuda`."""
+
+    def __init__(self, background_color=(0.0, 0.0, 0.0), batched: bool = True):
+        super().__init__()
+        self.register_buffer("background_color", torch.tensor(background_color, dtype=torch.float32),
+                             persistent=False)
+        self.batched = batched
+
+    def forward(self, gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                image_shape: tuple[int, int], depth_mode=None, no_color: bool = False) -> DecoderOutput:
+        b, v = extrinsics.shape[:2]
+        if no_color:
+            if depth_mode is not None:
+                # reference raises UnboundLocalError here (decoder_splatting_cuda.py:47-71)
+                raise RuntimeError("no_color=True with depth_mode set has no defined result in the reference")
+            return DecoderOutput(None, None)
+        bg = self.background_color
+        if self.batched:
+            colors, depths = [], []
+            for i in range(b):
+                c, d = render_views(extrinsics[i], intrinsics[i], near[i], far[i], image_shape,
+                                    bg[None].expand(v, 3), gaussians.means[i], gaussians.covariances[i],
+                                    gaussians.harmonics[i], gaussians.opacities[i])
+                colors.append(c); depths.append(d)
+            color = torch.stack(colors)
+            depth = torch.stack(depths).squeeze(2)
+        else:
+            rep = lambda t: t[:, None].expand(b, v, *t.shape[1:]).reshape(b * v, *t.shape[1:])
+            color, depth = render_cuda(
+                extrinsics.reshape(b * v, 4, 4), intrinsics.reshape(b * v, 3, 3), near.reshape(b * v),
+                far.reshape(b * v), image_shape, bg[None].expand(b * v, 3), rep(gaussians.means),
+                rep(gaussians.covariances), rep(gaussians.harmonics), rep(gaussians.opacities))
+            color = color.reshape(b, v, *color.shape[1:])
+            depth = depth.reshape(b, v, *depth.shape[1:]).squeeze(2)
+        depth = depth / 2  # decoder_splatting_cuda.py:62
+        return DecoderOutput(color, None if depth_mode is None else depth)

@@ -1,0 +1,286 @@
+"""Host side of the MI355X rasterizer behind the reference's operator API.
+
+Mirrors the interface FreeSplat imports from the (un-vendored) CUDA extension
+`diff_gaussian_rasterization_depth` at /root/reference/src/model/decoder/cuda_splatting.py:5-8
+and calls at :100-127:
+
+    settings   = GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg,
+                     scale_modifier, viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug)
+    rasterizer = GaussianRasterizer(settings)
+    color, radii, depth, alpha = rasterizer(means3D, means2D, shs=..., colors_precomp=...,
+                                            opacities=..., cov3D_precomp=...)
+
+Same names, argument meaning and error behaviour (Python exceptions).  The compute is
+libfreesplat_hip.so (C ABI, include/freesplat_amd.h) on the current HIP stream; there is no CPU
+or eager fallback -- a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    viewmatrix: Tensor
+    projmatrix: Tensor
+    sh_degree: int
+    campos: Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ---------------------------------------------------------------------------------------------
+# workspace management (plumbing): the C ABI never allocates, torch's caching allocator does.
+# ---------------------------------------------------------------------------------------------
+class _DeviceState:
+    """Per-device scratch (reused across calls on the same stream) and capacity history."""
+
+    def __init__(self):
+        self.scratch: Optional[Tensor] = None
+        self.last_instances = 0
+
+
+_states: dict[int, _DeviceState] = {}
+
+
+def _state(device: torch.device) -> _DeviceState:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _states.get(idx)
+    if st is None:
+        st = _states[idx] = _DeviceState()
+    return st
+
+
+def _buffer_sizes(N: int, H: int, W: int, cap: int):
+    out = (C.c_size_t * 4)()
+    _lib.check(_lib.lib().fs_raster_buffer_sizes(N, H, W, cap, out), "fs_raster_buffer_sizes")
+    return [int(x) for x in out]
+
+
+def default_capacity(N: int, st: _DeviceState) -> int:
+    """Instance capacity: generous (HBM is 288 GB) so the overflow retry is the rare path."""
+    return max(1 << 20, 8 * N, int(st.last_instances * 1.25) + 1024)
+
+
+class RasterState:
+    """Everything one forward leaves behind for its backward (device buffers + dims)."""
+
+    __slots__ = ("dims", "geom", "binning", "image", "radii", "counters", "cap", "bg", "view", "proj",
+                 "campos", "num_rendered")
+
+
+def _launch_forward(dims: _lib.RasterDims, means3D, cov3D, shs, colors, opacities, bg, view, proj,
+                    campos, cap: int) -> tuple[RasterState, Tensor, Tensor, Tensor]:
+    dev = means3D.device
+    N, H, W = dims.N, dims.H, dims.W
+    sz = _buffer_sizes(N, H, W, cap)
+    st = _state(dev)
+    if st.scratch is None or st.scratch.numel() < sz[3]:
+        st.scratch = torch.empty(sz[3], dtype=torch.uint8, device=dev)
+    rs = RasterState()
+    rs.dims = dims
+    rs.geom = torch.empty(sz[0], dtype=torch.uint8, device=dev)
+    rs.binning = torch.empty(sz[1], dtype=torch.uint8, device=dev)
+    rs.image = torch.empty(sz[2], dtype=torch.uint8, device=dev)
+    rs.radii = torch.empty(N, dtype=torch.int32, device=dev)
+    rs.counters = torch.empty(2, dtype=torch.int32, device=dev)
+    rs.cap = cap
+    rs.bg, rs.view, rs.proj, rs.campos = bg, view, proj, campos
+    rs.num_rendered = -1
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+    alpha = torch.empty(H, W, dtype=torch.float32, device=dev)
+    p = _lib.ptr
+    _lib.check(_lib.lib().fs_raster_forward(
+        C.byref(dims), p(means3D), p(cov3D), p(shs), p(colors), p(opacities), p(bg), p(view), p(proj),
+        p(campos), p(rs.geom), p(rs.binning), p(rs.image), p(st.scratch), cap, p(color), p(depth),
+        p(alpha), p(rs.radii), p(rs.counters), _lib.current_stream()), "fs_raster_forward")
+    return rs, color, depth, alpha
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    if t.device.type != "cuda":
+        raise RuntimeError(f"freesplat_amd rasterizer: `{name}` must live on a HIP device "
+                           f"(got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"freesplat_amd rasterizer: `{name}` must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+def make_dims(N, M, settings: GaussianRasterizationSettings) -> _lib.RasterDims:
+    d = _lib.RasterDims()
+    d.N, d.M = int(N), int(M)
+    d.H, d.W = int(settings.image_height), int(settings.image_width)
+    d.sh_degree = int(settings.sh_degree)
+    d.tanfovx, d.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
+    return d
+
+
+def rasterize_forward_checked(dims, means3D, cov3D, shs, colors, opacities, bg, view, proj, campos):
+    """Forward + capacity check (one host sync on the 8-byte counter pair), retrying once with the
+    exact capacity when the instance list overflowed."""
+    st = _state(means3D.device)
+    cap = default_capacity(dims.N, st)
+    rs, color, depth, alpha = _launch_forward(dims, means3D, cov3D, shs, colors, opacities, bg, view,
+                                              proj, campos, cap)
+    n_inst, overflow = (int(x) & 0xFFFFFFFF for x in rs.counters.tolist())
+    if overflow:
+        cap = n_inst + 1024
+        rs, color, depth, alpha = _launch_forward(dims, means3D, cov3D, shs, colors, opacities, bg,
+                                                  view, proj, campos, cap)
+        n_inst, overflow = (int(x) & 0xFFFFFFFF for x in rs.counters.tolist())
+        if overflow:
+            raise _lib.FreeSplatHipError("rasterizer instance list overflowed twice")
+    rs.num_rendered = n_inst
+    st.last_instances = n_inst
+    return rs, color, depth, alpha
+
+
+def rasterize_backward(rs: RasterState, means3D, cov3D, shs, colors, g_color, g_depth, out=None,
+                       accumulate: bool = False):
+    """Launch the backward of one view.  `out` = dict of preallocated gradient tensors (for the
+    multi-view accumulate path) or None to allocate."""
+    dev = means3D.device
+    d = rs.dims
+    N = d.N
+    if out is None:
+        out = dict(
+            means3D=torch.empty(N, 3, dtype=torch.float32, device=dev),
+            means2D=torch.empty(N, 3, dtype=torch.float32, device=dev),
+            cov3D=torch.empty(N, 6, dtype=torch.float32, device=dev),
+            shs=None if shs is None else torch.empty_like(shs),
+            colors=None if colors is None else torch.empty(N, 3, dtype=torch.float32, device=dev),
+            opacities=torch.empty(N, dtype=torch.float32, device=dev),
+        )
+    scratch = torch.empty(max(N, 1) * 12, dtype=torch.float32, device=dev)
+    if g_color is None:
+        g_color = torch.zeros(3, d.H, d.W, dtype=torch.float32, device=dev)
+    g_color = g_color.contiguous()
+    if g_depth is not None:
+        g_depth = g_depth.contiguous()
+    p = _lib.ptr
+    _lib.check(_lib.lib().fs_raster_backward(
+        C.byref(d), p(means3D), p(cov3D), p(shs), p(colors), p(rs.bg), p(rs.view), p(rs.proj),
+        p(rs.campos), p(rs.geom), p(rs.binning), p(rs.image), p(g_color), p(g_depth), p(scratch),
+        p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]), p(out["shs"]), p(out["colors"]),
+        p(out["opacities"]), 1 if accumulate else 0, _lib.current_stream()), "fs_raster_backward")
+    return out
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, settings):
+        N = means3D.shape[0]
+        M = 0 if shs is None else shs.shape[1]
+        dims = make_dims(N, M, settings)
+        bg = _f32c(settings.bg, "bg")
+        view = _f32c(settings.viewmatrix, "viewmatrix")
+        proj = _f32c(settings.projmatrix, "projmatrix")
+        campos = _f32c(settings.campos, "campos")
+        rs, color, depth, alpha = rasterize_forward_checked(dims, means3D, cov3D, shs, colors_precomp,
+                                                            opacities, bg, view, proj, campos)
+        ctx.rs = rs
+        ctx.opac_shape = None
+        ctx.save_for_backward(means3D, cov3D, shs, colors_precomp)
+        ctx.mark_non_differentiable(rs.radii)
+        ctx.set_materialize_grads(False)
+        return color, rs.radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii, g_depth, g_alpha):
+        means3D, cov3D, shs, colors = ctx.saved_tensors
+        if g_alpha is not None:
+            raise NotImplementedError("gradient through the accumulated-alpha output is not supported "
+                                      "(no reference caller uses it; cuda_splatting.py:120)")
+        if g_color is None and g_depth is None:
+            return (None,) * 7
+        g = rasterize_backward(ctx.rs, means3D, cov3D, shs, colors, g_color, g_depth)
+        return g["means3D"], g["means2D"], g["shs"], g["colors"], g["opacities"], g["cov3D"], None
+
+
+def build_cov3d(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
+    """cov3D 6-vector from scales [N,3] and rotations [N,4] (w,x,y,z) -- the (scales, rotations)
+    input form of the original extension; plain differentiable torch ops (host-side plumbing, not
+    on FreeSplat's path, which always passes cov3D_precomp: cuda_splatting.py:126)."""
+    q = rotations / rotations.norm(dim=-1, keepdim=True)
+    r, x, y, z = q.unbind(-1)
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    Mx = R * (scales * scale_modifier)[:, None, :]
+    S = Mx @ Mx.transpose(1, 2)
+    i, j = torch.triu_indices(3, 3)
+    return S[:, i, j]
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        s = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        means3D = _f32c(means3D, "means3D")
+        N = means3D.shape[0]
+        if cov3D_precomp is None:
+            cov3D_precomp = build_cov3d(scales, rotations, float(s.scale_modifier))
+        cov3D = _f32c(cov3D_precomp, "cov3D_precomp").reshape(N, 6)
+        opac = _f32c(opacities, "opacities").reshape(N)
+        if shs is not None:
+            shs = _f32c(shs, "shs")
+            if shs.dim() != 3 or shs.shape[0] != N or shs.shape[2] != 3:
+                raise RuntimeError(f"shs must be [N, M, 3], got {tuple(shs.shape)}")
+            if (int(s.sh_degree) + 1) ** 2 > shs.shape[1] or int(s.sh_degree) > 3:
+                raise RuntimeError(f"sh_degree {s.sh_degree} unsupported for shs with {shs.shape[1]} coefficients "
+                                   "(degree <= 3)")
+        else:
+            colors_precomp = _f32c(colors_precomp, "colors_precomp").reshape(N, 3)
+        if means2D is None:
+            means2D = torch.zeros(N, 3, dtype=torch.float32, device=means3D.device)
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opac, cov3D, s)
+
+
+# --- debug views into the opaque buffers (tests only) -------------------------------------------
+def debug_state(rs: RasterState) -> dict:
+    """Copy the forward's internal state to host numpy arrays (test helper)."""
+    import numpy as np
+    d = rs.dims
+    T = ((d.W + 15) // 16) * ((d.H + 15) // 16)
+    off_bytes = ((T + 1) * 4 + 255) // 256 * 256
+    binning = rs.binning.cpu().numpy()
+    offsets = binning[: (T + 1) * 4].view(np.uint32).copy()
+    I = int(offsets[-1])
+    point_list = binning[off_bytes: off_bytes + I * 4].view(np.uint32).copy()
+    geom = rs.geom.cpu().numpy()
+    N = d.N
+    rec = geom[: N * 48].view(np.float32).reshape(N, 12).copy()
+    o1 = (N * 48 + 255) // 256 * 256
+    rect = geom[o1: o1 + N * 8].view(np.uint16).reshape(N, 4).copy()
+    o2 = o1 + (N * 8 + 255) // 256 * 256
+    clamp = geom[o2: o2 + N].copy()
+    P = d.H * d.W
+    img = rs.image.cpu().numpy()
+    final_T = img[: P * 4].view(np.float32).reshape(d.H, d.W).copy()
+    o3 = (P * 4 + 255) // 256 * 256
+    n_contrib = img[o3: o3 + P * 4].view(np.int32).reshape(d.H, d.W).copy()
+    return dict(offsets=offsets, point_list=point_list, rec=rec, rect=rect, clamp=clamp,
+                final_T=final_T, n_contrib=n_contrib, radii=rs.radii.cpu().numpy(),
+                num_rendered=I)

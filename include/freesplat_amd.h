@@ -1,0 +1,121 @@
+/*
+ * freesplat_amd.h -- C ABI of libfreesplat_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary of the FreeSplat hot path.  Every entry point takes plain
+ * device pointers + sizes + a hipStream_t (passed as void*), returns an int status
+ * (0 = ok, <0 = FS_ERR_*), performs NO host synchronisation and NO allocation, and is
+ * therefore stream-ordered and hipGraph-capturable.  All tensors are dense, row-major,
+ * fp32 unless noted.  Nothing here depends on torch.
+ *
+ * Reference interfaces replaced (paths relative to the FreeSplat tree):
+ *   fs_raster_forward / fs_raster_backward
+ *       the un-vendored CUDA extension `diff_gaussian_rasterization_depth`
+ *       (requirements.txt:17) as called from src/model/decoder/cuda_splatting.py:100-127
+ *       (GaussianRasterizationSettings 12 fields + GaussianRasterizer.forward 6 tensors ->
+ *       (color[3,H,W], radii[N], depth[H,W], aux)), and its autograd backward.
+ *   fs_cost_volume_forward
+ *       AVGFeatureVolumeManager.build_cost_volume,
+ *       src/model/encoder/modules/cost_volume.py:429-619 (+ sr_utils/geometry_utils.py:22-89,
+ *       src/model/encoder/modules/networks.py:218-236).
+ *   fs_ptf_*
+ *       the device steps of EncoderFreeSplat.fuse_gaussians,
+ *       src/model/encoder/encoder_freesplat.py:431-522.
+ */
+#ifndef FREESPLAT_AMD_H
+#define FREESPLAT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_OK 0
+#define FS_ERR_INVALID_ARG (-1)
+#define FS_ERR_LAUNCH (-2)
+#define FS_ERR_UNSUPPORTED (-3)
+
+#define FS_TILE 16 /* rasterizer tile edge in pixels (16x16 = 4 wavefronts of 64) */
+
+/* Library / build identification: "freesplat_amd <ver> gfx950". */
+const char* fs_version(void);
+/* Last HIP error string observed by a failing call on this thread (never NULL). */
+const char* fs_last_error(void);
+
+/* Optional per-kernel timing: while enabled, every kernel launch of this library is bracketed by a
+ * hipEvent pair recorded on the launch stream (stream-ordered, no sync).  fs_profile_collect()
+ * synchronises the recorded events, sums milliseconds / launch counts per stage into the first n
+ * slots (stage i is named fs_profile_stage_name(i), NULL past the last stage) and resets. */
+int fs_profile_enable(int on);
+int fs_profile_collect(int n, float* ms_total, int32_t* launches);
+const char* fs_profile_stage_name(int i);
+
+/* ------------------------------------------------------------------------------------ *
+ * Rasterizer                                                                            *
+ * ------------------------------------------------------------------------------------ */
+
+/* Scalars of GaussianRasterizationSettings (cuda_splatting.py:100-113).  The tensor-valued
+ * settings (bg[3], viewmatrix[16], projmatrix[16], campos[3]) stay on the device and are
+ * passed as pointers so that no device->host copy is ever needed. */
+typedef struct fs_raster_dims {
+    int32_t N;         /* gaussians */
+    int32_t M;         /* SH coefficients per colour channel stored in `shs` ([N, M, 3]); 0 with colors_precomp */
+    int32_t H, W;      /* image_height, image_width */
+    int32_t sh_degree; /* active SH degree, 0..3, (sh_degree+1)^2 <= M */
+    float tanfovx, tanfovy;
+} fs_raster_dims;
+
+/* Byte sizes of the four caller-owned device buffers for (N, H, W, instance capacity):
+ *   out[0] geom    : per-Gaussian screen-space state            (saved for backward)
+ *   out[1] binning : per-tile ranges + depth-sorted id list      (saved for backward)
+ *   out[2] image   : per-pixel final transmittance + n_contrib   (saved for backward)
+ *   out[3] scratch : sort keys, tile counters                    (reusable after the call)
+ * `inst_capacity` bounds the number of (gaussian, tile) instances; see fs_raster_forward. */
+int fs_raster_buffer_sizes(int32_t N, int32_t H, int32_t W, int64_t inst_capacity, size_t out[4]);
+
+/*
+ * Forward.  Inputs (device): means3D[N,3], cov3D[N,6] (upper-triangular xx,xy,xz,yy,yz,zz),
+ * exactly one of shs[N,M,3] / colors_precomp[N,3], opacities[N], bg[3], viewmatrix[16],
+ * projmatrix[16] (both as torch passes them: transposed, i.e. column-major), campos[3].
+ * Outputs (device): out_color[3,H,W], out_depth[H,W] (sum z*alpha*T, un-normalised),
+ * out_alpha[H,W] (1 - T_final), radii[N] (int32, 0 = culled),
+ * counters[2] (uint32): {number of instances I, overflow flag (I > inst_capacity)}.
+ * If the overflow flag is set the image outputs are undefined and the caller must retry
+ * with inst_capacity >= I (the library never allocates).
+ */
+int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
+                      const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* bg, const float* viewmatrix, const float* projmatrix,
+                      const float* campos, void* geom, void* binning, void* image, void* scratch,
+                      int64_t inst_capacity, float* out_color, float* out_depth, float* out_alpha,
+                      int32_t* radii, uint32_t* counters, void* stream);
+
+/*
+ * Backward.  dL_dcolor[3,H,W] (required), dL_ddepth[H,W] (may be NULL).  geom/binning/image
+ * are the buffers filled by the matching forward.  `grad_scratch` >= N*12*4 bytes.
+ * Outputs (device; overwritten when accumulate == 0, added to when accumulate != 0 -- the
+ * multi-view decoder sums the per-view gradients of one shared Gaussian set this way):
+ * dL_dmeans3D[N,3], dL_dmeans2D[N,3] (screen-space grad
+ * sink, z = 0; cuda_splatting.py:94-98), dL_dcov3D[N,6] (off-diagonals carry both symmetric
+ * positions), dL_dshs[N,M,3] or dL_dcolors[N,3] (the other NULL), dL_dopacities[N].
+ */
+int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
+                       const float* shs, const float* colors_precomp, const float* bg,
+                       const float* viewmatrix, const float* projmatrix, const float* campos,
+                       const void* geom, const void* binning, const void* image,
+                       const float* dL_dcolor, const float* dL_ddepth, void* grad_scratch,
+                       float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs,
+                       float* dL_dcolors, float* dL_dopacities, int accumulate, void* stream);
+
+/* Debug/test accessors into the opaque buffers (device pointers, no copies). */
+const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t H, int32_t W);  /* [T+1] offsets */
+const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] ids */
+const float* fs_raster_geom_records(const void* geom);                             /* [N,12] */
+const float* fs_raster_final_T(const void* image);                                 /* [H*W] */
+const int32_t* fs_raster_n_contrib(const void* image, int32_t H, int32_t W);       /* [H*W] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREESPLAT_AMD_H */
