@@ -187,7 +187,11 @@ def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload):
         if n == 0:
             st0 = st
         n += 1
-    g = gpu_color0.detach().cpu().numpy()
+    # parity of the kernels: the SAME (CPU-framed) inputs through the product rasterizer
+    import torch
+    from util_raster import hip_forward
+    (gc, _, _, _), _ = hip_forward(view_inputs(scene, cams_all, 0, H, W), torch.device("cuda", torch.cuda.current_device()))
+    g = gc.detach().cpu().numpy()
     err = float(np.abs(g - st0["color"]).max())
     mse = float(((g.clip(0, 1) - st0["color"].clip(0, 1)) ** 2).mean())
     psnr = None if mse == 0 else float(-10 * np.log10(mse))

@@ -20,7 +20,11 @@ class FreeSplatHipError(RuntimeError):
 
 class RasterDims(C.Structure):
     _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("sh_degree", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float)]
+                ("sh_degree", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("flags", C.c_int32)]
+
+
+RASTER_TILE_CULL = 1
 
 
 def build(force: bool = False) -> str:

@@ -63,6 +63,62 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Tile binning helpers shared by the count (preprocess) and emit passes.
+// ------------------------------------------------------------------------------------------
+constexpr int kBinLds = 4096;  // tiles of a workgroup's bounding box whose counters live in LDS
+
+// Can any pixel of tile (tx,ty) reach alpha >= 1/255 from this Gaussian?  Conservative (never
+// culls a contributing tile): max over the tile's pixel rectangle of the exponent `power`
+// (a concave quadratic) against the record's skip threshold r1.z (which already carries a safety
+// margin).  Instances removed here could only ever be skipped by the blend loop, so images are
+// unchanged bit for bit; the retained instances keep the reference's (tile, depth, index) order.
+__device__ __forceinline__ bool tile_reachable(const float4 r0, const float4 r1, int tx, int ty)
+{
+    const float ulo = (float)(tx * kTile) - r0.x, uhi = ulo + (float)(kTile - 1);
+    const float vlo = (float)(ty * kTile) - r0.y, vhi = vlo + (float)(kTile - 1);
+    if (ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f) return true;  // centre inside
+    const float a = -r0.z, c = -r0.w, b = -r1.x;  // q(u,v) = a u^2 + c v^2 + b u v = -power
+    float qmin = 3.0e38f;
+    {   // edges u = const
+        const float vs_lo = fminf(vhi, fmaxf(vlo, -b * ulo / (2.0f * c)));
+        const float vs_hi = fminf(vhi, fmaxf(vlo, -b * uhi / (2.0f * c)));
+        qmin = fminf(qmin, a * ulo * ulo + c * vs_lo * vs_lo + b * ulo * vs_lo);
+        qmin = fminf(qmin, a * uhi * uhi + c * vs_hi * vs_hi + b * uhi * vs_hi);
+        const float us_lo = fminf(uhi, fmaxf(ulo, -b * vlo / (2.0f * a)));
+        const float us_hi = fminf(uhi, fmaxf(ulo, -b * vhi / (2.0f * a)));
+        qmin = fminf(qmin, a * us_lo * us_lo + c * vlo * vlo + b * us_lo * vlo);
+        qmin = fminf(qmin, a * us_hi * us_hi + c * vhi * vhi + b * us_hi * vhi);
+    }
+    // power_max = -qmin; cull only when certainly below the threshold (NaN -> keep)
+    const float slack = 1e-3f * (1.0f + fabsf(r1.z));
+    return !(-qmin < r1.z - slack);
+}
+
+// Workgroup-private tile counters: the 256 Gaussians of a workgroup are neighbours on screen
+// (the encoder emits them in pixel order), so their tile rectangles span a small bounding box.
+// Counting happens with LDS atomics inside that box and only one global atomic per touched
+// tile and workgroup leaves the CU.  Falls back to direct global atomics when the box is larger
+// than kBinLds tiles.  Returns the box in bx0,by0,bw,bh (bw*bh == 0: nothing to bin).
+struct BinBox { int x0, y0, w, h; bool lds; };
+
+__device__ __forceinline__ BinBox block_bin_box(int* s_box, bool valid, ushort4 rc)
+{
+    if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = 0; s_box[3] = 0; }
+    __syncthreads();
+    if (valid) {
+        atomicMin(&s_box[0], (int)rc.x); atomicMin(&s_box[1], (int)rc.y);
+        atomicMax(&s_box[2], (int)rc.z); atomicMax(&s_box[3], (int)rc.w);
+    }
+    __syncthreads();
+    BinBox b;
+    b.x0 = s_box[0]; b.y0 = s_box[1];
+    b.w = max(0, s_box[2] - b.x0); b.h = max(0, s_box[3] - b.y0);
+    b.lds = (b.w * b.h) <= kBinLds;
+    return b;
+}
+
 __global__ __launch_bounds__(256) void preprocess_kernel(
     fs_raster_dims d, const float* __restrict__ means3D, const float* __restrict__ cov3D,
     const float* __restrict__ shs, const float* __restrict__ colors,
@@ -82,7 +138,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     stage_rows(l_mean, means3D, base, cnt, 3);
     __syncthreads();
     const int t = threadIdx.x;
-    if (t >= cnt) return;
+    const bool live = t < cnt;
     const int i = base + t;
 
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
@@ -90,9 +146,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     uint8_t cb = 0;
     int rad = 0;
 
-    const float3 p = make_float3(l_mean[3 * t], l_mean[3 * t + 1], l_mean[3 * t + 2]);
+    const float3 p = live ? make_float3(l_mean[3 * t], l_mean[3 * t + 1], l_mean[3 * t + 2])
+                          : make_float3(0.0f, 0.0f, 0.0f);
     const float3 pv = xform43(view, p);
-    if (pv.z > 0.2f) {
+    if (live && pv.z > 0.2f) {
         const float4 ph = xform44(proj, p);
         const float pw = 1.0f / (ph.w + 0.0000001f);
         const float ndcx = ph.x * pw, ndcy = ph.y * pw;
@@ -152,17 +209,45 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1,
                                     (unsigned short)y1);
                 rad = r;
-                for (int y = y0; y < y1; ++y)
-                    for (int x = x0; x < x1; ++x) atomicAdd(&tile_counts[y * gx + x], 1u);
             }
         }
     }
-    g.rec[3 * (size_t)i + 0] = r0;
-    g.rec[3 * (size_t)i + 1] = r1;
-    g.rec[3 * (size_t)i + 2] = r2;
-    g.rect[i] = rect;
-    g.clamp[i] = cb;
-    radii[i] = rad;
+    if (live) {
+        g.rec[3 * (size_t)i + 0] = r0;
+        g.rec[3 * (size_t)i + 1] = r1;
+        g.rec[3 * (size_t)i + 2] = r2;
+        g.rect[i] = rect;
+        g.clamp[i] = cb;
+        radii[i] = rad;
+    }
+
+    // ---- per-tile instance counts (the staging LDS is dead from here on) ----
+    __syncthreads();
+    int* s_box = (int*)lds;
+    uint32_t* s_cnt = (uint32_t*)lds + 16;
+    const bool valid = rad > 0;
+    const bool cull = (d.flags & FS_RASTER_TILE_CULL) != 0;
+    const int gx = (d.W + kTile - 1) / kTile;
+    const BinBox bb = block_bin_box(s_box, valid, rect);
+    if (bb.w * bb.h == 0) return;
+    if (bb.lds) {
+        for (int k = t; k < bb.w * bb.h; k += 256) s_cnt[k] = 0;
+        __syncthreads();
+        if (valid)
+            for (int y = rect.y; y < rect.w; ++y)
+                for (int x = rect.x; x < rect.z; ++x)
+                    if (!cull || tile_reachable(r0, r1, x, y))
+                        atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
+        __syncthreads();
+        for (int k = t; k < bb.w * bb.h; k += 256) {
+            const uint32_t c = s_cnt[k];
+            if (c) atomicAdd(&tile_counts[(bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w], c);
+        }
+    } else if (valid) {
+        for (int y = rect.y; y < rect.w; ++y)
+            for (int x = rect.x; x < rect.z; ++x)
+                if (!cull || tile_reachable(r0, r1, x, y)) atomicAdd(&tile_counts[y * gx + x], 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -204,24 +289,59 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
 // ------------------------------------------------------------------------------------------
 // emit: one key per (gaussian, tile) instance
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_kernel(int N, int gx, GeomView g,
+__global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, GeomView g,
                                                    const uint32_t* __restrict__ offsets,
                                                    uint32_t* __restrict__ cursors,
                                                    unsigned long long* __restrict__ keys,
                                                    unsigned long long cap)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const ushort4 rc = g.rect[i];
-    if (rc.z <= rc.x || rc.w <= rc.y) return;
-    const float z = g.rec[3 * (size_t)i + 1].w;
-    const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (uint32_t)i;
-    for (int y = rc.y; y < rc.w; ++y)
-        for (int x = rc.x; x < rc.z; ++x) {
-            const int t = y * gx + x;
-            const unsigned long long slot = (unsigned long long)offsets[t] + atomicAdd(&cursors[t], 1u);
-            if (slot < cap) keys[slot] = key;
+    __shared__ int s_box[4];
+    __shared__ uint32_t s_cnt[kBinLds];   // per-tile count, then per-tile running rank
+    __shared__ uint32_t s_base[kBinLds];  // first slot of this workgroup inside the tile's range
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 256 + t;
+    const bool live = i < N;
+    const ushort4 rc = live ? g.rect[i] : make_ushort4(0, 0, 0, 0);
+    const bool valid = rc.z > rc.x && rc.w > rc.y;
+    const bool cull = (flags & FS_RASTER_TILE_CULL) != 0;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+    if (valid) { r0 = g.rec[3 * (size_t)i]; r1 = g.rec[3 * (size_t)i + 1]; }
+    const unsigned long long key = ((unsigned long long)__float_as_uint(r1.w) << 32) | (uint32_t)i;
+    const BinBox bb = block_bin_box(s_box, valid, rc);
+    if (bb.w * bb.h == 0) return;
+    if (bb.lds) {
+        for (int k = t; k < bb.w * bb.h; k += 256) s_cnt[k] = 0;
+        __syncthreads();
+        if (valid)
+            for (int y = rc.y; y < rc.w; ++y)
+                for (int x = rc.x; x < rc.z; ++x)
+                    if (!cull || tile_reachable(r0, r1, x, y))
+                        atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
+        __syncthreads();
+        for (int k = t; k < bb.w * bb.h; k += 256) {
+            const uint32_t c = s_cnt[k];
+            const int tile = (bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w;
+            s_base[k] = c ? offsets[tile] + atomicAdd(&cursors[tile], c) : 0u;
+            s_cnt[k] = 0;
         }
+        __syncthreads();
+        if (valid)
+            for (int y = rc.y; y < rc.w; ++y)
+                for (int x = rc.x; x < rc.z; ++x)
+                    if (!cull || tile_reachable(r0, r1, x, y)) {
+                        const int k = (y - bb.y0) * bb.w + (x - bb.x0);
+                        const unsigned long long slot = (unsigned long long)s_base[k] + atomicAdd(&s_cnt[k], 1u);
+                        if (slot < cap) keys[slot] = key;
+                    }
+    } else if (valid) {
+        for (int y = rc.y; y < rc.w; ++y)
+            for (int x = rc.x; x < rc.z; ++x)
+                if (!cull || tile_reachable(r0, r1, x, y)) {
+                    const int tl = y * gx + x;
+                    const unsigned long long slot = (unsigned long long)offsets[tl] + atomicAdd(&cursors[tl], 1u);
+                    if (slot < cap) keys[slot] = key;
+                }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -437,7 +557,8 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     }
     const int M = shs ? d.M : 0;
     if (d.N > 0) {
-        const size_t lds = (size_t)(((256 * M * 3 + 3) & ~3) + 256 * 6 + 256 * 3) * sizeof(float);
+        size_t lds = (size_t)(((256 * M * 3 + 3) & ~3) + 256 * 6 + 256 * 3) * sizeof(float);
+        if (lds < (size_t)(16 + kBinLds) * 4) lds = (size_t)(16 + kBinLds) * 4;
         {
             ScopedStage prof_(kStPreprocess, st);
             hipLaunchKernelGGL(preprocess_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, means3D,
@@ -455,7 +576,7 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     if (d.N > 0) {
         {
             ScopedStage prof_(kStEmit, st);
-            hipLaunchKernelGGL(emit_kernel, dim3((d.N + 255) / 256), dim3(256), 0, st, d.N, gx, g, offsets,
+            hipLaunchKernelGGL(emit_kernel, dim3((d.N + 255) / 256), dim3(256), 0, st, d.N, gx, d.flags, g, offsets,
                                cursors, keys, (unsigned long long)cap);
         }
         FS_CHECK_LAUNCH("emit");

@@ -17,12 +17,19 @@ or eager fallback -- a CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
 from torch import Tensor, nn
 
 from . import _lib
+
+
+# Precise tile culling (include/freesplat_amd.h FS_RASTER_TILE_CULL): images unchanged bit for bit,
+# tile lists shrink to the instances that can actually contribute.  FREESPLAT_TILE_CULL=0 keeps the
+# reference's full 3-sigma-square lists.
+TILE_CULL = os.environ.get("FREESPLAT_TILE_CULL", "1") != "0"
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -124,6 +131,7 @@ def make_dims(N, M, settings: GaussianRasterizationSettings) -> _lib.RasterDims:
     d.H, d.W = int(settings.image_height), int(settings.image_width)
     d.sh_degree = int(settings.sh_degree)
     d.tanfovx, d.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
+    d.flags = _lib.RASTER_TILE_CULL if TILE_CULL else 0
     return d
 
 

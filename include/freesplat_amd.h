@@ -64,7 +64,14 @@ typedef struct fs_raster_dims {
     int32_t H, W;      /* image_height, image_width */
     int32_t sh_degree; /* active SH degree, 0..3, (sh_degree+1)^2 <= M */
     float tanfovx, tanfovy;
+    int32_t flags;     /* FS_RASTER_* bits */
 } fs_raster_dims;
+
+/* Drop (gaussian, tile) instances that provably cannot reach alpha >= 1/255 anywhere in the tile
+ * (conservative bound on the exponent over the tile's pixel rectangle).  Images are bit-identical
+ * with and without; without it the tile lists equal the reference's 3-sigma-square lists, with it
+ * they are an order-preserving subsequence. */
+#define FS_RASTER_TILE_CULL 1
 
 /* Byte sizes of the four caller-owned device buffers for (N, H, W, instance capacity):
  *   out[0] geom    : per-Gaussian screen-space state            (saved for backward)

@@ -40,18 +40,58 @@ def _internal_state(vi, device):
     return debug_state(out[0].grad_fn.rs), out, leaves
 
 
+def _set_cull(monkeypatch, on):
+    from freesplat_amd import rasterizer as R
+    monkeypatch.setattr(R, "TILE_CULL", on)
+
+
+def _check_lists(dbg, st, W, H, cull, sample=None):
+    """cull off: tile ranges and id lists equal the oracle's (= reference semantics).
+    cull on : every tile list is an order-preserving subsequence of the oracle's, and every dropped
+    (gaussian, tile) instance has alpha < 1/255 on all 256 pixels of its tile (float64 check)."""
+    if not cull:
+        assert dbg["num_rendered"] == st["num_rendered"]
+        np.testing.assert_array_equal(dbg["offsets"][:-1], st["ranges"][:, 0])
+        np.testing.assert_array_equal(dbg["offsets"][1:], st["ranges"][:, 1])
+        np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+        np.testing.assert_array_equal(dbg["n_contrib"], st["n_contrib"])
+        return 1.0
+    T = st["ranges"].shape[0]
+    g_tile = np.repeat(np.arange(T, dtype=np.int64), np.diff(dbg["offsets"].astype(np.int64)))
+    o_tile = np.repeat(np.arange(T, dtype=np.int64), (st["ranges"][:, 1] - st["ranges"][:, 0]).astype(np.int64))
+    g_id, o_id = dbg["point_list"].astype(np.int64), st["point_list"].astype(np.int64)
+    g_comp, o_comp = (g_tile << 32) | g_id, (o_tile << 32) | o_id
+    kept = np.isin(o_comp, g_comp)
+    assert np.isin(g_comp, o_comp).all() and kept.sum() == len(g_comp)
+    np.testing.assert_array_equal(o_comp[kept], g_comp)  # same relative order
+    rm = np.nonzero(~kept)[0]
+    if sample is not None and len(rm) > sample:
+        rm = np.random.default_rng(0).choice(rm, sample, replace=False)
+    gx = (W + 15) // 16
+    ids, tiles = o_id[rm], o_tile[rm]
+    ys, xs = np.mgrid[0:16, 0:16]
+    pxs = (tiles % gx)[:, None] * 16 + xs.reshape(1, -1)
+    pys = (tiles // gx)[:, None] * 16 + ys.reshape(1, -1)
+    co = st["conic_opacity"].astype(np.float64)[ids]
+    dx = st["means2D"].astype(np.float64)[ids, 0:1] - pxs
+    dy = st["means2D"].astype(np.float64)[ids, 1:2] - pys
+    power = -0.5 * (co[:, 0:1] * dx * dx + co[:, 2:3] * dy * dy) - co[:, 1:2] * dx * dy
+    alpha = co[:, 3:4] * np.exp(np.minimum(power, 0.0))
+    inside = (pxs < W) & (pys < H)
+    assert (alpha[inside & (power <= 0)] < 1.0 / 255.0).all()
+    return len(g_comp) / max(len(o_comp), 1)
+
+
+@pytest.mark.parametrize("cull", [False, True])
 @pytest.mark.parametrize("H,W,N,seed", [(64, 80, 600, 7), (72, 100, 3000, 3), (256, 256, 20000, 5), (16, 16, 50, 1)])
-def test_forward_bit_exact_and_ordering(hip_device, H, W, N, seed):
+def test_forward_bit_exact_and_ordering(hip_device, monkeypatch, H, W, N, seed, cull):
+    _set_cull(monkeypatch, cull)
     scene, cams = small_scene(N=N, H=H, W=W, seed=seed)
     vi = view_inputs(scene, cams, 1, H, W, bg=(0.1, 0.2, 0.3))
     st, _, _ = _check_forward(vi, hip_device)
     dbg, _, _ = _internal_state(vi, hip_device)
-    assert dbg["num_rendered"] == st["num_rendered"]
-    np.testing.assert_array_equal(dbg["offsets"][:-1], st["ranges"][:, 0])
-    np.testing.assert_array_equal(dbg["offsets"][1:], st["ranges"][:, 1])
-    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])  # identical tile/depth ordering
+    _check_lists(dbg, st, W, H, cull)  # identical tile/depth ordering
     np.testing.assert_array_equal(dbg["final_T"], st["final_T"])
-    np.testing.assert_array_equal(dbg["n_contrib"], st["n_contrib"])
     np.testing.assert_array_equal(dbg["rect"].astype(np.int32), st["rect"])
     np.testing.assert_array_equal(dbg["rec"][:, 0:2], st["means2D"])
     np.testing.assert_array_equal(dbg["rec"][:, 8:11], st["rgb"])
@@ -89,8 +129,9 @@ def test_empty_and_all_culled(hip_device):
     assert torch.equal(color.cpu(), torch.tensor([0.3, 0.1, 0.2])[:, None, None].expand(3, 32, 32))
 
 
-def test_long_tile_lists_global_sort_path(hip_device):
+def test_long_tile_lists_global_sort_path(hip_device, monkeypatch):
     """> 4096 instances in one tile: exercises the in-HBM sort fallback and many render rounds."""
+    _set_cull(monkeypatch, False)
     H = W = 32
     scene, cams = small_scene(N=6000, H=H, W=W, seed=4)
     scene["covariances"] = scene["covariances"] * 400.0  # every Gaussian covers the whole image
@@ -99,10 +140,12 @@ def test_long_tile_lists_global_sort_path(hip_device):
     st, _, _ = _check_forward(vi, hip_device)
     assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 4096
     dbg, _, _ = _internal_state(vi, hip_device)
-    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    assert np.diff(dbg["offsets"].astype(np.int64)).max() > 4096
+    _check_lists(dbg, st, W, H, False)
 
 
-def test_depth_ties_break_by_index(hip_device):
+def test_depth_ties_break_by_index(hip_device, monkeypatch):
+    _set_cull(monkeypatch, False)
     H = W = 32
     scene, cams = small_scene(N=64, H=H, W=W, seed=6)
     # duplicate every Gaussian: identical depth keys, order must follow the index
@@ -184,7 +227,9 @@ def test_render_views_equals_render_cuda_and_reference_framing(hip_device):
     # each view against the oracle, framed by the same host code on CPU
     for i in range(v):
         st = oracle_forward(view_inputs(scene, cams, i, H, W, bg=(0.2, 0.3, 0.4)))
-        np.testing.assert_array_equal(c1[i].detach().cpu().numpy(), st["color"])
+        # (the 4x4 inverses of the framing run on the GPU here and on the CPU for the oracle: ulp-level
+        # different matrices, so this comparison is to the north_star tolerance, not bit-exact)
+        assert np.abs(c1[i].detach().cpu().numpy() - st["color"]).max() <= ATOL_PIXEL
     dec = DecoderSplattingCUDA((0.2, 0.3, 0.4)).to(dev)
     gs = Gaussians(*(g[k][None] for k in ("means", "covariances", "harmonics", "opacities")))
     out = dec(gs, cam["extrinsics"][None], cam["intrinsics"][None], cam["near"][None], cam["far"][None], (H, W),
@@ -220,8 +265,8 @@ def test_full_size_parity_and_properties(hip_device, workload):
     psnr = float("inf") if mse == 0 else -10 * np.log10(mse)
     assert psnr > 80.0
     dbg, _, _ = _internal_state(vi, hip_device)
-    assert dbg["num_rendered"] == st["num_rendered"]
-    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    frac = _check_lists(dbg, st, W, H, True, sample=20000)
+    print(f"{workload}: instances kept by tile culling: {frac:.3f} of {st['num_rendered']}")
     # sortedness of every tile list by (depth bits, id)
     off, pl = dbg["offsets"].astype(np.int64), dbg["point_list"].astype(np.int64)
     key = (dbg["rec"][:, 7].view(np.uint32).astype(np.int64)[pl] << 32) | pl
