@@ -63,7 +63,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from freesplat_amd import _lib, synthetic
-    from freesplat_amd.decoder import render_views
+    from freesplat_amd.decoder import check_deferred, render_views
     from freesplat_amd.view_sharding import AsyncViewGather, allreduce_gaussian_grads, shard_range
 
     H, W, N = synthetic.WORKLOADS[args.workload]
@@ -94,8 +94,11 @@ def main():
                 allreduce_gaussian_grads([t.grad for t in g.values()])
             return color, depth
         with torch.no_grad():
+            # capacity check deferred to the end of the timed region (check_deferred below): the GPU
+            # queue stays full across steps; all launched work still completes inside the region
             color, depth = render_views(cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"],
-                                        (H, W), bg, g["means"], g["covariances"], g["harmonics"], g["opacities"])
+                                        (H, W), bg, g["means"], g["covariances"], g["harmonics"], g["opacities"],
+                                        check="deferred")
             if gather is not None:
                 gather.wait()  # previous step's gather must be done before its buffers are dropped
                 gather.launch(torch.cat([color, depth], dim=1))
@@ -111,6 +114,7 @@ def main():
         color, depth = step()
     if gather is not None:
         gather.wait()
+    check_deferred()
     barrier()
     profile = not args.no_profile
     if profile:
@@ -121,6 +125,7 @@ def main():
         color, depth = step()
     if gather is not None:
         gather.wait()
+    check_deferred()  # raises if any view of the timed region overflowed its instance capacity
     barrier()
     dt = time.perf_counter() - t0
     stages = {}

@@ -47,8 +47,8 @@ SIGNATURES = {
     "fs_profile_collect": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "fs_profile_stage_name": (C.c_char_p, [C.c_int]),
     "fs_raster_buffer_sizes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_size_t)]),
-    "fs_raster_forward": (C.c_int, [C.POINTER(RasterDims)] + [_VP] * 13 + [C.c_int64] + [_VP] * 6),
-    "fs_raster_backward": (C.c_int, [C.POINTER(RasterDims)] + [_VP] * 20 + [C.c_int, _VP]),
+    "fs_raster_forward": (C.c_int, [C.POINTER(RasterDims)] + [_VP] * 15 + [C.c_int64] + [_VP] * 6),
+    "fs_raster_backward": (C.c_int, [C.POINTER(RasterDims)] + [_VP] * 22 + [C.c_int, _VP]),
     "fs_raster_tile_ranges": (_VP, [_VP, C.c_int32, C.c_int32]),
     "fs_raster_point_list": (_VP, [_VP, C.c_int32, C.c_int32]),
     "fs_raster_geom_records": (_VP, [_VP]),

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     const float* __restrict__ dL_ddepth, float* __restrict__ grad)
 {
     __shared__ float4 s0[256], s1[256], s2[256];
-    __shared__ uint32_t s_id[256];
+    __shared__ uint32_t s_id[256];  // (id << 4) | quadrant mask
     __shared__ float s_acc[256 * 10];
     __shared__ int s_maxlast;
 
@@ -43,8 +43,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
     const int gx = (W + kTile - 1) / kTile;
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int px = tx * kTile + (tid & 15), py = ty * kTile + (tid >> 4);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);   // same 8x8 quadrant per wavefront
+    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);  // as the forward
+    const uint32_t qbit = 1u << wave;
     const bool inside = px < W && py < H;
     const float pfx = (float)px, pfy = (float)py;
     const uint32_t a = offsets[tile], b = offsets[tile + 1];
@@ -75,19 +77,26 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     for (int r = (maxlast - 1) >> 8; r >= 0; --r) {
         __syncthreads();  // previous batch fully flushed
         const int idx = (r << 8) + tid;
+        uint32_t wq = 0;
         if (idx < n) {
-            const uint32_t gid = point_list[a + idx];
-            const float4* q = rec + 3 * (size_t)gid;
-            s0[tid] = q[0];
-            s1[tid] = q[1];
-            s2[tid] = q[2];
-            s_id[tid] = gid;
+            wq = point_list[a + idx];
+            if (wq & 15u) {
+                const float4* q = rec + 3 * (size_t)(wq >> 4);
+                s0[tid] = q[0];
+                s1[tid] = q[1];
+                s2[tid] = q[2];
+            }
         }
+        s_id[tid] = wq;
 #pragma unroll
         for (int k = 0; k < 10; ++k) s_acc[k * 256 + tid] = 0.0f;
         __syncthreads();
         const int m = min(256, min(n, maxlast) - (r << 8));
-        for (int j = m - 1; j >= 0; --j) {
+        for (int c = (m - 1) & ~63; c >= 0; c -= 64) {
+          unsigned long long hits = __ballot((c + lane < m) && (s_id[c + lane] & qbit));
+          while (hits) {
+            const int j = c + 63 - __builtin_clzll(hits);  // back to front
+            hits &= ~(1ull << (j - c));
             const int contributor = (r << 8) + j + 1;
             const float4 g0 = s0[j], g1 = s1[j];
             const float dx = g0.x - pfx, dy = g0.y - pfy;
@@ -142,10 +151,11 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
                 atomicAdd(&s_acc[8 * 256 + j], v_b);
                 atomicAdd(&s_acc[9 * 256 + j], v_z);
             }
+          }
         }
         __syncthreads();
-        if (tid < m) {
-            float* gout = grad + (size_t)s_id[tid] * kGradStride;
+        if (tid < m && (s_id[tid] & 15u)) {
+            float* gout = grad + (size_t)(s_id[tid] >> 4) * kGradStride;
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
                 const float v = s_acc[k * 256 + tid];
@@ -201,7 +211,8 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float 
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     fs_raster_dims d, const float* __restrict__ means3D, const float* __restrict__ cov3D,
     const float* __restrict__ shs, const float* __restrict__ view, const float* __restrict__ proj,
-    const float* __restrict__ campos, GeomView g, const float* __restrict__ grad,
+    const float* __restrict__ campos, const float* __restrict__ tanfov_dev,
+    const float* __restrict__ scale_dev, GeomView g, const float* __restrict__ grad,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac,
     int accumulate)
@@ -213,6 +224,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const int i = base + t;
     const int per_sh = d.M * 3;
     const bool have_sh = shs != nullptr;
+    const float tanfovx = tanfov_dev ? tanfov_dev[0] : d.tanfovx;
+    const float tanfovy = tanfov_dev ? tanfov_dev[1] : d.tanfovy;
+    const float wscale = scale_dev ? scale_dev[0] : 1.0f;
 
     if (t < cnt) {
         float gm[3] = {0, 0, 0}, gcov[6] = {0, 0, 0, 0, 0, 0}, gop = 0.0f;
@@ -224,14 +238,20 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         const ushort4 rc = g.rect[i];
         if (rc.z > rc.x && rc.w > rc.y) {
             const float* ga = grad + (size_t)i * kGradStride;
-            const float3 p = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+            float3 p = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+            if (scale_dev) { p.x = p.x * wscale; p.y = p.y * wscale; p.z = p.z * wscale; }
             gop = ga[5];
             gm2x = ga[0]; gm2y = ga[1];
-            const float fx = (float)d.W / (2.0f * d.tanfovx), fy = (float)d.H / (2.0f * d.tanfovy);
+            const float fx = (float)d.W / (2.0f * tanfovx), fy = (float)d.H / (2.0f * tanfovy);
             float c3[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) c3[k] = cov3D[6 * (size_t)i + k];
-            const Cov2D cv = project_cov(view, p, c3, fx, fy, d.tanfovx, d.tanfovy);
+            if (scale_dev) {
+                const float s2 = wscale * wscale;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c3[k] = c3[k] * s2;
+            }
+            const Cov2D cv = project_cov(view, p, c3, fx, fy, tanfovx, tanfovy);
             const float a = cv.a, b = cv.b, c = cv.c;
             const float denom = a * c - b * b;
             const float d2inv = 1.0f / (denom * denom + 0.0000001f);
@@ -309,6 +329,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 gm[2] += (-dox * doz * gdv[0] - doy * doz * gdv[1] + (s2 - doz * doz) * gdv[2]) * inv32;
             }
         }
+        if (scale_dev) {
+            const float s2 = wscale * wscale;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gm[k] = gm[k] * wscale;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gcov[k] = gcov[k] * s2;
+        }
         if (accumulate) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) gm[k] += dL_dmeans3D[3 * (size_t)i + k];
@@ -358,6 +385,7 @@ using namespace fs;
 FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
                               const float* shs, const float* colors_precomp, const float* bg,
                               const float* viewmatrix, const float* projmatrix, const float* campos,
+                              const float* tanfov_dev, const float* scale_dev,
                               const void* geom, const void* binning, const void* image,
                               const float* dL_dcolor, const float* dL_ddepth, void* grad_scratch,
                               float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D,
@@ -397,7 +425,8 @@ FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, 
     {
         ScopedStage prof_(kStPreprocessBwd, st);
         hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, means3D,
-                           cov3D, shs, viewmatrix, projmatrix, campos, g, grad, dL_dmeans3D, dL_dmeans2D,
+                           cov3D, shs, viewmatrix, projmatrix, campos, tanfov_dev, scale_dev, g, grad, dL_dmeans3D,
+                           dL_dmeans2D,
                            dL_dcov3D, dL_dshs, dL_dcolors, dL_dopacities, accumulate);
     }
     FS_CHECK_LAUNCH("preprocess_bwd");

@@ -69,31 +69,49 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__
 // ------------------------------------------------------------------------------------------
 constexpr int kBinLds = 4096;  // tiles of a workgroup's bounding box whose counters live in LDS
 
-// Can any pixel of tile (tx,ty) reach alpha >= 1/255 from this Gaussian?  Conservative (never
-// culls a contributing tile): max over the tile's pixel rectangle of the exponent `power`
-// (a concave quadratic) against the record's skip threshold r1.z (which already carries a safety
-// margin).  Instances removed here could only ever be skipped by the blend loop, so images are
-// unchanged bit for bit; the retained instances keep the reference's (tile, depth, index) order.
-__device__ __forceinline__ bool tile_reachable(const float4 r0, const float4 r1, int tx, int ty)
+// Which 8x8-pixel quadrants of tile (tx,ty) can receive alpha >= 1/255 from this Gaussian?
+// bit q = (qy<<1)|qx.  Conservative (never drops a contributing quadrant): the maximum over the
+// quadrant's pixel-centre rectangle of the exponent `power` (a concave quadratic) is compared with
+// the record's skip threshold r1.z, which already carries a safety margin.  A (gaussian, tile)
+// instance whose mask is 0 could only ever be skipped by the blend loop, so dropping it leaves the
+// image unchanged bit for bit; retained instances keep the reference's (tile, depth, index) order.
+struct QuadForm {  // q(u,v) = a u^2 + c v^2 + b u v = -power, per Gaussian
+    float a, b, c, thr_slack, kv, ku;  // kv = -b/(2c): argmin_v q(u,.) = kv*u ; ku = -b/(2a)
+};
+__device__ __forceinline__ QuadForm quad_form(const float4 r0, const float4 r1)
 {
-    const float ulo = (float)(tx * kTile) - r0.x, uhi = ulo + (float)(kTile - 1);
-    const float vlo = (float)(ty * kTile) - r0.y, vhi = vlo + (float)(kTile - 1);
+    QuadForm f;
+    f.a = -r0.z; f.c = -r0.w; f.b = -r1.x;
+    f.thr_slack = r1.z - 1e-3f * (1.0f + fabsf(r1.z));
+    // approximate reciprocals are fine: an error d in the argmin raises q by O(d^2) << slack
+    f.kv = -f.b * __builtin_amdgcn_rcpf(2.0f * f.c);
+    f.ku = -f.b * __builtin_amdgcn_rcpf(2.0f * f.a);
+    return f;
+}
+__device__ __forceinline__ bool rect_reachable(const QuadForm& f, float ulo, float uhi, float vlo,
+                                               float vhi)
+{
     if (ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f) return true;  // centre inside
-    const float a = -r0.z, c = -r0.w, b = -r1.x;  // q(u,v) = a u^2 + c v^2 + b u v = -power
-    float qmin = 3.0e38f;
-    {   // edges u = const
-        const float vs_lo = fminf(vhi, fmaxf(vlo, -b * ulo / (2.0f * c)));
-        const float vs_hi = fminf(vhi, fmaxf(vlo, -b * uhi / (2.0f * c)));
-        qmin = fminf(qmin, a * ulo * ulo + c * vs_lo * vs_lo + b * ulo * vs_lo);
-        qmin = fminf(qmin, a * uhi * uhi + c * vs_hi * vs_hi + b * uhi * vs_hi);
-        const float us_lo = fminf(uhi, fmaxf(ulo, -b * vlo / (2.0f * a)));
-        const float us_hi = fminf(uhi, fmaxf(ulo, -b * vhi / (2.0f * a)));
-        qmin = fminf(qmin, a * us_lo * us_lo + c * vlo * vlo + b * us_lo * vlo);
-        qmin = fminf(qmin, a * us_hi * us_hi + c * vhi * vhi + b * us_hi * vhi);
+    const float vs_lo = fminf(vhi, fmaxf(vlo, f.kv * ulo));
+    const float vs_hi = fminf(vhi, fmaxf(vlo, f.kv * uhi));
+    const float us_lo = fminf(uhi, fmaxf(ulo, f.ku * vlo));
+    const float us_hi = fminf(uhi, fmaxf(ulo, f.ku * vhi));
+    float qmin = f.a * ulo * ulo + f.c * vs_lo * vs_lo + f.b * ulo * vs_lo;
+    qmin = fminf(qmin, f.a * uhi * uhi + f.c * vs_hi * vs_hi + f.b * uhi * vs_hi);
+    qmin = fminf(qmin, f.a * us_lo * us_lo + f.c * vlo * vlo + f.b * us_lo * vlo);
+    qmin = fminf(qmin, f.a * us_hi * us_hi + f.c * vhi * vhi + f.b * us_hi * vhi);
+    return !(-qmin < f.thr_slack);  // cull only when certainly below the threshold (NaN -> keep)
+}
+__device__ __forceinline__ uint32_t quad_mask(const QuadForm& f, const float4 r0, int tx, int ty)
+{
+    const float u0 = (float)(tx * kTile) - r0.x, v0 = (float)(ty * kTile) - r0.y;
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float ulo = u0 + (float)((q & 1) * 8), vlo = v0 + (float)((q >> 1) * 8);
+        if (rect_reachable(f, ulo, ulo + 7.0f, vlo, vlo + 7.0f)) m |= 1u << q;
     }
-    // power_max = -qmin; cull only when certainly below the threshold (NaN -> keep)
-    const float slack = 1e-3f * (1.0f + fabsf(r1.z));
-    return !(-qmin < r1.z - slack);
+    return m;
 }
 
 // Workgroup-private tile counters: the 256 Gaussians of a workgroup are neighbours on screen
@@ -123,9 +141,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     fs_raster_dims d, const float* __restrict__ means3D, const float* __restrict__ cov3D,
     const float* __restrict__ shs, const float* __restrict__ colors,
     const float* __restrict__ opacities, const float* __restrict__ view,
-    const float* __restrict__ proj, const float* __restrict__ campos, GeomView g,
+    const float* __restrict__ proj, const float* __restrict__ campos,
+    const float* __restrict__ tanfov_dev, const float* __restrict__ scale_dev, GeomView g,
     int32_t* __restrict__ radii, uint32_t* __restrict__ tile_counts)
 {
+    const float tanfovx = tanfov_dev ? tanfov_dev[0] : d.tanfovx;
+    const float tanfovy = tanfov_dev ? tanfov_dev[1] : d.tanfovy;
+    const float wscale = scale_dev ? scale_dev[0] : 1.0f;  // scale-invariant rescale (1/near)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int base = blockIdx.x * 256;
     const int cnt = min(256, d.N - base);
@@ -146,18 +168,24 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     uint8_t cb = 0;
     int rad = 0;
 
-    const float3 p = live ? make_float3(l_mean[3 * t], l_mean[3 * t + 1], l_mean[3 * t + 2])
-                          : make_float3(0.0f, 0.0f, 0.0f);
+    float3 p = live ? make_float3(l_mean[3 * t], l_mean[3 * t + 1], l_mean[3 * t + 2])
+                    : make_float3(0.0f, 0.0f, 0.0f);
+    if (scale_dev) { p.x = p.x * wscale; p.y = p.y * wscale; p.z = p.z * wscale; }
     const float3 pv = xform43(view, p);
     if (live && pv.z > 0.2f) {
         const float4 ph = xform44(proj, p);
         const float pw = 1.0f / (ph.w + 0.0000001f);
         const float ndcx = ph.x * pw, ndcy = ph.y * pw;
-        const float fx = (float)d.W / (2.0f * d.tanfovx), fy = (float)d.H / (2.0f * d.tanfovy);
+        const float fx = (float)d.W / (2.0f * tanfovx), fy = (float)d.H / (2.0f * tanfovy);
         float c3[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) c3[k] = l_cov[6 * t + k];
-        const Cov2D cv = project_cov(view, p, c3, fx, fy, d.tanfovx, d.tanfovy);
+        if (scale_dev) {
+            const float s2 = wscale * wscale;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c3[k] = c3[k] * s2;
+        }
+        const Cov2D cv = project_cov(view, p, c3, fx, fy, tanfovx, tanfovy);
         const float det = cv.a * cv.c - cv.b * cv.b;
         if (det != 0.0f) {
             const float det_inv = 1.0f / det;
@@ -228,6 +256,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const bool valid = rad > 0;
     const bool cull = (d.flags & FS_RASTER_TILE_CULL) != 0;
     const int gx = (d.W + kTile - 1) / kTile;
+    const QuadForm qf = quad_form(r0, r1);
     const BinBox bb = block_bin_box(s_box, valid, rect);
     if (bb.w * bb.h == 0) return;
     if (bb.lds) {
@@ -236,7 +265,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         if (valid)
             for (int y = rect.y; y < rect.w; ++y)
                 for (int x = rect.x; x < rect.z; ++x)
-                    if (!cull || tile_reachable(r0, r1, x, y))
+                    if (!cull || quad_mask(qf, r0, x, y))
                         atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
         __syncthreads();
         for (int k = t; k < bb.w * bb.h; k += 256) {
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     } else if (valid) {
         for (int y = rect.y; y < rect.w; ++y)
             for (int x = rect.x; x < rect.z; ++x)
-                if (!cull || tile_reachable(r0, r1, x, y)) atomicAdd(&tile_counts[y * gx + x], 1u);
+                if (!cull || quad_mask(qf, r0, x, y)) atomicAdd(&tile_counts[y * gx + x], 1u);
     }
 }
 
@@ -306,7 +335,10 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
     const bool cull = (flags & FS_RASTER_TILE_CULL) != 0;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
     if (valid) { r0 = g.rec[3 * (size_t)i]; r1 = g.rec[3 * (size_t)i + 1]; }
-    const unsigned long long key = ((unsigned long long)__float_as_uint(r1.w) << 32) | (uint32_t)i;
+    // key = depth bits : (gaussian id << 4 | quadrant mask); the mask is a function of (id, tile), so
+    // ordering by the key is ordering by (depth, id)
+    const unsigned long long key_hi = ((unsigned long long)__float_as_uint(r1.w) << 32) | ((uint32_t)i << 4);
+    const QuadForm qf = quad_form(r0, r1);
     const BinBox bb = block_bin_box(s_box, valid, rc);
     if (bb.w * bb.h == 0) return;
     if (bb.lds) {
@@ -315,7 +347,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
         if (valid)
             for (int y = rc.y; y < rc.w; ++y)
                 for (int x = rc.x; x < rc.z; ++x)
-                    if (!cull || tile_reachable(r0, r1, x, y))
+                    if (!cull || quad_mask(qf, r0, x, y))
                         atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
         __syncthreads();
         for (int k = t; k < bb.w * bb.h; k += 256) {
@@ -328,19 +360,25 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
         if (valid)
             for (int y = rc.y; y < rc.w; ++y)
                 for (int x = rc.x; x < rc.z; ++x)
-                    if (!cull || tile_reachable(r0, r1, x, y)) {
+                {
+                    const uint32_t qm = quad_mask(qf, r0, x, y);
+                    if (!cull || qm) {
                         const int k = (y - bb.y0) * bb.w + (x - bb.x0);
                         const unsigned long long slot = (unsigned long long)s_base[k] + atomicAdd(&s_cnt[k], 1u);
-                        if (slot < cap) keys[slot] = key;
+                        if (slot < cap) keys[slot] = key_hi | qm;
                     }
+                }
     } else if (valid) {
         for (int y = rc.y; y < rc.w; ++y)
             for (int x = rc.x; x < rc.z; ++x)
-                if (!cull || tile_reachable(r0, r1, x, y)) {
+            {
+                const uint32_t qm = quad_mask(qf, r0, x, y);
+                if (!cull || qm) {
                     const int tl = y * gx + x;
                     const unsigned long long slot = (unsigned long long)offsets[tl] + atomicAdd(&cursors[tl], 1u);
-                    if (slot < cap) keys[slot] = key;
+                    if (slot < cap) keys[slot] = key_hi | qm;
                 }
+            }
     }
 }
 
@@ -409,7 +447,11 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------
-// render: front-to-back alpha compositing, one 16x16 tile per workgroup
+// render: front-to-back alpha compositing, one 16x16 tile per workgroup.
+// Each of the 4 wavefronts owns one 8x8 quadrant.  The list entries carry a 4-bit quadrant mask
+// (computed once at emit time), so a wavefront ballots 64 entries at a time against its own bit
+// and walks only the survivors (s_ff1 over the ballot): entries that cannot touch the quadrant
+// cost 1/64 of a VALU test instead of a full per-pixel evaluation.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void render_kernel(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
@@ -419,16 +461,19 @@ __global__ __launch_bounds__(256) void render_kernel(
     float* __restrict__ final_T, int32_t* __restrict__ n_contrib)
 {
     __shared__ float4 s0[256], s1[256], s2[256];
+    __shared__ uint32_t s_q[256];
     if (counters[1]) return;
     const int chunk = (T + 7) >> 3;
     const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
     const int gx = (W + kTile - 1) / kTile;
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x;
-    const int px = tx * kTile + (tid & 15), py = ty * kTile + (tid >> 4);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pfx = (float)px, pfy = (float)py;
+    const uint32_t qbit = 1u << wave;
 
     const uint32_t a = offsets[tile], b = offsets[tile + 1];
     const int n = (int)(b - a);
@@ -441,36 +486,52 @@ __global__ __launch_bounds__(256) void render_kernel(
     for (int r = 0; r < rounds; ++r) {
         if (__syncthreads_and(done)) break;
         const int idx = (r << 8) + tid;
+        uint32_t w = 0;
         if (idx < n) {
-            const uint32_t gid = point_list[a + idx];
-            const float4* q = rec + 3 * (size_t)gid;
-            s0[tid] = q[0];
-            s1[tid] = q[1];
-            s2[tid] = q[2];
+            w = point_list[a + idx];
+            if (w & 15u) {
+                const float4* q = rec + 3 * (size_t)(w >> 4);
+                s0[tid] = q[0];
+                s1[tid] = q[1];
+                s2[tid] = q[2];
+            }
         }
+        s_q[tid] = w;
         __syncthreads();
         const int m = min(256, n - (r << 8));
-        for (int j = 0; j < m; ++j) {
+        for (int c = 0; c < m; c += 64) {
             if (__all(done)) break;  // wave-uniform
-            const float4 g0 = s0[j], g1 = s1[j];
-            const float dx = g0.x - pfx, dy = g0.y - pfy;
-            const float power = fmaf(g0.z * dx, dx, fmaf(g0.w * dy, dy, (g1.x * dx) * dy));
-            // wave-uniform early-out: nobody in this wave can reach alpha >= 1/255
-            const bool cand = !done && power <= 0.0f && power >= g1.z;
-            if (!__any(cand)) continue;
-            if (!cand) continue;
-            const float alpha = fminf(0.99f, g1.y * fs_exp(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T_ * (1.0f - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            const float4 g2 = s2[j];
-            const float w = alpha * T_;
-            C0 = fmaf(g2.x, w, C0);
-            C1 = fmaf(g2.y, w, C1);
-            C2 = fmaf(g2.z, w, C2);
-            D = fmaf(g1.w, w, D);
-            T_ = test_T;
-            last = (r << 8) + j + 1;
+            unsigned long long hits = __ballot((c + lane < m) && (s_q[c + lane] & qbit));
+            if (!hits) continue;
+            // software pipeline: the next survivor's record is fetched from LDS while this one blends
+            int jn = c + __builtin_ctzll(hits);
+            float4 n0 = s0[jn], n1 = s1[jn], n2 = s2[jn];
+            while (hits) {
+                const int j = jn;
+                const float4 g0 = n0, g1 = n1, g2 = n2;
+                hits &= hits - 1;
+                if (hits) {
+                    jn = c + __builtin_ctzll(hits);
+                    n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
+                }
+                const float dx = g0.x - pfx, dy = g0.y - pfy;
+                const float power = fmaf(g0.z * dx, dx, fmaf(g0.w * dy, dy, (g1.x * dx) * dy));
+                const bool cand = !done && power <= 0.0f && power >= g1.z;
+                if (!__any(cand)) continue;  // wave-uniform
+                // straight-line from here: per-lane decisions become selects, not exec-mask branches
+                const float alpha = fminf(0.99f, g1.y * fs_exp(power));
+                const float test_T = T_ * (1.0f - alpha);
+                const bool vis = cand && alpha >= 1.0f / 255.0f;
+                const bool ok = vis && test_T >= 0.0001f;
+                done = done || (vis && !ok);
+                const float wgt = alpha * T_;
+                C0 = ok ? fmaf(g2.x, wgt, C0) : C0;
+                C1 = ok ? fmaf(g2.y, wgt, C1) : C1;
+                C2 = ok ? fmaf(g2.z, wgt, C2) : C2;
+                D = ok ? fmaf(g1.w, wgt, D) : D;
+                T_ = ok ? test_T : T_;
+                last = ok ? (r << 8) + j + 1 : last;
+            }
         }
     }
     if (inside) {
@@ -521,8 +582,8 @@ FS_API const int32_t* fs_raster_n_contrib(const void* image, int32_t H, int32_t 
 FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
                              const float* shs, const float* colors_precomp, const float* opacities,
                              const float* bg, const float* viewmatrix, const float* projmatrix,
-                             const float* campos, void* geom, void* binning, void* image,
-                             void* scratch, int64_t cap, float* out_color, float* out_depth,
+                             const float* campos, const float* tanfov_dev, const float* scale_dev,
+                             void* geom, void* binning, void* image, void* scratch, int64_t cap, float* out_color, float* out_depth,
                              float* out_alpha, int32_t* radii, uint32_t* counters, void* stream_)
 {
     if (!dims || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
@@ -538,6 +599,7 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
         return FS_ERR_UNSUPPORTED;
     const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
     if (gx > 65535 || gy > 65535) return FS_ERR_UNSUPPORTED;
+    if (d.N > (1 << 28)) return FS_ERR_UNSUPPORTED;  // list entries are (id << 4 | quadrant mask)
     hipStream_t st = (hipStream_t)stream_;
     const int T = gx * gy;
     const size_t P = (size_t)d.H * d.W;
@@ -562,8 +624,8 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
         {
             ScopedStage prof_(kStPreprocess, st);
             hipLaunchKernelGGL(preprocess_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, means3D,
-                               cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, g,
-                               radii, counts);
+                               cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos,
+                               tanfov_dev, scale_dev, g, radii, counts);
         }
         FS_CHECK_LAUNCH("preprocess");
     }

@@ -25,18 +25,35 @@ from . import rasterizer as R
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
+_const_cache: dict = {}
+
+
+def _consts(device: torch.device) -> dict:
+    """Small constant tensors kept resident per device: creating them per call costs a pageable
+    host-to-device copy each, and on ROCm that copy waits for all queued work of the stream."""
+    key = (device.type, device.index)
+    c = _const_cache.get(key)
+    if c is None:
+        row, col = torch.triu_indices(3, 3)
+        c = _const_cache[key] = dict(
+            edge_mid=torch.tensor([[0, 0.5, 1], [1, 0.5, 1], [0.5, 0, 1], [0.5, 1, 1]], dtype=torch.float32,
+                                  device=device),
+            triu_row=row.to(device), triu_col=col.to(device))
+    return c
+
+
 def get_fov(intrinsics: Tensor) -> Tensor:
     """[B,3,3] normalised intrinsics -> [B,2] (fov_x, fov_y): angle between the unit rays through the
     image-edge midpoints (projection.py:233-247)."""
-    inv = intrinsics.inverse()
+    inv = torch.linalg.inv_ex(intrinsics).inverse  # same LU as .inverse(), without its host sync
+    mids = _consts(intrinsics.device)["edge_mid"]
 
-    def ray(v):
-        v = torch.tensor(v, dtype=torch.float32, device=intrinsics.device)
-        r = torch.einsum("bij,j->bi", inv, v)
+    def ray(k):
+        r = torch.einsum("bij,j->bi", inv, mids[k])
         return r / r.norm(dim=-1, keepdim=True)
 
-    left, right = ray([0, 0.5, 1]), ray([1, 0.5, 1])
-    top, bottom = ray([0.5, 0, 1]), ray([0.5, 1, 1])
+    left, right = ray(0), ray(1)
+    top, bottom = ray(2), ray(3)
     fov_x = (left * right).sum(dim=-1).acos()
     fov_y = (top * bottom).sum(dim=-1).acos()
     return torch.stack((fov_x, fov_y), dim=-1)
@@ -75,7 +92,7 @@ def _frame(extrinsics, intrinsics, near, far, scale_invariant: bool):
     tan_fov_x = (0.5 * fov_x).tan()
     tan_fov_y = (0.5 * fov_y).tan()
     projection = get_projection_matrix(near, far, fov_x, fov_y).transpose(1, 2)
-    view = extrinsics.inverse().transpose(1, 2)
+    view = torch.linalg.inv_ex(extrinsics).inverse.transpose(1, 2)
     full = view @ projection
     return extrinsics, scale, tan_fov_x, tan_fov_y, view.contiguous(), full.contiguous()
 
@@ -98,7 +115,7 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
     b = extr.shape[0]
     h, w = image_shape
     tan_x_h, tan_y_h = tan_x.tolist(), tan_y.tolist()  # one sync for all views (reference: 2 per view)
-    row, col = torch.triu_indices(3, 3)
+    row, col = _consts(extr.device)["triu_row"], _consts(extr.device)["triu_col"]
     images, depths = [], []
     for i in range(b):
         mean_gradients = torch.zeros_like(gaussian_means[i], requires_grad=True)
@@ -121,76 +138,104 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
 # ---------------------------------------------------------------------------------------------
 # Batched multi-view path: one shared Gaussian set, v views, one sync.
 # ---------------------------------------------------------------------------------------------
+_pending_checks: list = []  # (RasterState list) of render_views(..., check="deferred") calls
+
+
+def check_deferred() -> None:
+    """Validate the instance-capacity counters of every deferred render_views call (one host sync).
+    Raises if any of them overflowed -- their images are invalid and must be re-rendered."""
+    global _pending_checks
+    pend, _pending_checks = _pending_checks, []
+    if not pend:
+        return
+    flat = [rs for states in pend for rs in states]
+    counters = torch.stack([rs.counters for rs in flat]).tolist()
+    bad = 0
+    for rs, (n_inst, overflow) in zip(flat, counters):
+        rs.num_rendered = n_inst & 0xFFFFFFFF
+        st = R._state(rs.geom.device)
+        st.last_instances = max(st.last_instances, rs.num_rendered)
+        bad += 1 if overflow else 0
+    if bad:
+        raise R._lib.FreeSplatHipError(f"{bad} deferred view(s) overflowed their instance capacity; "
+                                       "re-render them (capacity history has been updated)")
+
+
 class _RenderViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, cov6, shs, opac, views, fulls, campos, bgs, tan_x, tan_y, h, w, degree):
+    def forward(ctx, means, cov6, shs, opac, views, fulls, campos, bgs, tanfov, scale, h, w, degree,
+                deferred):
         v = views.shape[0]
         N = means.shape[0]
         dev = means.device
         st = R._state(dev)
-        states, colors, depths = [], [], []
         cap = R.default_capacity(N, st)
-        for i in range(v):
-            s = GaussianRasterizationSettings(h, w, tan_x[i], tan_y[i], bgs[i], 1.0, views[i], fulls[i],
-                                              degree, campos[i], False, False)
-            dims = R.make_dims(N, shs.shape[1], s)
-            rs, c, d, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i], fulls[i],
-                                            campos[i], cap)
-            states.append(rs); colors.append(c); depths.append(d)
-        counters = torch.stack([rs.counters for rs in states]).tolist()  # the single sync
-        for i, (n_inst, overflow) in enumerate(counters):
-            n_inst &= 0xFFFFFFFF
-            if overflow:
-                s = GaussianRasterizationSettings(h, w, tan_x[i], tan_y[i], bgs[i], 1.0, views[i], fulls[i],
-                                                  degree, campos[i], False, False)
-                dims = R.make_dims(N, shs.shape[1], s)
-                rs, c, d, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i],
-                                                fulls[i], campos[i], n_inst + 1024)
-                states[i], colors[i], depths[i] = rs, c, d
-            states[i].num_rendered = n_inst
-            st.last_instances = max(st.last_instances if i else 0, n_inst)
+        color = torch.empty(v, 3, h, w, dtype=torch.float32, device=dev)
+        depth = torch.empty(v, h, w, dtype=torch.float32, device=dev)
+        alpha = torch.empty(v, h, w, dtype=torch.float32, device=dev)
+        s0 = GaussianRasterizationSettings(h, w, 0.0, 0.0, None, 1.0, None, None, degree, None, False, False)
+
+        def launch(i, cap_i):
+            dims = R.make_dims(N, shs.shape[1], s0)
+            rs, _, _, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i], fulls[i],
+                                            campos[i], cap_i, tanfov=tanfov[i],
+                                            scale=None if scale is None else scale[i],
+                                            out=(color[i], depth[i], alpha[i]))
+            return rs
+
+        states = [launch(i, cap) for i in range(v)]
+        if deferred:
+            _pending_checks.append(states)
+        else:
+            counters = torch.stack([rs.counters for rs in states]).tolist()  # the single sync
+            worst = 0
+            for i, (n_inst, overflow) in enumerate(counters):
+                n_inst &= 0xFFFFFFFF
+                if overflow:
+                    states[i] = launch(i, n_inst + 1024)
+                states[i].num_rendered = n_inst
+                worst = max(worst, n_inst)
+            st.last_instances = worst
         ctx.states = states
         ctx.save_for_backward(means, cov6, shs)
         ctx.set_materialize_grads(False)
-        return torch.stack(colors), torch.stack(depths)
+        return color, depth
 
     @staticmethod
     def backward(ctx, g_color, g_depth):
         means, cov6, shs = ctx.saved_tensors
         if g_color is None and g_depth is None:
-            return (None,) * 13
+            return (None,) * 14
         out = None
         for i, rs in enumerate(ctx.states):
             gc = None if g_color is None else g_color[i]
             gd = None if g_depth is None else g_depth[i]
             out = R.rasterize_backward(rs, means, cov6, shs, None, gc, gd, out=out, accumulate=i > 0)
-        return (out["means3D"], out["cov3D"], out["shs"], out["opacities"]) + (None,) * 9
+        return (out["means3D"], out["cov3D"], out["shs"], out["opacities"]) + (None,) * 10
 
 
 def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                  image_shape: tuple[int, int], background_color: Tensor, means: Tensor,
                  covariances: Tensor, sh_coefficients: Tensor, opacities: Tensor,
-                 scale_invariant: bool = True):
+                 scale_invariant: bool = True, check: str = "now"):
     """v views [v,...] of ONE Gaussian set (means [G,3], covariances [G,3,3], sh [G,3,d_sh],
-    opacities [G]).  Same numbers as render_cuda on v repeated copies; requires a common `near`
-    across the views when scale_invariant (true for every shipped config: near = 0.5)."""
+    opacities [G]).  Same numbers as render_cuda on v repeated copies, but the per-view 1/near
+    rescale and tan(fov) stay on the device (fs_raster_forward's scale_dev / tanfov_dev), nothing is
+    repeated, the images are written straight into the [v,...] outputs, and the only host sync is
+    the instance-capacity check: check="now" (default) does it at the end of the call and re-renders
+    overflowed views; check="deferred" leaves it to decoder.check_deferred() so that back-to-back
+    calls keep the GPU queue full."""
     extr, scale, tan_x, tan_y, view, full = _frame(extrinsics, intrinsics, near, far, scale_invariant)
-    host = torch.stack([tan_x, tan_y, near]).tolist()  # one small sync for the scalar settings
-    tan_x_h, tan_y_h, near_h = host
-    if scale_invariant:
-        if any(n != near_h[0] for n in near_h):
-            raise ValueError("render_views needs one `near` for all views; use render_cuda otherwise")
-        s0 = scale[0]
-        means = means * s0
-        covariances = covariances * (s0 * s0)
+    tanfov = torch.stack([tan_x, tan_y], dim=-1).contiguous()
     degree = isqrt(sh_coefficients.shape[-1]) - 1
     shs = sh_coefficients.transpose(-1, -2).contiguous()
-    row, col = torch.triu_indices(3, 3)
-    cov6 = covariances[:, row, col].contiguous()
+    k = _consts(means.device)
+    cov6 = covariances[:, k["triu_row"], k["triu_col"]].contiguous()
     h, w = image_shape
     color, depth = _RenderViews.apply(means.contiguous(), cov6, shs, opacities.contiguous(), view, full,
-                                      extr[:, :3, 3].contiguous(), background_color.contiguous(),
-                                      tan_x_h, tan_y_h, h, w, degree)
+                                      extr[:, :3, 3].contiguous(), background_color.contiguous(), tanfov,
+                                      None if scale is None else scale.contiguous(), h, w, degree,
+                                      check == "deferred")
     return color, depth.unsqueeze(1)
 
 

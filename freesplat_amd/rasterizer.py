@@ -84,11 +84,14 @@ class RasterState:
     """Everything one forward leaves behind for its backward (device buffers + dims)."""
 
     __slots__ = ("dims", "geom", "binning", "image", "radii", "counters", "cap", "bg", "view", "proj",
-                 "campos", "num_rendered")
+                 "campos", "tanfov", "scale", "num_rendered")
 
 
 def _launch_forward(dims: _lib.RasterDims, means3D, cov3D, shs, colors, opacities, bg, view, proj,
-                    campos, cap: int) -> tuple[RasterState, Tensor, Tensor, Tensor]:
+                    campos, cap: int, tanfov: Optional[Tensor] = None, scale: Optional[Tensor] = None,
+                    out: Optional[tuple] = None) -> tuple[RasterState, Tensor, Tensor, Tensor]:
+    """One stream-ordered forward launch (no host sync).  `tanfov` [2] / `scale` [1]: optional
+    device-resident settings; `out` = (color[3,H,W], depth[H,W], alpha[H,W]) views to write into."""
     dev = means3D.device
     N, H, W = dims.N, dims.H, dims.W
     sz = _buffer_sizes(N, H, W, cap)
@@ -104,14 +107,19 @@ def _launch_forward(dims: _lib.RasterDims, means3D, cov3D, shs, colors, opacitie
     rs.counters = torch.empty(2, dtype=torch.int32, device=dev)
     rs.cap = cap
     rs.bg, rs.view, rs.proj, rs.campos = bg, view, proj, campos
+    rs.tanfov, rs.scale = tanfov, scale
     rs.num_rendered = -1
-    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-    depth = torch.empty(H, W, dtype=torch.float32, device=dev)
-    alpha = torch.empty(H, W, dtype=torch.float32, device=dev)
+    if out is None:
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+        alpha = torch.empty(H, W, dtype=torch.float32, device=dev)
+    else:
+        color, depth, alpha = out
     p = _lib.ptr
     _lib.check(_lib.lib().fs_raster_forward(
         C.byref(dims), p(means3D), p(cov3D), p(shs), p(colors), p(opacities), p(bg), p(view), p(proj),
-        p(campos), p(rs.geom), p(rs.binning), p(rs.image), p(st.scratch), cap, p(color), p(depth),
+        p(campos), p(tanfov), p(scale), p(rs.geom), p(rs.binning), p(rs.image), p(st.scratch), cap,
+        p(color), p(depth),
         p(alpha), p(rs.radii), p(rs.counters), _lib.current_stream()), "fs_raster_forward")
     return rs, color, depth, alpha
 
@@ -180,7 +188,8 @@ def rasterize_backward(rs: RasterState, means3D, cov3D, shs, colors, g_color, g_
     p = _lib.ptr
     _lib.check(_lib.lib().fs_raster_backward(
         C.byref(d), p(means3D), p(cov3D), p(shs), p(colors), p(rs.bg), p(rs.view), p(rs.proj),
-        p(rs.campos), p(rs.geom), p(rs.binning), p(rs.image), p(g_color), p(g_depth), p(scratch),
+        p(rs.campos), p(rs.tanfov), p(rs.scale), p(rs.geom), p(rs.binning), p(rs.image), p(g_color),
+        p(g_depth), p(scratch),
         p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]), p(out["shs"]), p(out["colors"]),
         p(out["opacities"]), 1 if accumulate else 0, _lib.current_stream()), "fs_raster_backward")
     return out
@@ -276,7 +285,8 @@ def debug_state(rs: RasterState) -> dict:
     binning = rs.binning.cpu().numpy()
     offsets = binning[: (T + 1) * 4].view(np.uint32).copy()
     I = int(offsets[-1])
-    point_list = binning[off_bytes: off_bytes + I * 4].view(np.uint32).copy()
+    words = binning[off_bytes: off_bytes + I * 4].view(np.uint32).copy()
+    point_list, quad = words >> 4, words & 15
     geom = rs.geom.cpu().numpy()
     N = d.N
     rec = geom[: N * 48].view(np.float32).reshape(N, 12).copy()
@@ -289,6 +299,6 @@ def debug_state(rs: RasterState) -> dict:
     final_T = img[: P * 4].view(np.float32).reshape(d.H, d.W).copy()
     o3 = (P * 4 + 255) // 256 * 256
     n_contrib = img[o3: o3 + P * 4].view(np.int32).reshape(d.H, d.W).copy()
-    return dict(offsets=offsets, point_list=point_list, rec=rec, rect=rect, clamp=clamp,
+    return dict(offsets=offsets, point_list=point_list, quad=quad, rec=rec, rect=rect, clamp=clamp,
                 final_T=final_T, n_contrib=n_contrib, radii=rs.radii.cpu().numpy(),
                 num_rendered=I)

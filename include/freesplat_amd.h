@@ -90,11 +90,18 @@ int fs_raster_buffer_sizes(int32_t N, int32_t H, int32_t W, int64_t inst_capacit
  * counters[2] (uint32): {number of instances I, overflow flag (I > inst_capacity)}.
  * If the overflow flag is set the image outputs are undefined and the caller must retry
  * with inst_capacity >= I (the library never allocates).
+ * Optional device-resident settings (NULL = unused), so that a multi-view caller never has to
+ * read a tensor back to the host:
+ *   tanfov_dev[2]  overrides dims->tanfovx/tanfovy;
+ *   scale_dev[1]   the scale-invariant rescale of cuda_splatting.py:64-71 folded into the kernel:
+ *                  means3D * s and cov3D * (s*s) are formed on the fly (bit-identical to doing it
+ *                  in torch first); viewmatrix/projmatrix/campos must already be the scaled ones.
  */
 int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
                       const float* shs, const float* colors_precomp, const float* opacities,
                       const float* bg, const float* viewmatrix, const float* projmatrix,
-                      const float* campos, void* geom, void* binning, void* image, void* scratch,
+                      const float* campos, const float* tanfov_dev, const float* scale_dev,
+                      void* geom, void* binning, void* image, void* scratch,
                       int64_t inst_capacity, float* out_color, float* out_depth, float* out_alpha,
                       int32_t* radii, uint32_t* counters, void* stream);
 
@@ -110,6 +117,7 @@ int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const fl
 int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
                        const float* shs, const float* colors_precomp, const float* bg,
                        const float* viewmatrix, const float* projmatrix, const float* campos,
+                       const float* tanfov_dev, const float* scale_dev,
                        const void* geom, const void* binning, const void* image,
                        const float* dL_dcolor, const float* dL_ddepth, void* grad_scratch,
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs,
@@ -117,7 +125,7 @@ int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const f
 
 /* Debug/test accessors into the opaque buffers (device pointers, no copies). */
 const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t H, int32_t W);  /* [T+1] offsets */
-const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] ids */
+const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] (id << 4) | 8x8-quadrant mask */
 const float* fs_raster_geom_records(const void* geom);                             /* [N,12] */
 const float* fs_raster_final_T(const void* image);                                 /* [H*W] */
 const int32_t* fs_raster_n_contrib(const void* image, int32_t H, int32_t W);       /* [H*W] */

@@ -42,7 +42,7 @@ def test_buffer_sizes_and_arg_validation():
     assert L.fs_raster_buffer_sizes(-1, 10, 10, 10, out) == -1
     assert L.fs_raster_buffer_sizes(10, 0, 10, 10, out) == -1
     # NULL dims -> FS_ERR_INVALID_ARG before anything touches a device
-    args = [None] * 14 + [1] + [None] * 6
+    args = [None] * 16 + [1] + [None] * 6
     assert L.fs_raster_forward(*args) == -1
 
 
