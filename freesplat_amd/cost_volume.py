@@ -1,0 +1,129 @@
+"""Drop-in for the reference's plane-sweep cost volume module.
+
+Mirrors /root/reference/src/model/encoder/modules/cost_volume.py:
+    AVGFeatureVolumeManager(matching_height, matching_width, num_depth_bins=64,
+                            mlp_channels=[202,32,32,1], matching_dim_size=16)       (:399-426)
+    .forward(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth,
+             max_depth, depth_planes_bdhw=None, return_mask=False) -> [B, D, h, w]     (:351-381)
+    .generate_depth_planes(batch_size, min_depth, max_depth)                           (:98-134)
+with the same parameter / buffer names (so the reference's checkpoints load: `linear_ramp_1d11`,
+`backprojector.pix_coords_13N`, `projector.eps`, `mlp.net.{0,2,4}.{weight,bias}`) and the same
+construction order (so a seeded construction yields the same initial weights).  The compute is
+fs_cost_volume_forward in libfreesplat_hip.so -- no torch fallback.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+
+class _Backprojector(nn.Module):
+    """Holds the `pix_coords_13N` buffer of sr_utils/geometry_utils.py:22-48 (state-dict parity);
+    the kernel regenerates (u+0.5, v+0.5, 1) itself."""
+
+    def __init__(self, height: int, width: int):
+        super().__init__()
+        xx, yy = torch.meshgrid(torch.arange(width), torch.arange(height), indexing="xy")
+        pix = torch.stack((xx, yy), 0) + 0.5
+        pix = torch.cat([pix, torch.ones_like(pix[:1])], 0).flatten(1).unsqueeze(0)
+        self.register_buffer("pix_coords_13N", pix)
+
+
+class _Projector(nn.Module):
+    def __init__(self, eps: float = 1e-8):
+        super().__init__()
+        self.register_buffer("eps", torch.tensor(eps).view(1, 1, 1))
+
+
+class MLP(nn.Module):
+    """networks.py:218-236: Linear / LeakyReLU stack, final activation disabled."""
+
+    def __init__(self, channel_list, disable_final_activation: bool = False):
+        super().__init__()
+        layers = []
+        for i in range(len(channel_list) - 1):
+            layers.append(nn.Linear(channel_list[i], channel_list[i + 1]))
+            layers.append(nn.LeakyReLU(inplace=True))
+        if disable_final_activation:
+            layers = layers[:-1]
+        self.net = nn.Sequential(*layers)
+
+
+class _CostVolumeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, strides, w1, b1, w2, b2,
+                w3, b3):
+        B, K, C, h, w = src_feats.shape
+        D = planes.shape[0] if planes.dim() == 1 else planes.shape[1]
+        dev = cur_feats.device
+        L = _lib.lib()
+        ws = torch.empty(L.fs_cost_volume_workspace_bytes(B, K, C, h, w), dtype=torch.uint8, device=dev)
+        out = torch.empty(B, D, h, w, dtype=torch.float32, device=dev)
+        p = _lib.ptr
+        _lib.check(L.fs_cost_volume_forward(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
+                                            p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
+                                            p(w1), p(b1), p(w2), p(b2), p(w3), p(b3), p(ws), p(out),
+                                            _lib.current_stream()), "fs_cost_volume_forward")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("freesplat_amd cost volume: backward kernel not built yet "
+                                  "(forward-only this round; there is no torch fallback)")
+
+
+def _dev32(t: Tensor, name: str) -> Tensor:
+    if t.device.type != "cuda":
+        raise RuntimeError(f"freesplat_amd cost volume: `{name}` must live on a HIP device (got {t.device}); "
+                           "there is no CPU path")
+    return t.float().contiguous()
+
+
+class AVGFeatureVolumeManager(nn.Module):
+    def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=[202, 32, 32, 1],
+                 matching_dim_size=16):
+        super().__init__()
+        self.num_depth_bins = num_depth_bins
+        self.matching_height = matching_height
+        self.matching_width = matching_width
+        self.register_buffer("linear_ramp_1d11", torch.linspace(0, 1, num_depth_bins).view(1, num_depth_bins, 1, 1))
+        self.backprojector = _Backprojector(matching_height, matching_width)
+        self.projector = _Projector()
+        mlp_channels = list(mlp_channels)  # (the reference mutates its default argument, :423)
+        mlp_channels[0] = matching_dim_size + 1
+        if mlp_channels[1:] != [32, 32, 1]:
+            raise NotImplementedError("the HIP cost volume implements the shipped 32-32-1 MLP")
+        self.mlp = MLP(channel_list=mlp_channels, disable_final_activation=True)
+
+    def generate_depth_planes(self, batch_size: int, min_depth: Tensor, max_depth: Tensor) -> Tensor:
+        ramp = self.linear_ramp_1d11.expand(batch_size, self.num_depth_bins, 1, 1)
+        inv_min, inv_max = 1 / min_depth, 1 / max_depth
+        planes = 1 / (inv_min + (inv_max - inv_min) * ramp)
+        planes = planes.expand(batch_size, self.num_depth_bins, self.matching_height, self.matching_width)
+        self.depth_planes_bdhw = planes
+        return planes
+
+    def forward(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+                depth_planes_bdhw=None, return_mask=False):
+        B, K, C, h, w = src_feats.shape
+        if (h, w) != (self.matching_height, self.matching_width):
+            raise RuntimeError("feature maps do not match matching_height/width")
+        if depth_planes_bdhw is None:
+            planes = self.generate_depth_planes(B, min_depth, max_depth)
+            flat = _dev32(planes[0, :, 0, 0], "depth planes")   # [D]: identical for every batch row / pixel
+            if planes.shape[0] > 1 and planes.stride(0) != 0:
+                flat = _dev32(planes[:, :, 0, 0], "depth planes")
+                strides = (flat.shape[1], 1, 0)
+            else:
+                strides = (0, 1, 0)
+        else:
+            flat = _dev32(depth_planes_bdhw, "depth_planes_bdhw")
+            D = flat.shape[1]
+            strides = (D * h * w, h * w, 1)
+        net = self.mlp.net
+        return _CostVolumeFn.apply(_dev32(cur_feats, "cur_feats"), _dev32(src_feats, "src_feats"),
+                                   _dev32(src_extrinsics, "src_extrinsics"), _dev32(src_Ks, "src_Ks"),
+                                   _dev32(cur_invK, "cur_invK"), flat, strides, net[0].weight, net[0].bias,
+                                   net[2].weight, net[2].bias, net[4].weight, net[4].bias)

@@ -1,0 +1,242 @@
+// cost_volume.hip -- fused plane-sweep cost volume for MI355X (gfx950).
+//
+// Replaces AVGFeatureVolumeManager.build_cost_volume
+// (src/model/encoder/modules/cost_volume.py:429-619 with sr_utils/geometry_utils.py:22-89 and
+// the MLP of src/model/encoder/modules/networks.py:218-236): the reference runs a Python loop
+// over the D planes with ~15 torch kernels each and re-materialises the warped [B*K,C,h,w]
+// features every iteration.  Here one kernel does everything:
+//
+//   * per (pixel, source) the plane-induced homography  q(d) = d * (P[:, :3] r) + P[:, 3]  is
+//     3 FMAs per plane;
+//   * features are re-laid out once per call to pixel-major [y][x][parity][C/2] so that one
+//     bilinear tap of one lane is 96 contiguous bytes (6 x dwordx4);
+//   * a wavefront owns 32 pixels: lane l = (pixel l&31, channel parity l>>5).  That is exactly
+//     the operand layout of v_mfma_f32_32x32x2_f32 (lane l supplies B[k = l>>5][j = l&31]), so the
+//     averaged warped features feed the 49->32 layer WITHOUT any cross-lane movement, computed
+//     transposed (H1^T = W1 X^T): the accumulator then holds, per lane, 16 hidden units of ITS
+//     pixel, which again is directly the B operand of the 32->32 layer with the k order permuted
+//     to the accumulator's row map; the final 32->1 layer is 16 FMAs + one cross-half add.
+//     41 MFMAs (exact fp32, = fmaf chains) per 32 pixels per plane; the gather/dot VALU work of
+//     one wavefront overlaps the MFMAs of the other wavefronts of the SIMD.
+//   * bias of layer 1 rides in the padding column of the K dimension (feature 49 := 1).
+#include <algorithm>
+
+#include "fs_common.h"
+
+namespace fs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- feature re-layout: [C,h,w] -> [h*w][2][C/2]  (channel c -> parity c&1, slot c>>1) --------
+__global__ __launch_bounds__(256) void cv_relayout_kernel(const float* __restrict__ src,
+                                                          float* __restrict__ dst, int C, int hw,
+                                                          int n_maps)
+{
+    // one thread per (map, pixel, channel-pair slot); reads are coalesced along the pixel index
+    const long long total = (long long)n_maps * hw * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int pix = (int)(e % hw);
+        const long long r = e / hw;
+        const int c = (int)(r % C);
+        const long long map = r / C;
+        const float v = src[(map * C + c) * hw + pix];
+        dst[(map * hw + pix) * C + (size_t)(c & 1) * (C / 2) + (c >> 1)] = v;
+    }
+}
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.0f ? x : 0.01f * x; }
+
+// accumulator row held by (reg r, half hf) of a 32x32 MFMA result (guide, "Fragment layout")
+__device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+template <int HC>  // HC = C/2 channels per lane
+__global__ __launch_bounds__(256) void cost_volume_kernel(
+    int B, int K, int h, int w, int D, const float* __restrict__ curT, const float* __restrict__ srcT,
+    const float* __restrict__ src_extrinsics, const float* __restrict__ src_Ks,
+    const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
+    long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
+    const float* __restrict__ b3, float* __restrict__ out)
+{
+    constexpr int C = 2 * HC;
+    const int hw = h * w;
+    const int groups = (hw + 31) / 32;
+    const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane & 31, hf = lane >> 5;
+    const int pix = grp * 32 + p;
+    const bool live = pix < hw;
+    const int pu = live ? pix % w : 0, pv = live ? pix / w : 0;
+
+    // ---- MLP weights in registers, in MFMA A-operand order ----
+    float a1[HC + 1];  // W1[p][2s+hf], s < HC; step HC: {W1[p][C] (dot feature), b1[p]}
+#pragma unroll
+    for (int s = 0; s < HC; ++s) a1[s] = w1[p * (C + 1) + 2 * s + hf];
+    a1[HC] = hf ? b1[p] : w1[p * (C + 1) + C];
+    float a2[16], w3r[16], b2r[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        a2[s] = w2[p * 32 + acc_row(s, hf)];  // W2[i=p][k = unit held as reg s by half hf]
+        w3r[s] = w3[acc_row(s, hf)];
+        b2r[s] = b2[acc_row(s, hf)];
+    }
+    const float b3v = b3[0];
+
+    // ---- current-view feature (this lane's parity) ----
+    float cur[HC];
+    {
+        const float4* q = (const float4*)(curT + ((size_t)b * hw + (live ? pix : 0)) * C + (size_t)hf * HC);
+#pragma unroll
+        for (int s = 0; s < HC / 4; ++s) {
+            const float4 v = q[s];
+            cur[4 * s] = v.x; cur[4 * s + 1] = v.y; cur[4 * s + 2] = v.z; cur[4 * s + 3] = v.w;
+        }
+    }
+    // ---- ray r = invK[:3,:3] (u+.5, v+.5, 1) ----
+    const float* iK = cur_invK + (size_t)b * 16;
+    const float ux = (float)pu + 0.5f, vy = (float)pv + 0.5f;
+    const float rx = iK[0] * ux + iK[1] * vy + iK[2];
+    const float ry = iK[4] * ux + iK[5] * vy + iK[6];
+    const float rz = iK[8] * ux + iK[9] * vy + iK[10];
+
+    const int dchunk = (D + 3) / 4;
+    const int d0 = wave * dchunk, d1 = min(D, d0 + dchunk);
+
+    for (int d = d0; d < d1; ++d) {
+        const float depth = planes[b * ps_b + d * ps_d + (live ? pix : 0) * ps_p];
+        float favg[HC];
+#pragma unroll
+        for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
+        float dot_sum = 0.0f, cnt = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            // P = (K_src @ T_src<-cur)[:3, :]  (geometry_utils.py:78-80); uniform per (b,k)
+            const float* Ks = src_Ks + ((size_t)b * K + k) * 16;
+            const float* Tx = src_extrinsics + ((size_t)b * K + k) * 16;
+            float P[12];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    P[4 * i + j] = Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] +
+                                   Ks[4 * i + 3] * Tx[12 + j];
+            // world point = depth * r (homogeneous 1): geometry_utils.py:56-58
+            const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+            const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+            const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+            const float qz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+            const float zz = qz + 1e-8f;                                  // :84
+            const float sc = (fabsf(qz) > 1e-8f) ? 1.0f / zz : 1.0f;       // :83,85
+            // grid_sample(align_corners=False) of uv = 2*pix/size - 1  ->  source index = pix - 0.5
+            const float ix = qx * sc - 0.5f, iy = qy * sc - 0.5f;
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const float tx = ix - fx0, ty = iy - fy0;
+            // NaN/inf coordinates sample nothing (comparisons false)
+            const bool xin0 = fx0 >= 0.0f && fx0 <= (float)(w - 1), xin1 = fx0 >= -1.0f && fx0 <= (float)(w - 2);
+            const bool yin0 = fy0 >= 0.0f && fy0 <= (float)(h - 1), yin1 = fy0 >= -1.0f && fy0 <= (float)(h - 2);
+            const int x0 = xin0 || xin1 ? (int)fx0 : 0, y0 = yin0 || yin1 ? (int)fy0 : 0;
+            float wv[HC];
+#pragma unroll
+            for (int s = 0; s < HC; ++s) wv[s] = 0.0f;
+            const float* base = srcT + (((size_t)b * K + k) * hw) * C + (size_t)hf * HC;
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const int ox = tap & 1, oy = tap >> 1;
+                const bool ok = live && (ox ? xin1 : xin0) && (oy ? yin1 : yin0);
+                const float wt = (ox ? tx : 1.0f - tx) * (oy ? ty : 1.0f - ty);
+                if (ok) {
+                    const float4* q = (const float4*)(base + ((size_t)(y0 + oy) * w + (x0 + ox)) * C);
+#pragma unroll
+                    for (int s = 0; s < HC / 4; ++s) {
+                        const float4 v = q[s];
+                        wv[4 * s] += wt * v.x; wv[4 * s + 1] += wt * v.y;
+                        wv[4 * s + 2] += wt * v.z; wv[4 * s + 3] += wt * v.w;
+                    }
+                }
+            }
+            float part = 0.0f;
+#pragma unroll
+            for (int s = 0; s < HC; ++s) part += wv[s] * cur[s];
+            float dotk = part + __shfl_xor(part, 32, 64);
+            dotk = (zz > 0.0f) ? dotk : 0.0f;                             // cost_volume.py:571-572,589-593
+            const bool valid = dotk != 0.0f;                              // :595 (exact zero test)
+            if (valid) {
+                cnt += 1.0f;
+                dot_sum += dotk;
+#pragma unroll
+                for (int s = 0; s < HC; ++s) favg[s] += wv[s];
+            }
+        }
+        const float inv = 1.0f / (cnt + 1e-8f);                          // :595-598
+        // ---- layer 1: H1^T = W1 [f; dot; 1]^T  (K dimension = C + 2, two features per MFMA) ----
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < HC; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], favg[s] * inv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[HC], hf ? 1.0f : dot_sum * inv, acc, 0, 0, 0);
+        // ---- layer 2: H2^T = W2 lrelu(H1)^T + b2, k order = accumulator row map ----
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = b2r[r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], lrelu(acc[s]), acc2, 0, 0, 0);
+        // ---- layer 3 ----
+        float o = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o += w3r[r] * lrelu(acc2[r]);
+        o += __shfl_xor(o, 32, 64);
+        if (live && hf == 0) out[((size_t)b * D + d) * hw + pix] = o + b3v;
+    }
+}
+
+}  // namespace fs
+
+using namespace fs;
+
+FS_API size_t fs_cost_volume_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w)
+{
+    if (B < 0 || K < 0 || C <= 0 || h <= 0 || w <= 0) return 0;
+    return align_up((size_t)B * (1 + (size_t)K) * C * h * w * sizeof(float), 256);
+}
+
+FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                  const float* cur_feats, const float* src_feats,
+                                  const float* src_extrinsics, const float* src_Ks,
+                                  const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                                  int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* w3,
+                                  const float* b3, void* workspace, float* out, void* stream_)
+{
+    if (B <= 0 || K <= 0 || h <= 0 || w <= 0 || D <= 0) return FS_ERR_INVALID_ARG;
+    if (!cur_feats || !src_feats || !src_extrinsics || !src_Ks || !cur_invK || !planes || !w1 || !b1 ||
+        !w2 || !b2 || !w3 || !b3 || !workspace || !out)
+        return FS_ERR_INVALID_ARG;
+    if (C != 48 && C != 16) return FS_ERR_UNSUPPORTED;  // matching_dim_size of FreeSplat (48) / SimpleRecon (16)
+    hipStream_t st = (hipStream_t)stream_;
+    const int hw = h * w;
+    float* curT = (float*)workspace;
+    float* srcT = curT + (size_t)B * hw * C;
+    {
+        ScopedStage prof_(kStCostVolume, st);
+        const long long tot1 = (long long)B * hw * C, tot2 = tot1 * K;
+        hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot1 + 255) / 256, 65536)),
+                           dim3(256), 0, st, cur_feats, curT, C, hw, B);
+        hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
+                           dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
+        const int groups = (hw + 31) / 32;
+        if (C == 48)
+            hipLaunchKernelGGL(cost_volume_kernel<24>, dim3(B * groups), dim3(256), 0, st, B, K, h, w, D, curT,
+                               srcT, src_extrinsics, src_Ks, cur_invK, planes, (long long)plane_stride_b,
+                               (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3,
+                               out);
+        else
+            hipLaunchKernelGGL(cost_volume_kernel<8>, dim3(B * groups), dim3(256), 0, st, B, K, h, w, D, curT,
+                               srcT, src_extrinsics, src_Ks, cur_invK, planes, (long long)plane_stride_b,
+                               (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3,
+                               out);
+    }
+    FS_CHECK_LAUNCH("cost_volume");
+    return FS_OK;
+}

@@ -123,6 +123,32 @@ int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const f
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs,
                        float* dL_dcolors, float* dL_dopacities, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * Plane-sweep cost volume                                                               *
+ * ------------------------------------------------------------------------------------ */
+
+/* Bytes of the re-layout workspace fs_cost_volume_forward needs (pixel-major copies of the
+ * current and source feature maps). */
+size_t fs_cost_volume_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w);
+
+/*
+ * AVGFeatureVolumeManager.build_cost_volume (cost_volume.py:429-619) fused into one pass.
+ * cur_feats[B,C,h,w], src_feats[B,K,C,h,w], src_extrinsics[B,K,4,4] (source<-current),
+ * src_Ks[B,K,4,4] (pixel units at the matching resolution), cur_invK[B,4,4];
+ * planes: depth of plane d for batch b at pixel p = planes[b*stride_b + d*stride_d + p*stride_pix]
+ * (the generated planes of cost_volume.py:98-134 use strides (0,1,0) over a [D] array);
+ * MLP (networks.py:218-236): w1[32,C+1], b1[32], w2[32,32], b2[32], w3[1,32], b3[1], LeakyReLU(0.01).
+ * out[B,D,h,w].  C must be 48 (FreeSplat) or 16.  fp32 throughout; the 49->32->32 layers run on
+ * v_mfma_f32_32x32x2_f32 (exact fp32).
+ */
+int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                           const float* cur_feats, const float* src_feats,
+                           const float* src_extrinsics, const float* src_Ks, const float* cur_invK,
+                           const float* planes, int64_t plane_stride_b, int64_t plane_stride_d,
+                           int64_t plane_stride_pix, const float* w1, const float* b1,
+                           const float* w2, const float* b2, const float* w3, const float* b3,
+                           void* workspace, float* out, void* stream);
+
 /* Debug/test accessors into the opaque buffers (device pointers, no copies). */
 const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t H, int32_t W);  /* [T+1] offsets */
 const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] (id << 4) | 8x8-quadrant mask */

@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz by IMPORTING the reference (read-only at /root/reference) in the
+build container and running its own code on seeded synthetic inputs.  Run here only:
+
+    python tests/golden/make_golden.py
+
+The reference's Python never travels to the GPU box; only the arrays written here do.  Nothing
+below copies reference source: it stubs the reference's missing third-party imports
+(SURVEY.md Appendix D), imports its modules, and calls them.
+
+Fixtures (fp32, torch.manual_seed, sizes per SURVEY.md 8(c)):
+  cv_small_k1.npz / cv_small_k2.npz   AVGFeatureVolumeManager.forward (cost_volume.py:351-381, 429-619)
+  cv_native_stat.json                  96x128, D=128 summary statistics + SHA-256 of the output
+  ptf_small.npz / ptf_tie.npz          EncoderFreeSplat.fuse_gaussians (encoder_freesplat.py:431-522)
+  adapter_small.npz                    GaussianAdapter.forward fusion=True / False (gaussian_adapter.py:135-201)
+  framing.npz                          get_fov / get_projection_matrix + render_cuda's matrices
+                                       (projection.py:233-247, cuda_splatting.py:17-87)
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, OUT)
+from inputs import cameras, cv_inputs, ptf_inputs  # noqa: E402  (seeded input generators shared with the tests)
+
+
+def install_shim():
+    stub_dir = tempfile.mkdtemp(prefix="fs_stub_")
+    os.makedirs(os.path.join(stub_dir, "kornia"))
+    with open(os.path.join(stub_dir, "kornia", "__init__.py"), "w") as f:
+        f.write("from . import filters\n")
+    with open(os.path.join(stub_dir, "kornia", "filters.py"), "w") as f:
+        f.write("import torch\n"
+                "def blur_pool2d(x: torch.Tensor, kernel_size: int) -> torch.Tensor:\n    return x\n"
+                "def gaussian_blur2d(*a, **k):\n    raise NotImplementedError\n"
+                "def spatial_gradient(*a, **k):\n    raise NotImplementedError\n")
+    sys.path[:0] = [stub_dir, REF]
+
+    class _Sub:
+        def __class_getitem__(cls, item):
+            return item[0] if isinstance(item, tuple) else item
+
+    jt = types.ModuleType("jaxtyping")
+    for n in ("Float", "Int64", "Bool", "Int", "UInt8", "Shaped"):
+        setattr(jt, n, _Sub)
+    jt.install_import_hook = None
+    sys.modules["jaxtyping"] = jt
+    for name in ("torchvision", "torchvision.models", "torchvision.transforms",
+                 "torchvision.transforms.functional", "timm", "cv2", "e3nn", "e3nn.o3"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["e3nn.o3"].matrix_to_angles = None
+    sys.modules["e3nn.o3"].wigner_D = None
+    sys.modules["e3nn"].o3 = sys.modules["e3nn.o3"]
+
+    def pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, path)]
+        sys.modules[name] = m
+        return m
+
+    pkg("src", "src")
+    pkg("src.model", "src/model")
+    pkg("src.model.encoder", "src/model/encoder")
+    b = pkg("src.model.encoder.backbone", "src/model/encoder/backbone")
+    b.Backbone = b.BackboneCfg = object
+    b.get_backbone = None
+    pkg("src.model.encoder.visualization", "src/model/encoder/visualization")
+    pkg("src.model.encoder.epipolar", "src/model/encoder/epipolar")
+    pkg("src.model.decoder", "src/model/decoder")
+    pkg("src.dataset", "src/dataset")
+    pkg("src.dataset.shims", "src/dataset/shims")
+    m = types.ModuleType("src.dataset.shims.patch_shim"); m.apply_patch_shim = None
+    sys.modules[m.__name__] = m
+    m = types.ModuleType("src.dataset.types"); m.BatchedExample = dict; m.DataShim = object; m.BatchedViews = dict
+    sys.modules[m.__name__] = m
+    m = types.ModuleType("src.model.encoder.visualization.encoder_visualizer_epipolar_cfg")
+    m.EncoderVisualizerEpipolarCfg = object
+    sys.modules[m.__name__] = m
+    m = types.ModuleType("diff_gaussian_rasterization_depth")
+    m.GaussianRasterizationSettings = None; m.GaussianRasterizer = None
+    sys.modules[m.__name__] = m
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name), **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                                     for k, v in arrs.items()})
+    print("wrote", name, {k: tuple(np.asarray(v.detach().cpu() if torch.is_tensor(v) else v).shape) for k, v in arrs.items()})
+
+
+def gen_cost_volume():
+    from src.model.encoder.modules.cost_volume import AVGFeatureVolumeManager
+    for name, V, K, behind in (("cv_small_k1", 2, 1, False), ("cv_small_k2", 3, 2, True)):
+        h4, w4, D, C = 12, 16, 8, 48
+        torch.manual_seed(100 + V)
+        cv = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                     mlp_channels=[202, 32, 32, 1], matching_dim_size=C).eval()
+        kw = cv_inputs(V, K, h4, w4, C, seed=200 + V, behind=behind)
+        with torch.no_grad():
+            out = cv(**kw)
+        sd = {k.replace(".", "__"): v for k, v in cv.state_dict().items()}
+        save(name + ".npz", out=out, D=D, **kw, **sd)
+    # native-size statistics
+    h4, w4, D, C, V, K = 96, 128, 128, 48, 2, 1
+    torch.manual_seed(7)
+    cv = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                 mlp_channels=[202, 32, 32, 1], matching_dim_size=C).eval()
+    kw = cv_inputs(V, K, h4, w4, C, seed=8)
+    with torch.no_grad():
+        out = cv(**kw)
+    o = out.numpy()
+    stat = dict(shape=list(o.shape), mean=float(o.mean()), abs_mean=float(np.abs(o).mean()), std=float(o.std()),
+                min=float(o.min()), max=float(o.max()), sha256=hashlib.sha256(o.tobytes()).hexdigest(),
+                seed_module=7, seed_inputs=8, probe=[float(x) for x in o[0, ::16, 40, 60]])
+    json.dump(stat, open(os.path.join(OUT, "cv_native_stat.json"), "w"), indent=1)
+    print("wrote cv_native_stat.json", stat["shape"], stat["mean"])
+
+
+def gen_ptf_and_adapter():
+    from src.model.encoder.encoder_freesplat import EncoderFreeSplat
+    from src.model.encoder.modules.networks import GRU
+    from src.model.encoder.common.gaussian_adapter import GaussianAdapter, GaussianAdapterCfg
+    from src.geometry.projection import sample_image_grid
+    for name, V, tie in (("ptf_small", 3, False), ("ptf_tie", 2, True)):
+        h, w = 24, 32
+        E, Kn, depths, lat, dens, wts = ptf_inputs(V, h, w, seed=300 + V, tie=tie)
+        torch.manual_seed(400 + V)
+        gru = GRU().eval()
+        adapter = GaussianAdapter(GaussianAdapterCfg(0.5, 15.0, 2))
+        with torch.no_grad():
+            # argument shapes exactly as encoder_freesplat.py:317-326 passes them
+            xy_ray, _ = sample_image_grid((h, w), torch.device("cpu"))
+            xy_ray = xy_ray.reshape(h * w, 1, 2)[None, None].expand(1, V, h * w, 1, 2)
+            coords = adapter.forward(E[None, :, None, None, None], Kn[None, :, None, None, None],
+                                     xy_ray[:, :, :, :, None, :], depths.view(1, V, h * w, 1, 1), dens, lat, (h, w),
+                                     fusion=True)
+            out = EncoderFreeSplat.fuse_gaussians(types.SimpleNamespace(gru=gru), [lat], [coords], dens, wts,
+                                                  depths.view(V, 1, h, w), E[None], Kn[None], (h, w))
+        sd = {"gru__" + k.replace(".", "__"): v for k, v in gru.state_dict().items()}
+        save(name + ".npz", latents=lat, coords=coords, densities=dens, weights=wts, depths=depths,
+             extrinsics=E, intrinsics=Kn, h=h, w=w, out_latent=out[0], out_xyz=out[1], out_extrinsics=out[2],
+             out_depths=out[3], **sd)
+    # adapter, fusion=False
+    h, w, V = 8, 12, 2
+    torch.manual_seed(500)
+    adapter = GaussianAdapter(GaussianAdapterCfg(0.5, 15.0, 2))
+    M = 40
+    E = torch.eye(4).repeat(M, 1, 1) + 0.05 * torch.randn(M, 4, 4)  # blended, non-rigid "extrinsics"
+    Kn = torch.tensor([[0.9, 0, 0.49], [0, 1.2, 0.51], [0, 0, 1]])
+    raw = torch.randn(1, M, 1, 7 + 27)
+    dep = 1.0 + torch.rand(1, M)
+    opa = torch.rand(1, M, 1, 1)
+    xyz = torch.randn(1, M, 3)
+    with torch.no_grad():
+        # argument shapes exactly as encoder_freesplat.py:376-386 passes them
+        g = adapter.forward(E.view(1, 1, M, 1, 1, 4, 4), Kn.view(1, 1, 1, 1, 1, 3, 3).expand(1, 1, M, 1, 1, 3, 3), None,
+                            dep.view(1, 1, M, 1, 1), opa.view(1, 1, M, 1, 1), raw.view(1, 1, M, 1, 1, 34), (h, w),
+                            fusion=False, coords=xyz.view(1, 1, M, 1, 1, 3))
+    save("adapter_small.npz", extrinsics=E, intrinsics=Kn, raw=raw, depths=dep, opacities=opa, coords=xyz, h=h, w=w,
+         out_means=g.means, out_cov=g.covariances, out_harmonics=g.harmonics, out_opacities=g.opacities,
+         out_scales=g.scales, out_rotations=g.rotations, sh_mask=adapter.sh_mask)
+
+
+def gen_framing():
+    from src.model.decoder.cuda_splatting import get_projection_matrix
+    from src.geometry.projection import get_fov
+    V = 3
+    E, Kn = cameras(V, 10, 10, seed=9)
+    E[:, :3, 3] += torch.tensor([0.1, -0.2, 0.3])
+    near, far = torch.tensor([0.5, 0.5, 0.25]), torch.tensor([15.0, 15.0, 10.0])
+    fov = get_fov(Kn)
+    scale = 1 / near
+    Es = E.clone()
+    Es[..., :3, 3] = Es[..., :3, 3] * scale[:, None]
+    P = get_projection_matrix(near * scale, far * scale, fov[:, 0], fov[:, 1])
+    view = Es.inverse().transpose(1, 2)
+    full = view @ P.transpose(1, 2)
+    save("framing.npz", extrinsics=E, intrinsics=Kn, near=near, far=far, fov=fov, projection=P, view=view, full=full,
+         tan=(0.5 * fov).tan(), campos=Es[:, :3, 3])
+
+
+if __name__ == "__main__":
+    install_shim()
+    gen_framing()
+    gen_cost_volume()
+    gen_ptf_and_adapter()

@@ -1,0 +1,108 @@
+"""GPU parity of the fused HIP cost volume (C ABI fs_cost_volume_forward) against (a) the
+reference's own outputs (golden fixtures) and (b) the CPU oracle at larger / ragged sizes.
+Tolerance: 1e-4 abs on O(1) outputs (fp32; the MLP runs on exact-fp32 MFMA, summation orders differ)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def _load(name):
+    z = np.load(os.path.join(HERE, "golden", name))
+    return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+
+
+def _module_from_fixture(g, h4, w4, D, C, dev):
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    sd = {k.replace("__", "."): v for k, v in g.items() if k.startswith(("mlp__", "linear_ramp", "backprojector", "projector"))}
+    missing, unexpected = m.load_state_dict(sd, strict=True), None  # same keys as the reference module
+    return m.to(dev)
+
+
+def _run(m, kw, dev, **extra):
+    args = {k: v.to(dev) for k, v in kw.items()}
+    with torch.no_grad():
+        return m(**args, **extra).cpu()
+
+
+@pytest.mark.parametrize("name", ["cv_small_k1.npz", "cv_small_k2.npz"])
+def test_matches_reference_golden(hip_device, name):
+    g = _load(name)
+    kw = {k: g[k] for k in ("cur_feats", "src_feats", "src_extrinsics", "src_poses", "src_Ks", "cur_invK",
+                            "min_depth", "max_depth")}
+    m = _module_from_fixture(g, 12, 16, int(g["D"]), 48, hip_device)
+    out = _run(m, kw, hip_device)
+    assert out.shape == g["out"].shape
+    assert (out - g["out"]).abs().max().item() <= ATOL
+
+
+def test_native_size_vs_reference_statistics_and_oracle(hip_device):
+    import inputs
+    from oracle import cost_volume_oracle as cvo
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    stat = json.load(open(os.path.join(HERE, "golden", "cv_native_stat.json")))
+    h4, w4, D, C, V, K = 96, 128, 128, 48, 2, 1
+    torch.manual_seed(stat["seed_module"])
+    m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=stat["seed_inputs"])
+    sd = {k.replace(".", "__"): v for k, v in m.state_dict().items()}
+    ref = cvo.cost_volume(kw["cur_feats"], kw["src_feats"], kw["src_extrinsics"], kw["src_Ks"], kw["cur_invK"],
+                          kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
+    out = _run(m.to(hip_device), kw, hip_device)
+    assert (out - ref).abs().max().item() <= ATOL
+    o = out.numpy()
+    assert abs(o.mean() - stat["mean"]) < 1e-5 and abs(o.std() - stat["std"]) < 1e-5
+    np.testing.assert_allclose(o[0, ::16, 40, 60], stat["probe"], atol=ATOL)
+
+
+@pytest.mark.parametrize("V,K,h4,w4,D,behind", [(3, 2, 15, 21, 11, True), (4, 3, 30, 40, 16, False),
+                                                 (2, 1, 5, 7, 3, True), (2, 1, 64, 64, 128, False)])
+def test_ragged_shapes_vs_oracle(hip_device, V, K, h4, w4, D, behind):
+    import inputs
+    from oracle import cost_volume_oracle as cvo
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    torch.manual_seed(V * 100 + K)
+    m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=48)
+    kw = inputs.cv_inputs(V, K, h4, w4, 48, seed=17 + V, behind=behind)
+    sd = {k.replace(".", "__"): v for k, v in m.state_dict().items()}
+    ref = cvo.cost_volume(kw["cur_feats"], kw["src_feats"], kw["src_extrinsics"], kw["src_Ks"], kw["cur_invK"],
+                          kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
+    out = _run(m.to(hip_device), kw, hip_device)
+    assert (out - ref).abs().max().item() <= ATOL
+
+
+def test_zero_features_exact_zero_semantics(hip_device):
+    """All-zero source features: every dot is exactly 0 -> no valid source -> MLP of the zero vector."""
+    import inputs
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    torch.manual_seed(5)
+    m = AVGFeatureVolumeManager(matching_height=8, matching_width=8, num_depth_bins=4,
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=48)
+    kw = inputs.cv_inputs(2, 1, 8, 8, 48, seed=3)
+    kw["src_feats"] = torch.zeros_like(kw["src_feats"])
+    with torch.no_grad():
+        const = m.mlp.net(torch.zeros(1, 49)).item()
+    out = _run(m.to(hip_device), kw, hip_device)
+    assert (out - const).abs().max().item() <= 1e-6
+
+
+def test_cpu_tensor_raises(hip_device):
+    import inputs
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    m = AVGFeatureVolumeManager(matching_height=8, matching_width=8, num_depth_bins=4,
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=48)
+    kw = inputs.cv_inputs(2, 1, 8, 8, 48, seed=3)
+    with pytest.raises(RuntimeError):
+        m(**kw)
