@@ -1,0 +1,262 @@
+// ptf.hip -- the data-dependent core of one Pixel-wise Triplet Fusion fold step, MI355X (gfx950).
+//
+// Replaces the index-producing part of EncoderFreeSplat.fuse_gaussians
+// (src/model/encoder/encoder_freesplat.py:443-482 and the ~fusion_mask selections of :508-519;
+// exact semantics: SURVEY.md Appendix C): project the M global Gaussians into view i, z-buffer
+// them per pixel (scatter amin), test depth consistency, pick the winners, and emit the three
+// ordered index lists the fold needs:
+//     keep_idx   ascending m that are NOT fused           (global[~mask])
+//     fuse_idx   ascending m that ARE fused, fuse_pix their pixels of view i
+//     append_pix ascending pixels of view i that start a new Gaussian (~fusion_mask)
+// The reference does this with scatter_reduce_, two torch.isin passes over M-sized index tensors,
+// boolean-mask indexing and four host syncs per view; here it is 6 short launches and no sync:
+// atomicMin on the float bits (z > 0, so uint order == float order), byte flags, and a
+// two-level ballot/prefix-sum compaction that preserves ascending order.
+//
+// Integer/index work => bit-exact against the oracle: compiled with -ffp-contract=off, the
+// projection uses plain IEEE mul/add/div in a fixed order, rounding is round-half-to-even.
+#include "fs_common.h"
+
+namespace fs {
+
+constexpr uint32_t kZInit = 0x461C4000u;  // bits of 10000.0f (encoder_freesplat.py:464)
+constexpr int kScanBlock = 1024;          // elements per compaction workgroup (256 threads x 4)
+
+__global__ __launch_bounds__(256) void ptf_fill_kernel(uint32_t* __restrict__ zbuf, int P)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < P) zbuf[p] = kZInit;
+}
+
+// w2c = inverse(extrinsics_i) row-major [16]; kpix = {fx, fy, cx, cy} in pixels
+__global__ __launch_bounds__(256) void ptf_project_kernel(int M, int h, int w, const float* __restrict__ xyz,
+                                                          const float* __restrict__ w2c,
+                                                          const float* __restrict__ kpix,
+                                                          int32_t* __restrict__ pix_of,
+                                                          uint32_t* __restrict__ zbits_of,
+                                                          uint32_t* __restrict__ zbuf)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float x = xyz[3 * (size_t)m], y = xyz[3 * (size_t)m + 1], z = xyz[3 * (size_t)m + 2];
+    const float cx = ((w2c[0] * x + w2c[1] * y) + w2c[2] * z) + w2c[3];
+    const float cy = ((w2c[4] * x + w2c[5] * y) + w2c[6] * z) + w2c[7];
+    const float cz = ((w2c[8] * x + w2c[9] * y) + w2c[10] * z) + w2c[11];
+    const float px = (cx / cz) * kpix[0] + kpix[2];
+    const float py = (cy / cz) * kpix[1] + kpix[3];
+    const float col = __builtin_rintf(px), row = __builtin_rintf(py);  // torch.round: half to even
+    const bool valid = row >= 0.0f && row < (float)h && col >= 0.0f && col < (float)w && cz > 0.0f;
+    int32_t pix = -1;
+    const uint32_t zb = __float_as_uint(cz);
+    if (valid) {
+        pix = (int)row * w + (int)col;
+        atomicMin(&zbuf[pix], zb);
+    }
+    pix_of[m] = pix;
+    zbits_of[m] = zb;
+}
+
+__device__ __forceinline__ bool fusion_mask(uint32_t zb, float d, float depth_thres)
+{
+    // |zbuf - d_i| < max(0.05 d_i, depth_thres)   (encoder_freesplat.py:468)
+    return fabsf(__uint_as_float(zb) - d) < fmaxf(d * 0.05f, depth_thres);
+}
+
+__global__ __launch_bounds__(256) void ptf_flags_kernel(int M, int P, const int32_t* __restrict__ pix_of,
+                                                        const uint32_t* __restrict__ zbits_of,
+                                                        const uint32_t* __restrict__ zbuf,
+                                                        const float* __restrict__ depth_i, float depth_thres,
+                                                        uint8_t* __restrict__ win, uint8_t* __restrict__ app)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < M) {
+        const int pix = pix_of[e];
+        bool wflag = false;
+        if (pix >= 0) {
+            const uint32_t zb = zbuf[pix];
+            wflag = zb == zbits_of[e] && fusion_mask(zb, depth_i[pix], depth_thres);
+        }
+        win[e] = wflag ? 1 : 0;
+    }
+    if (e < P) app[e] = fusion_mask(zbuf[e], depth_i[e], depth_thres) ? 0 : 1;
+}
+
+// ---- order-preserving compaction -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t load4(const uint8_t* __restrict__ f, int base, int n)
+{
+    // 4 consecutive byte flags (0/1) starting at `base`, zero past n
+    uint32_t v = 0;
+    if (base + 3 < n && ((((uintptr_t)(f + base)) & 3) == 0)) {
+        v = *(const uint32_t*)(f + base);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (base + k < n) v |= (uint32_t)f[base + k] << (8 * k);
+    }
+    return v;
+}
+
+// blocks [0, nbM) count `win` over M, blocks [nbM, nbM+nbP) count `app` over P
+__global__ __launch_bounds__(256) void ptf_count_kernel(int M, int P, int nbM, const uint8_t* __restrict__ win,
+                                                        const uint8_t* __restrict__ app,
+                                                        uint32_t* __restrict__ block_counts)
+{
+    __shared__ uint32_t s_w[4];
+    const bool second = (int)blockIdx.x >= nbM;
+    const uint8_t* f = second ? app : win;
+    const int n = second ? P : M;
+    const int blk = second ? blockIdx.x - nbM : blockIdx.x;
+    const uint32_t v = load4(f, blk * kScanBlock + threadIdx.x * 4, n);
+    uint32_t c = __popc(v);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of the two block-count ranges (one workgroup); counts = {n_keep, n_fuse, n_append}
+__global__ __launch_bounds__(1024) void ptf_scan_blocks_kernel(int M, int nbM, int nbP,
+                                                               uint32_t* __restrict__ block_counts,
+                                                               int32_t* __restrict__ counts)
+{
+    __shared__ uint32_t part[1024];
+    for (int range = 0; range < 2; ++range) {
+        uint32_t* a = block_counts + (range ? nbM : 0);
+        const int n = range ? nbP : nbM;
+        const int t = threadIdx.x;
+        const int per = (n + 1023) / 1024;
+        const int lo = min(n, t * per), hi = min(n, lo + per);
+        uint32_t s = 0;
+        for (int k = lo; k < hi; ++k) s += a[k];
+        part[t] = s;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t v = (t >= off) ? part[t - off] : 0u;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        uint32_t run = part[t] - s;
+        for (int k = lo; k < hi; ++k) {
+            const uint32_t c = a[k];
+            a[k] = run;
+            run += c;
+        }
+        if (t == 1023) {
+            if (range == 0) { counts[1] = (int32_t)part[1023]; counts[0] = M - (int32_t)part[1023]; }
+            else counts[2] = (int32_t)part[1023];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void ptf_emit_kernel(int M, int P, int nbM, const uint8_t* __restrict__ win,
+                                                       const uint8_t* __restrict__ app,
+                                                       const int32_t* __restrict__ pix_of,
+                                                       const uint32_t* __restrict__ block_offsets,
+                                                       long long* __restrict__ keep_idx,
+                                                       long long* __restrict__ fuse_idx,
+                                                       long long* __restrict__ fuse_pix,
+                                                       long long* __restrict__ append_pix)
+{
+    __shared__ uint32_t s_w[4];
+    const bool second = (int)blockIdx.x >= nbM;
+    const uint8_t* f = second ? app : win;
+    const int n = second ? P : M;
+    const int blk = second ? blockIdx.x - nbM : blockIdx.x;
+    const int base = blk * kScanBlock + threadIdx.x * 4;
+    const uint32_t v = load4(f, base, n);
+    const uint32_t c = __popc(v);
+    // exclusive scan of c over the 256 threads: wave inclusive scan, then 4 wave totals via LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = c;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t o = __shfl_up(inc, s, 64);
+        if (lane >= s) inc += o;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < wave) wave_off += s_w[k];
+    uint32_t rank = block_offsets[blockIdx.x] + wave_off + inc - c;  // set flags before `base`
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = base + k;
+        if (e >= n) break;
+        const bool on = (v >> (8 * k)) & 1u;
+        if (second) {
+            if (on) append_pix[rank] = e;
+        } else if (on) {
+            fuse_idx[rank] = e;
+            fuse_pix[rank] = pix_of[e];
+        } else {
+            keep_idx[(uint32_t)e - rank] = e;  // rank = number of fused entries before e
+        }
+        rank += on ? 1u : 0u;
+    }
+}
+
+__host__ __device__ inline size_t ptf_scratch_layout(int M, int P, size_t off[7])
+{
+    const int nbM = (M + kScanBlock - 1) / kScanBlock, nbP = (P + kScanBlock - 1) / kScanBlock;
+    size_t o = 0;
+    off[0] = o; o += align_up((size_t)P * 4, 256);            // zbuf
+    off[1] = o; o += align_up((size_t)M * 4, 256);            // pix_of
+    off[2] = o; o += align_up((size_t)M * 4, 256);            // zbits_of
+    off[3] = o; o += align_up((size_t)M, 256);                // win
+    off[4] = o; o += align_up((size_t)P, 256);                // app
+    off[5] = o; o += align_up((size_t)(nbM + nbP) * 4, 256);  // block counts / offsets
+    off[6] = o;
+    return o;
+}
+
+}  // namespace fs
+
+using namespace fs;
+
+FS_API size_t fs_ptf_scratch_bytes(int32_t M, int32_t h, int32_t w)
+{
+    if (M < 0 || h <= 0 || w <= 0) return 0;
+    size_t off[7];
+    return ptf_scratch_layout(M > 0 ? M : 1, h * w, off);
+}
+
+FS_API int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const float* w2c,
+                        const float* kpix, const float* depth_i, float depth_thres, void* scratch,
+                        int64_t* keep_idx, int64_t* fuse_idx, int64_t* fuse_pix, int64_t* append_pix,
+                        int32_t* counts, void* stream_)
+{
+    if (M < 0 || h <= 0 || w <= 0 || !w2c || !kpix || !depth_i || !scratch || !append_pix || !counts)
+        return FS_ERR_INVALID_ARG;
+    if (M > 0 && (!xyz || !keep_idx || !fuse_idx || !fuse_pix)) return FS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    const int P = h * w;
+    size_t off[7];
+    ptf_scratch_layout(M > 0 ? M : 1, P, off);
+    char* s = (char*)scratch;
+    uint32_t* zbuf = (uint32_t*)(s + off[0]);
+    int32_t* pix_of = (int32_t*)(s + off[1]);
+    uint32_t* zbits_of = (uint32_t*)(s + off[2]);
+    uint8_t* win = (uint8_t*)(s + off[3]);
+    uint8_t* app = (uint8_t*)(s + off[4]);
+    uint32_t* blocks = (uint32_t*)(s + off[5]);
+    const int nbM = (M + kScanBlock - 1) / kScanBlock, nbP = (P + kScanBlock - 1) / kScanBlock;
+    ScopedStage prof_(kStPtf, st);
+    hipLaunchKernelGGL(ptf_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, st, zbuf, P);
+    if (M > 0)
+        hipLaunchKernelGGL(ptf_project_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, h, w, xyz, w2c, kpix,
+                           pix_of, zbits_of, zbuf);
+    const int E = M > P ? M : P;
+    hipLaunchKernelGGL(ptf_flags_kernel, dim3((E + 255) / 256), dim3(256), 0, st, M, P, pix_of, zbits_of, zbuf,
+                       depth_i, depth_thres, win, app);
+    hipLaunchKernelGGL(ptf_count_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, P, nbM, win, app, blocks);
+    hipLaunchKernelGGL(ptf_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, M, nbM, nbP, blocks, counts);
+    hipLaunchKernelGGL(ptf_emit_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, P, nbM, win, app, pix_of, blocks,
+                       (long long*)keep_idx, (long long*)fuse_idx, (long long*)fuse_pix, (long long*)append_pix);
+    FS_CHECK_LAUNCH("ptf_match");
+    return FS_OK;
+}

@@ -1,0 +1,142 @@
+"""Pixel-wise Triplet Fusion: drop-in for EncoderFreeSplat.fuse_gaussians.
+
+Mirrors /root/reference/src/model/encoder/encoder_freesplat.py:431-522 (same signature, same four
+outputs in the same ORDER) together with the modules it needs: `GRU`
+(src/model/encoder/modules/networks.py:188-214, parameter names mlp_{z,r,n}.{0,2}.{weight,bias} and
+construction order kept so checkpoints and seeded inits carry over) and `positional_encoding`
+(encoder_freesplat.py:62-77).
+
+Split of work per fold step:
+  * everything data-dependent and non-differentiable -- projection of the M global Gaussians, the
+    per-pixel z-buffer, the depth-consistency mask, winner selection and the three ORDERED index
+    lists -- is fs_ptf_match in libfreesplat_hip.so (6 launches, no host sync, replaces
+    scatter_reduce_ + 2x torch.isin + boolean-mask indexing + 4 syncs of the reference);
+  * the differentiable part (gather by those indices, GRU, density-weighted blends, concatenation)
+    stays in torch ops on the device, so autograd gives the reference's gradients unchanged; the GRU's
+    176/152 -> 64 -> 64 linears are plain library GEMMs (rocBLAS).
+One host sync per view remains (the three list lengths size the torch tensors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+
+def positional_encoding(positions: Tensor, freqs: int, ori: bool = False) -> Tensor:
+    bands = (2 ** torch.arange(freqs).float()).to(positions.device)
+    ori_c = positions.shape[-1]
+    pts = (positions[..., None] * bands).reshape(positions.shape[:-1] + (freqs * positions.shape[-1],))
+    if ori:
+        return torch.cat([positions, torch.sin(pts), torch.cos(pts)], dim=-1).reshape(
+            pts.shape[:-1] + (pts.shape[-1] * 2 + ori_c,))
+    return torch.stack([torch.sin(pts), torch.cos(pts)], dim=-1).reshape(pts.shape[:-1] + (pts.shape[-1] * 2,))
+
+
+class GRU(nn.Module):
+    def __init__(self, input_channel=64, hidden_channel=64, weights_dim=24):
+        super().__init__()
+        mk = lambda d: nn.Sequential(nn.Linear(d, hidden_channel), nn.ReLU(), nn.Linear(hidden_channel, hidden_channel))
+        self.mlp_z = mk(hidden_channel + input_channel + 2 * weights_dim)
+        self.mlp_r = mk(hidden_channel + input_channel + 2 * weights_dim)
+        self.mlp_n = mk(hidden_channel + input_channel + 1 * weights_dim)
+
+    def forward(self, input_feat, hidden_feat, input_weights_emb, hidden_weights_emb):
+        if len(input_feat.size()) == 2 and input_feat.size(0) == 1:
+            input_feat = input_feat.unsqueeze(1)
+        if hidden_feat is None:
+            hidden_feat = torch.zeros_like(input_feat)
+        x1 = torch.cat((input_feat, input_weights_emb), dim=-1)
+        h1 = torch.cat((hidden_feat, hidden_weights_emb), dim=-1)
+        cat = torch.cat((h1, x1), dim=-1)
+        r = torch.sigmoid(self.mlp_r(cat))
+        z = torch.sigmoid(self.mlp_z(cat))
+        q = torch.tanh(self.mlp_n(torch.cat((r * hidden_feat, x1), dim=-1)))
+        return (1 - z) * hidden_feat + z * q
+
+
+def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, w: int, depth_thres: float = 0.1):
+    """fs_ptf_match on device tensors: xyz [M,3], w2c [4,4], kpix [4], depth_i [h*w] -> ascending int64
+    index tensors (keep_idx, fuse_idx, fuse_pix, append_pix).  One host sync (the three counts)."""
+    if xyz.device.type != "cuda":
+        raise RuntimeError(f"freesplat_amd PTF: tensors must live on a HIP device (got {xyz.device}); no CPU path")
+    dev = xyz.device
+    M, P = xyz.shape[0], h * w
+    L = _lib.lib()
+    xyz = xyz.detach().float().contiguous()
+    scratch = torch.empty(L.fs_ptf_scratch_bytes(M, h, w), dtype=torch.uint8, device=dev)
+    keep = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
+    fuse = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
+    fpix = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
+    app = torch.empty(P, dtype=torch.int64, device=dev)
+    counts = torch.empty(3, dtype=torch.int32, device=dev)
+    p = _lib.ptr
+    _lib.check(L.fs_ptf_match(M, h, w, p(xyz), p(w2c.detach().float().contiguous()),
+                              p(kpix.detach().float().contiguous()), p(depth_i.detach().float().contiguous()),
+                              C.c_float(depth_thres), p(scratch), p(keep), p(fuse), p(fpix), p(app), p(counts),
+                              _lib.current_stream()), "fs_ptf_match")
+    nk, nf, na = counts.tolist()
+    return keep[:nk], fuse[:nf], fpix[:nf], app[:na]
+
+
+def fuse_gaussians(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
+                   depth_thres=0.1):
+    """Same contract as EncoderFreeSplat.fuse_gaussians (encoder_freesplat.py:431-522); `self` only
+    needs a `.gru` attribute.  gaussians = [latents [1,V,P,64]], coords = [[1,V,P,1,1,3]],
+    densities / weight_emb [1,V,P,1,1], depths [V,1,h,w], extrinsics [1,V,4,4], intrinsics [1,V,3,3].
+    Returns (latents [1,M,64], xyz [1,M,3], extrinsics [1,M,4,4], depths [1,M])."""
+    length = gaussians[0].shape[1]
+    G = gaussians[0][:, 0]
+    R = densities[:, 0]
+    O = weight_emb[:, 0]
+    X = coords[0][:, 0, :, 0, 0]
+    Ex = extrinsics[:, 0][:, None].repeat(1, G.shape[1], 1, 1)
+    depths = depths.reshape(depths.shape[0], -1)
+    Dp = depths[None, 0]
+    h, w = image_shape
+    for i in range(1, length):
+        extrinsic = extrinsics[0, i]
+        K = intrinsics[0, i].clone()
+        K[:1, :] *= w
+        K[1:2, :] *= h
+        kpix = torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+        w2c = torch.linalg.inv_ex(extrinsic).inverse
+        keep, fuse, fpix, app = match_view(X[0], w2c, kpix, depths[i], h, w, depth_thres)
+        if fuse.numel() > 0:
+            xe = positional_encoding(torch.cat([R[:, fuse], weight_emb[:, i, fpix]], dim=-1), 6)
+            he = positional_encoding(torch.cat([densities[:, i, fpix], O[:, fuse]], dim=-1), 6)
+            fused = self.gru(gaussians[0][:, i, fpix].unsqueeze(2), G[:, fuse].unsqueeze(2), xe, he).squeeze(2)
+            w0 = R[:, fuse].repeat(1, 1, 1, 2)
+            w1 = densities[:, i, fpix].repeat(1, 1, 1, 2)
+            G = torch.cat([G[:, keep], fused], dim=1)
+            X = torch.cat([X[:, keep], (X[:, fuse] * w0[..., 1] + coords[0][:, i, fpix, 0, 0] * w1[..., 1])
+                           / (w0[..., 1] + w1[..., 1])], dim=1)
+            Ex = torch.cat([Ex[:, keep], (Ex[:, fuse] * w0[..., :1] + extrinsics[:, i, None] * w1[..., :1])
+                            / (w0[..., :1] + w1[..., :1])], dim=1)
+            Dp = torch.cat([Dp[:, keep], (Dp[:, fuse] * w0[..., 0, 0] + depths[None, i, fpix] * w1[..., 0, 0])
+                            / (w0[..., 0, 0] + w1[..., 0, 0])], dim=1)
+            R_new = R[:, fuse] + densities[:, i, fpix]
+            O_new = O[:, fuse] + weight_emb[:, i, fpix]
+            R = torch.cat([R[:, keep], R_new], dim=1)
+            O = torch.cat([O[:, keep], O_new], dim=1)
+        G = torch.cat([G, gaussians[0][:, i, app]], dim=1)
+        X = torch.cat([X, coords[0][:, i, app, 0, 0]], dim=1)
+        R = torch.cat([R, densities[:, i, app]], dim=1)
+        O = torch.cat([O, weight_emb[:, i, app]], dim=1)
+        Ex = torch.cat([Ex, extrinsics[:, i, None].repeat(1, app.numel(), 1, 1)], dim=1)
+        Dp = torch.cat([Dp, depths[None, i, app]], dim=1)
+    return G, X, Ex, Dp
+
+
+class PixelwiseTripletFusion(nn.Module):
+    """Owner of the `gru` sub-module with the reference's `fuse_gaussians` method bound to it, so that
+    `encoder.gru.*` state-dict keys and `encoder.fuse_gaussians(...)` call sites carry over."""
+
+    def __init__(self):
+        super().__init__()
+        self.gru = GRU()
+
+    fuse_gaussians = fuse_gaussians

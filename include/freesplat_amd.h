@@ -149,6 +149,28 @@ int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
                            const float* w2, const float* b2, const float* w3, const float* b3,
                            void* workspace, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * Pixel-wise Triplet Fusion: matching step                                              *
+ * ------------------------------------------------------------------------------------ */
+
+size_t fs_ptf_scratch_bytes(int32_t M, int32_t h, int32_t w);
+
+/*
+ * One fold step of EncoderFreeSplat.fuse_gaussians (encoder_freesplat.py:443-482, 508): project the
+ * M global Gaussians xyz[M,3] into view i (w2c[16] = inverse(extrinsics_i) row-major, kpix[4] =
+ * {fx, fy, cx, cy} in pixels, both on the device), z-buffer per pixel, depth-consistency test against
+ * depth_i[h*w] with threshold max(0.05*d, depth_thres), and write ascending index lists:
+ *   keep_idx[n_keep]  global entries that stay as they are          (global[~mask])
+ *   fuse_idx[n_fuse]  global entries fused with view i, fuse_pix[n_fuse] their pixel in view i
+ *   append_pix[n_app] pixels of view i that start new Gaussians     (~fusion_mask)
+ * counts[3] = {n_keep, n_fuse, n_app} (device).  Index buffers must hold M (resp. h*w) int64.
+ * Bit-exact index semantics (round-half-even pixel, exact z equality, ties fuse together).
+ */
+int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const float* w2c,
+                 const float* kpix, const float* depth_i, float depth_thres, void* scratch,
+                 int64_t* keep_idx, int64_t* fuse_idx, int64_t* fuse_pix, int64_t* append_pix,
+                 int32_t* counts, void* stream);
+
 /* Debug/test accessors into the opaque buffers (device pointers, no copies). */
 const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t H, int32_t W);  /* [T+1] offsets */
 const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] (id << 4) | 8x8-quadrant mask */

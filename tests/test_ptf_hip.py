@@ -1,0 +1,116 @@
+"""GPU parity of the PTF path: fs_ptf_match (index work -> bit-exact vs the oracle) and the whole
+fold against the reference's golden outputs and the oracle (fp32 tolerance 1e-4, identical ORDER)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+pytestmark = pytest.mark.gpu
+
+
+def _load(name):
+    z = np.load(os.path.join(HERE, "golden", name))
+    g = {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+    gru = {k[len("gru__"):].replace("__", "."): v for k, v in g.items() if k.startswith("gru__")}
+    return g, gru
+
+
+def _scene(V, h, w, seed, noise=0.02):
+    import inputs
+    from oracle import ptf_oracle as po
+    E, Kn, depths, lat, dens, wts = inputs.ptf_inputs(V, h, w, seed=seed)
+    depths = 2.0 + noise * torch.randn(V, 1, h, w, generator=torch.Generator().manual_seed(seed))
+    # unproject like gaussian_adapter.py:36-79 (integer pixel coords, no +0.5)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    coords = []
+    for i in range(V):
+        K = Kn[i].clone(); K[0] *= w; K[1] *= h
+        z = depths[i, 0]
+        pc = torch.stack([(xs - K[0, 2]) / K[0, 0] * z, (ys - K[1, 2]) / K[1, 1] * z, z, torch.ones_like(z)], -1).reshape(-1, 4)
+        coords.append((pc @ E[i].T)[:, :3])
+    coords = torch.stack(coords)[None, :, :, None, None, :]
+    return E, Kn, depths, lat, dens, wts, coords
+
+
+@pytest.mark.parametrize("h,w,M,seed", [(24, 32, 768, 1), (48, 64, 10000, 2), (384, 512, 196608 * 2, 3), (7, 9, 5, 4)])
+def test_match_bit_exact_vs_oracle(hip_device, h, w, M, seed):
+    from oracle import ptf_oracle as po
+    from freesplat_amd.ptf import match_view
+    rng = np.random.default_rng(seed)
+    P = h * w
+    fx, fy, cx, cy = 0.9 * w, 1.2 * h, 0.49 * w, 0.51 * h
+    # points spread over (and beyond) the frustum at depth ~2, many pairs sharing pixels, some behind
+    u = rng.uniform(-0.1 * w, 1.1 * w, M); v = rng.uniform(-0.1 * h, 1.1 * h, M)
+    z = 2.0 + 0.05 * rng.normal(size=M)
+    z[rng.random(M) < 0.02] *= -1
+    xyz = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], -1).astype(np.float32)
+    xyz[: M // 10] = xyz[M // 10: 2 * (M // 10)][: M // 10]          # exact duplicates -> z ties
+    ang = 0.03
+    w2c = np.array([[np.cos(ang), 0, np.sin(ang), 0.01], [0, 1, 0, -0.02], [-np.sin(ang), 0, np.cos(ang), 0.03],
+                    [0, 0, 0, 1]], np.float32)
+    kpix = np.array([fx, fy, cx, cy], np.float32)
+    depth_i = (2.0 + 0.05 * rng.normal(size=P)).astype(np.float32)
+    ref = po.match_step(xyz, w2c, kpix, depth_i, h, w)
+    t = lambda a: torch.from_numpy(a).to(hip_device)
+    got = match_view(t(xyz), t(w2c), t(kpix), t(depth_i), h, w)
+    for a, b, name in zip(got, ref, ("keep", "fuse", "fuse_pix", "append")):
+        np.testing.assert_array_equal(a.cpu().numpy(), b, err_msg=name)
+    assert len(ref[1]) > 0 or M < 10
+
+
+def test_match_empty_state(hip_device):
+    from freesplat_amd.ptf import match_view
+    h, w = 8, 8
+    d = torch.full((h * w,), 2.0, device=hip_device)
+    keep, fuse, fpix, app = match_view(torch.zeros(0, 3, device=hip_device), torch.eye(4, device=hip_device),
+                                       torch.tensor([4.0, 4.0, 4.0, 4.0], device=hip_device), d, h, w)
+    assert keep.numel() == 0 and fuse.numel() == 0 and torch.equal(app.cpu(), torch.arange(h * w))
+
+
+def _run_fold(g, gru_params, dev):
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    m = PixelwiseTripletFusion()
+    m.gru.load_state_dict(gru_params, strict=True)
+    m = m.to(dev)
+    d = lambda t: t.to(dev)
+    return m, m.fuse_gaussians([d(g["latents"])], [d(g["coords"])], d(g["densities"]), d(g["weights"]), d(g["depths"]),
+                               d(g["extrinsics"])[None], d(g["intrinsics"])[None], (int(g["h"]), int(g["w"])))
+
+
+@pytest.mark.parametrize("name", ["ptf_small.npz", "ptf_tie.npz"])
+def test_fold_matches_reference_golden(hip_device, name):
+    g, gru = _load(name)
+    _, out = _run_fold(g, gru, hip_device)
+    for got, key in zip(out, ("out_latent", "out_xyz", "out_extrinsics", "out_depths")):
+        assert got.shape == g[key].shape, key
+        assert (got.cpu() - g[key]).abs().max().item() <= 1e-4, key
+
+
+@pytest.mark.parametrize("V,h,w", [(2, 96, 128), (4, 48, 64)])
+def test_fold_vs_oracle_and_gradients(hip_device, V, h, w):
+    from oracle import ptf_oracle as po
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=40 + V)
+    torch.manual_seed(9)
+    m = PixelwiseTripletFusion()
+    params = {k: v.detach().clone() for k, v in m.gru.state_dict().items()}
+    # oracle with autograd (CPU)
+    lat_c, dens_c = lat.clone().requires_grad_(True), dens.clone().requires_grad_(True)
+    ref = po.fuse_gaussians(params, lat_c, coords, dens_c, wts, depths, E[None], Kn[None], (h, w))
+    m = m.to(hip_device)
+    d = lambda t: t.to(hip_device)
+    lat_g, dens_g = d(lat).requires_grad_(True), d(dens).requires_grad_(True)
+    out = m.fuse_gaussians([lat_g], [d(coords)], dens_g, d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))
+    assert out[0].shape == ref[0].shape and out[0].shape[1] < V * h * w   # something fused
+    for a, b, name in zip(out, ref, ("latent", "xyz", "extrinsics", "depths")):
+        assert (a.detach().cpu() - b.detach()).abs().max().item() <= 1e-4, name
+    wgt = torch.randn(ref[0].shape, generator=torch.Generator().manual_seed(1))
+    (ref[0] * wgt).sum().backward()
+    (out[0] * wgt.to(hip_device)).sum().backward()
+    for a, b, name in ((lat_g.grad, lat_c.grad, "d latents"), (dens_g.grad, dens_c.grad, "d densities")):
+        s = b.abs().max().item() + 1e-20
+        assert (a.cpu() - b).abs().max().item() / s < 1e-3, name
