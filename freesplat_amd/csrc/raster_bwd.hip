@@ -19,11 +19,49 @@ namespace fs {
 constexpr int kGradStride = 12;  // floats per Gaussian in the accumulation scratch
 // layout: 0,1 mean2D | 2,3,4 conic (x, y(half), z) | 5 opacity | 6,7,8 rgb | 9 view z | 10,11 pad
 
-__device__ __forceinline__ float wave_sum(float v)
+// ---- cross-lane exchange with lane ^ M without touching LDS memory where the ISA allows ----
+template <int M>
+__device__ __forceinline__ float xchg(float v)
 {
+    const int i = __float_as_int(v);
+    if constexpr (M == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    else if constexpr (M == 32) return __shfl_xor(v, 32, 64);
+    else return __int_as_float(__builtin_amdgcn_ds_swizzle(i, (M << 10) | 0x1F));                          // bit-mode xor M
+}
+
+// Sum 10 per-lane values over the 64 lanes of a wavefront with a HALVING butterfly: at every level a
+// lane keeps one half of its values and hands the other half to its partner, so 10 values cost
+// 5+3+2+1+1+1 = 13 exchanges instead of 10 x 6.  Afterwards the 16 lanes with (lane & 3) == 0 each
+// hold the complete sum of ONE value (or of a zero pad); wave_value_index() says which.
+__device__ __forceinline__ int wave_value_index(int lane)
+{
+    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+    // level 1 keeps [0..4] | [5..9]; level 2 keeps slots [0,1,2] | [3,4,-]; level 3 [0,1] | [2,-]; level 4 [0] | [1]
+    const int s3 = b2;                      // slot within the level-3 survivors (2 slots)
+    if (b3 && s3 == 1) return -1;           // pad
+    const int s2 = b3 ? 2 : s3;             // slot within the level-2 survivors (3 slots)
+    if (b4 && s2 == 2) return -1;           // pad
+    const int s1 = b4 ? 3 + s2 : s2;        // slot within the level-1 survivors (5 slots)
+    return b5 ? 5 + s1 : s1;
+}
+__device__ __forceinline__ float wave_sum10(const float (&v)[10], int lane)
+{
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    float a[5];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    for (int k = 0; k < 5; ++k) a[k] = (b5 ? v[5 + k] : v[k]) + xchg<32>(b5 ? v[k] : v[5 + k]);
+    float c[3];
+    c[0] = (b4 ? a[3] : a[0]) + xchg<16>(b4 ? a[0] : a[3]);
+    c[1] = (b4 ? a[4] : a[1]) + xchg<16>(b4 ? a[1] : a[4]);
+    c[2] = (b4 ? 0.0f : a[2]) + xchg<16>(b4 ? a[2] : 0.0f);
+    float e[2];
+    e[0] = (b3 ? c[2] : c[0]) + xchg<8>(b3 ? c[0] : c[2]);
+    e[1] = (b3 ? 0.0f : c[1]) + xchg<8>(b3 ? c[1] : 0.0f);
+    float f = (b2 ? e[1] : e[0]) + xchg<4>(b2 ? e[0] : e[1]);
+    f += xchg<2>(f);
+    f += xchg<1>(f);
+    return f;
 }
 
 __global__ __launch_bounds__(256) void render_bwd_kernel(
@@ -47,6 +85,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);   // same 8x8 quadrant per wavefront
     const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);  // as the forward
     const uint32_t qbit = 1u << wave;
+    const int my_slot = (lane & 3) == 0 ? wave_value_index(lane) : -1;  // which reduced value this lane owns
     const bool inside = px < W && py < H;
     const float pfx = (float)px, pfy = (float)py;
     const uint32_t a = offsets[tile], b = offsets[tile + 1];
@@ -135,22 +174,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
                 v_cc = -0.5f * gdy * dy * dL_dG;
                 v_op = G * dL_dalpha;
             }
-            v_mx = wave_sum(v_mx); v_my = wave_sum(v_my);
-            v_ca = wave_sum(v_ca); v_cb = wave_sum(v_cb); v_cc = wave_sum(v_cc);
-            v_op = wave_sum(v_op);
-            v_r = wave_sum(v_r); v_g = wave_sum(v_g); v_b = wave_sum(v_b); v_z = wave_sum(v_z);
-            if (lane == 0) {
-                atomicAdd(&s_acc[0 * 256 + j], v_mx);
-                atomicAdd(&s_acc[1 * 256 + j], v_my);
-                atomicAdd(&s_acc[2 * 256 + j], v_ca);
-                atomicAdd(&s_acc[3 * 256 + j], v_cb);
-                atomicAdd(&s_acc[4 * 256 + j], v_cc);
-                atomicAdd(&s_acc[5 * 256 + j], v_op);
-                atomicAdd(&s_acc[6 * 256 + j], v_r);
-                atomicAdd(&s_acc[7 * 256 + j], v_g);
-                atomicAdd(&s_acc[8 * 256 + j], v_b);
-                atomicAdd(&s_acc[9 * 256 + j], v_z);
-            }
+            const float vals[10] = {v_mx, v_my, v_ca, v_cb, v_cc, v_op, v_r, v_g, v_b, v_z};
+            const float tot = wave_sum10(vals, lane);
+            if (my_slot >= 0) atomicAdd(&s_acc[my_slot * 256 + j], tot);
           }
         }
         __syncthreads();

@@ -114,6 +114,17 @@ __device__ __forceinline__ uint32_t quad_mask(const QuadForm& f, const float4 r0
     return m;
 }
 
+// Quadrant masks of every tile of a (small) rect packed 4 bits per tile, row-major: computed once in
+// preprocess, reused by both phases of emit.
+__device__ __forceinline__ unsigned long long pack_quad_masks(const QuadForm& f, const float4 r0, ushort4 rc)
+{
+    unsigned long long m = 0;
+    int k = 0;
+    for (int y = rc.y; y < rc.w; ++y)
+        for (int x = rc.x; x < rc.z; ++x, ++k) m |= (unsigned long long)quad_mask(f, r0, x, y) << (4 * k);
+    return m;
+}
+
 // Workgroup-private tile counters: the 256 Gaussians of a workgroup are neighbours on screen
 // (the encoder emits them in pixel order), so their tile rectangles span a small bounding box.
 // Counting happens with LDS atomics inside that box and only one global atomic per touched
@@ -257,25 +268,36 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const bool cull = (d.flags & FS_RASTER_TILE_CULL) != 0;
     const int gx = (d.W + kTile - 1) / kTile;
     const QuadForm qf = quad_form(r0, r1);
+    const int area = (rect.z - rect.x) * (rect.w - rect.y);
+    const bool small = area <= 16;
+    unsigned long long qm = 0;
+    if (valid && small) qm = pack_quad_masks(qf, r0, rect);
+    if (live) g.qmask[i] = qm;
     const BinBox bb = block_bin_box(s_box, valid, rect);
     if (bb.w * bb.h == 0) return;
     if (bb.lds) {
         for (int k = t; k < bb.w * bb.h; k += 256) s_cnt[k] = 0;
         __syncthreads();
-        if (valid)
+        if (valid) {
+            int k = 0;
             for (int y = rect.y; y < rect.w; ++y)
-                for (int x = rect.x; x < rect.z; ++x)
-                    if (!cull || quad_mask(qf, r0, x, y))
-                        atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
+                for (int x = rect.x; x < rect.z; ++x, ++k) {
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                    if (!cull || m) atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
+                }
+        }
         __syncthreads();
         for (int k = t; k < bb.w * bb.h; k += 256) {
             const uint32_t c = s_cnt[k];
             if (c) atomicAdd(&tile_counts[(bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w], c);
         }
     } else if (valid) {
+        int k = 0;
         for (int y = rect.y; y < rect.w; ++y)
-            for (int x = rect.x; x < rect.z; ++x)
-                if (!cull || quad_mask(qf, r0, x, y)) atomicAdd(&tile_counts[y * gx + x], 1u);
+            for (int x = rect.x; x < rect.z; ++x, ++k) {
+                const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                if (!cull || m) atomicAdd(&tile_counts[y * gx + x], 1u);
+            }
     }
 }
 
@@ -334,21 +356,31 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
     const bool valid = rc.z > rc.x && rc.w > rc.y;
     const bool cull = (flags & FS_RASTER_TILE_CULL) != 0;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
-    if (valid) { r0 = g.rec[3 * (size_t)i]; r1 = g.rec[3 * (size_t)i + 1]; }
+    if (valid) {
+        r1 = g.rec[3 * (size_t)i + 1];
+        if ((rc.z - rc.x) * (rc.w - rc.y) > 16) r0 = g.rec[3 * (size_t)i];
+    }
     // key = depth bits : (gaussian id << 4 | quadrant mask); the mask is a function of (id, tile), so
     // ordering by the key is ordering by (depth, id)
     const unsigned long long key_hi = ((unsigned long long)__float_as_uint(r1.w) << 32) | ((uint32_t)i << 4);
-    const QuadForm qf = quad_form(r0, r1);
+    const int area = (rc.z - rc.x) * (rc.w - rc.y);
+    const bool small = area <= 16;
+    const unsigned long long qm = (valid && small) ? g.qmask[i] : 0ull;
+    QuadForm qf = {};
+    if (valid && !small) qf = quad_form(r0, r1);
     const BinBox bb = block_bin_box(s_box, valid, rc);
     if (bb.w * bb.h == 0) return;
     if (bb.lds) {
         for (int k = t; k < bb.w * bb.h; k += 256) s_cnt[k] = 0;
         __syncthreads();
-        if (valid)
+        if (valid) {
+            int k = 0;
             for (int y = rc.y; y < rc.w; ++y)
-                for (int x = rc.x; x < rc.z; ++x)
-                    if (!cull || quad_mask(qf, r0, x, y))
-                        atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
+                for (int x = rc.x; x < rc.z; ++x, ++k) {
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                    if (!cull || m) atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
+                }
+        }
         __syncthreads();
         for (int k = t; k < bb.w * bb.h; k += 256) {
             const uint32_t c = s_cnt[k];
@@ -357,26 +389,27 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
             s_cnt[k] = 0;
         }
         __syncthreads();
-        if (valid)
+        if (valid) {
+            int k = 0;
             for (int y = rc.y; y < rc.w; ++y)
-                for (int x = rc.x; x < rc.z; ++x)
-                {
-                    const uint32_t qm = quad_mask(qf, r0, x, y);
-                    if (!cull || qm) {
-                        const int k = (y - bb.y0) * bb.w + (x - bb.x0);
-                        const unsigned long long slot = (unsigned long long)s_base[k] + atomicAdd(&s_cnt[k], 1u);
-                        if (slot < cap) keys[slot] = key_hi | qm;
+                for (int x = rc.x; x < rc.z; ++x, ++k) {
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                    if (!cull || m) {
+                        const int kk = (y - bb.y0) * bb.w + (x - bb.x0);
+                        const unsigned long long slot = (unsigned long long)s_base[kk] + atomicAdd(&s_cnt[kk], 1u);
+                        if (slot < cap) keys[slot] = key_hi | m;
                     }
                 }
+        }
     } else if (valid) {
+        int k = 0;
         for (int y = rc.y; y < rc.w; ++y)
-            for (int x = rc.x; x < rc.z; ++x)
-            {
-                const uint32_t qm = quad_mask(qf, r0, x, y);
-                if (!cull || qm) {
+            for (int x = rc.x; x < rc.z; ++x, ++k) {
+                const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                if (!cull || m) {
                     const int tl = y * gx + x;
                     const unsigned long long slot = (unsigned long long)offsets[tl] + atomicAdd(&cursors[tl], 1u);
-                    if (slot < cap) keys[slot] = key_hi | qm;
+                    if (slot < cap) keys[slot] = key_hi | m;
                 }
             }
     }
