@@ -75,42 +75,68 @@ constexpr int kBinLds = 4096;  // tiles of a workgroup's bounding box whose coun
 // the record's skip threshold r1.z, which already carries a safety margin.  A (gaussian, tile)
 // instance whose mask is 0 could only ever be skipped by the blend loop, so dropping it leaves the
 // image unchanged bit for bit; retained instances keep the reference's (tile, depth, index) order.
-struct QuadForm {  // q(u,v) = a u^2 + c v^2 + b u v = -power, per Gaussian
-    float a, b, c, thr_slack, kv, ku;  // kv = -b/(2c): argmin_v q(u,.) = kv*u ; ku = -b/(2a)
+struct QuadForm {  // q(u,v) = a u^2 + c v^2 + b u v = -power, per Gaussian, and its level set q <= Q
+    float a, b, c;
+    float Q;      // -(skip threshold with slack): a pixel can contribute only where q <= Q
+    float D;      // 4ac - b^2 (> 0)
+    float vplus;  // v of the ellipse's rightmost point (leftmost: -vplus)
+    float Vmax;   // v-extent of the ellipse
+    float inv2a;
 };
 __device__ __forceinline__ QuadForm quad_form(const float4 r0, const float4 r1)
 {
+    // approximate rcp/sqrt are fine here: every interval below is widened by kEps pixels and the
+    // threshold itself carries slack, so rounding can only keep (never drop) a borderline quadrant
     QuadForm f;
     f.a = -r0.z; f.c = -r0.w; f.b = -r1.x;
-    f.thr_slack = r1.z - 1e-3f * (1.0f + fabsf(r1.z));
-    // approximate reciprocals are fine: an error d in the argmin raises q by O(d^2) << slack
-    f.kv = -f.b * __builtin_amdgcn_rcpf(2.0f * f.c);
-    f.ku = -f.b * __builtin_amdgcn_rcpf(2.0f * f.a);
+    f.Q = -(r1.z - 1e-3f * (1.0f + fabsf(r1.z)));
+    f.D = 4.0f * f.a * f.c - f.b * f.b;
+    const float invD = __builtin_amdgcn_rcpf(f.D);
+    const float U = __builtin_amdgcn_sqrtf(fmaxf(4.0f * f.c * f.Q * invD, 0.0f));
+    f.vplus = -f.b * __builtin_amdgcn_rcpf(2.0f * f.c) * U;
+    f.Vmax = __builtin_amdgcn_sqrtf(fmaxf(4.0f * f.a * f.Q * invD, 0.0f));
+    f.inv2a = __builtin_amdgcn_rcpf(2.0f * f.a);
     return f;
 }
-__device__ __forceinline__ bool rect_reachable(const QuadForm& f, float ulo, float uhi, float vlo,
-                                               float vhi)
+// u-interval [uL, uR] of the level set inside the horizontal band v in [vlo, vhi]: the right boundary
+// u_R(v) = (-b v + sqrt(4aQ - D v^2)) / 2a is concave with its maximum at v = vplus, so over the band it
+// peaks at clamp(vplus, vlo, vhi); mirrored for the left boundary.  Empty -> uL > uR.
+struct Band { float uL, uR; };
+constexpr float kEps = 2e-5f;
+__device__ __forceinline__ Band band_interval(const QuadForm& f, float vlo, float vhi)
 {
-    if (ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f) return true;  // centre inside
-    const float vs_lo = fminf(vhi, fmaxf(vlo, f.kv * ulo));
-    const float vs_hi = fminf(vhi, fmaxf(vlo, f.kv * uhi));
-    const float us_lo = fminf(uhi, fmaxf(ulo, f.ku * vlo));
-    const float us_hi = fminf(uhi, fmaxf(ulo, f.ku * vhi));
-    float qmin = f.a * ulo * ulo + f.c * vs_lo * vs_lo + f.b * ulo * vs_lo;
-    qmin = fminf(qmin, f.a * uhi * uhi + f.c * vs_hi * vs_hi + f.b * uhi * vs_hi);
-    qmin = fminf(qmin, f.a * us_lo * us_lo + f.c * vlo * vlo + f.b * us_lo * vlo);
-    qmin = fminf(qmin, f.a * us_hi * us_hi + f.c * vhi * vhi + f.b * us_hi * vhi);
-    return !(-qmin < f.thr_slack);  // cull only when certainly below the threshold (NaN -> keep)
+    Band o;
+    if (f.Q < 0.0f || vlo > f.Vmax + kEps || vhi < -f.Vmax - kEps) { o.uL = 3.0e38f; o.uR = -3.0e38f; return o; }
+    const float vr = fminf(vhi, fmaxf(vlo, f.vplus)), vl = fminf(vhi, fmaxf(vlo, -f.vplus));
+    const float sr = __builtin_amdgcn_sqrtf(fmaxf(4.0f * f.a * f.Q - f.D * vr * vr, 0.0f));
+    const float sl = __builtin_amdgcn_sqrtf(fmaxf(4.0f * f.a * f.Q - f.D * vl * vl, 0.0f));
+    o.uR = (-f.b * vr + sr) * f.inv2a;
+    o.uL = (-f.b * vl - sl) * f.inv2a;
+    const float w = kEps * (1.0f + fabsf(o.uR) + fabsf(o.uL));
+    o.uR += w; o.uL -= w;
+    return o;
 }
-__device__ __forceinline__ uint32_t quad_mask(const QuadForm& f, const float4 r0, int tx, int ty)
+// Which 8x8-pixel quadrants of a tile can receive alpha >= 1/255 from this Gaussian?  bit q = (qy<<1)|qx.
+// Conservative (never drops a contributing quadrant).  A (gaussian, tile) instance whose mask is 0
+// could only ever be skipped by the blend loop, so dropping it leaves the image unchanged bit for bit;
+// retained instances keep the reference's (tile, depth, index) order.  NaNs keep everything.
+struct RowBands { Band top, bot; };
+__device__ __forceinline__ RowBands row_bands(const QuadForm& f, const float4 r0, int ty)
 {
-    const float u0 = (float)(tx * kTile) - r0.x, v0 = (float)(ty * kTile) - r0.y;
+    const float v0 = (float)(ty * kTile) - r0.y;
+    RowBands r;
+    r.top = band_interval(f, v0, v0 + 7.0f);
+    r.bot = band_interval(f, v0 + 8.0f, v0 + 15.0f);
+    return r;
+}
+__device__ __forceinline__ uint32_t quad_mask_row(const RowBands& rb, const float4 r0, int tx)
+{
+    const float u0 = (float)(tx * kTile) - r0.x, u1 = u0 + 8.0f;
     uint32_t m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float ulo = u0 + (float)((q & 1) * 8), vlo = v0 + (float)((q >> 1) * 8);
-        if (rect_reachable(f, ulo, ulo + 7.0f, vlo, vlo + 7.0f)) m |= 1u << q;
-    }
+    if (!(u0 > rb.top.uR) && !(u0 + 7.0f < rb.top.uL)) m |= 1u;
+    if (!(u1 > rb.top.uR) && !(u1 + 7.0f < rb.top.uL)) m |= 2u;
+    if (!(u0 > rb.bot.uR) && !(u0 + 7.0f < rb.bot.uL)) m |= 4u;
+    if (!(u1 > rb.bot.uR) && !(u1 + 7.0f < rb.bot.uL)) m |= 8u;
     return m;
 }
 
@@ -120,8 +146,10 @@ __device__ __forceinline__ unsigned long long pack_quad_masks(const QuadForm& f,
 {
     unsigned long long m = 0;
     int k = 0;
-    for (int y = rc.y; y < rc.w; ++y)
-        for (int x = rc.x; x < rc.z; ++x, ++k) m |= (unsigned long long)quad_mask(f, r0, x, y) << (4 * k);
+    for (int y = rc.y; y < rc.w; ++y) {
+        const RowBands rb = row_bands(f, r0, y);
+        for (int x = rc.x; x < rc.z; ++x, ++k) m |= (unsigned long long)quad_mask_row(rb, r0, x) << (4 * k);
+    }
     return m;
 }
 
@@ -280,11 +308,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         __syncthreads();
         if (valid) {
             int k = 0;
-            for (int y = rect.y; y < rect.w; ++y)
+            for (int y = rect.y; y < rect.w; ++y) {
+                RowBands rb = {};
+                if (!small) rb = row_bands(qf, r0, y);
                 for (int x = rect.x; x < rect.z; ++x, ++k) {
-                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
                     if (!cull || m) atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
                 }
+            }
         }
         __syncthreads();
         for (int k = t; k < bb.w * bb.h; k += 256) {
@@ -293,11 +324,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         }
     } else if (valid) {
         int k = 0;
-        for (int y = rect.y; y < rect.w; ++y)
+        for (int y = rect.y; y < rect.w; ++y) {
+            RowBands rb = {};
+            if (!small) rb = row_bands(qf, r0, y);
             for (int x = rect.x; x < rect.z; ++x, ++k) {
-                const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
                 if (!cull || m) atomicAdd(&tile_counts[y * gx + x], 1u);
             }
+        }
     }
 }
 
@@ -375,11 +409,14 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
         __syncthreads();
         if (valid) {
             int k = 0;
-            for (int y = rc.y; y < rc.w; ++y)
+            for (int y = rc.y; y < rc.w; ++y) {
+                RowBands rb = {};
+                if (!small) rb = row_bands(qf, r0, y);
                 for (int x = rc.x; x < rc.z; ++x, ++k) {
-                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
                     if (!cull || m) atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
                 }
+            }
         }
         __syncthreads();
         for (int k = t; k < bb.w * bb.h; k += 256) {
@@ -391,27 +428,33 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
         __syncthreads();
         if (valid) {
             int k = 0;
-            for (int y = rc.y; y < rc.w; ++y)
+            for (int y = rc.y; y < rc.w; ++y) {
+                RowBands rb = {};
+                if (!small) rb = row_bands(qf, r0, y);
                 for (int x = rc.x; x < rc.z; ++x, ++k) {
-                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
                     if (!cull || m) {
                         const int kk = (y - bb.y0) * bb.w + (x - bb.x0);
                         const unsigned long long slot = (unsigned long long)s_base[kk] + atomicAdd(&s_cnt[kk], 1u);
                         if (slot < cap) keys[slot] = key_hi | m;
                     }
                 }
+            }
         }
     } else if (valid) {
         int k = 0;
-        for (int y = rc.y; y < rc.w; ++y)
+        for (int y = rc.y; y < rc.w; ++y) {
+            RowBands rb = {};
+            if (!small) rb = row_bands(qf, r0, y);
             for (int x = rc.x; x < rc.z; ++x, ++k) {
-                const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask(qf, r0, x, y);
+                const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
                 if (!cull || m) {
                     const int tl = y * gx + x;
                     const unsigned long long slot = (unsigned long long)offsets[tl] + atomicAdd(&cursors[tl], 1u);
                     if (slot < cap) keys[slot] = key_hi | m;
                 }
             }
+        }
     }
 }
 
@@ -452,6 +495,115 @@ __device__ __forceinline__ void bitonic_sort_any(Ptr a, uint32_t n)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident bitonic sort for tile lists of <= 4096 keys: thread t of the 256 holds the EPT
+// consecutive keys [t*EPT, (t+1)*EPT).  Strides below EPT are compare-exchanges between a thread's
+// own registers; strides that stay inside a wavefront (partner thread = t ^ m, m < 64) move through
+// DPP / ds_swizzle / ds_bpermute, i.e. without LDS round trips or barriers; only the last stages'
+// cross-wavefront strides (m >= 64) go through LDS.  For 2048 keys that is 3 LDS exchanges instead
+// of the 66 barrier-separated LDS passes of the plain network.  Same "flip" network as
+// bitonic_sort_any (all compare-exchanges ascending), so padding keys of ~0 stay at the top.
+// ------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
+{
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+    else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);
+    else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);
+    else return (uint32_t)__shfl_xor((int)v, M, 64);
+}
+template <int M>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long v)
+{
+    const uint32_t lo = lane_xor<M>((uint32_t)v), hi = lane_xor<M>((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Exchange with thread t ^ TM; REV: partner's keys are taken in reversed order (flip step).
+template <int EPT, int TM, bool REV>
+__device__ __forceinline__ void thread_exchange(unsigned long long (&k)[EPT], int t, unsigned long long* lds)
+{
+    constexpr int HB = TM >= 128 ? 128 : TM >= 64 ? 64 : TM >= 32 ? 32 : TM >= 16 ? 16 : TM >= 8 ? 8 : TM >= 4 ? 4 : TM >= 2 ? 2 : 1;
+    const bool low = (t & HB) == 0;  // this thread holds the lower global indices of every pair
+    unsigned long long y[EPT];
+    if constexpr (TM < 64) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) y[e] = lane_xor64<TM>(k[REV ? EPT - 1 - e : e]);
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) lds[e * 256 + t] = k[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) y[e] = lds[(REV ? EPT - 1 - e : e) * 256 + (t ^ TM)];
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const unsigned long long x = k[e];
+        k[e] = low ? (y[e] < x ? y[e] : x) : (y[e] > x ? y[e] : x);
+    }
+}
+
+template <int EPT, int J>  // half-cleaner strides J, J/2, ..., 1
+struct Clean {
+    static __device__ __forceinline__ void run(unsigned long long (&k)[EPT], int t, unsigned long long* lds)
+    {
+        if constexpr (J >= EPT) {
+            thread_exchange<EPT, J / EPT, false>(k, t, lds);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if ((e & J) == 0) {
+                    const unsigned long long a = k[e], b = k[e | J];
+                    if (a > b) { k[e] = b; k[e | J] = a; }
+                }
+        }
+        if constexpr (J > 1) Clean<EPT, J / 2>::run(k, t, lds);
+    }
+};
+template <int EPT, int K>  // stages 2, 4, ..., K
+struct Stages {
+    static __device__ __forceinline__ void run(unsigned long long (&k)[EPT], int t, unsigned long long* lds)
+    {
+        if constexpr (K > 2) Stages<EPT, K / 2>::run(k, t, lds);
+        // flip step: i <-> i ^ (K-1)
+        if constexpr (K <= EPT) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int p = e ^ (K - 1);
+                if (e < p) {
+                    const unsigned long long a = k[e], b = k[p];
+                    if (a > b) { k[e] = b; k[p] = a; }
+                }
+            }
+        } else {
+            thread_exchange<EPT, K / EPT - 1, true>(k, t, lds);
+        }
+        if constexpr (K >= 4) Clean<EPT, K / 4>::run(k, t, lds);
+    }
+};
+
+template <int EPT>
+__device__ __forceinline__ void sort_tile_in_registers(const unsigned long long* __restrict__ keys,
+                                                       uint32_t* __restrict__ out, uint32_t n,
+                                                       unsigned long long* lds)
+{
+    const int t = threadIdx.x;
+    unsigned long long k[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = (uint32_t)t * EPT + e;
+        k[e] = i < n ? keys[i] : ~0ull;
+    }
+    Stages<EPT, 256 * EPT>::run(k, t, lds);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = (uint32_t)t * EPT + e;
+        if (i < n) out[i] = (uint32_t)k[e];
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint32_t* __restrict__ offsets,
                                                         unsigned long long* __restrict__ keys,
                                                         uint32_t* __restrict__ point_list,
@@ -466,11 +618,14 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint32_t* _
     const uint32_t a = offsets[tile], b = offsets[tile + 1];
     const uint32_t n = b - a;
     if (n == 0) return;
-    if (n <= (uint32_t)kSortLds) {
-        for (uint32_t k = threadIdx.x; k < n; k += 256) sk[k] = keys[a + k];
-        __syncthreads();
-        bitonic_sort_any(sk, n);
-        for (uint32_t k = threadIdx.x; k < n; k += 256) point_list[a + k] = (uint32_t)sk[k];
+    if (n <= 512u) {
+        sort_tile_in_registers<2>(keys + a, point_list + a, n, sk);
+    } else if (n <= 1024u) {
+        sort_tile_in_registers<4>(keys + a, point_list + a, n, sk);
+    } else if (n <= 2048u) {
+        sort_tile_in_registers<8>(keys + a, point_list + a, n, sk);
+    } else if (n <= 4096u) {
+        sort_tile_in_registers<16>(keys + a, point_list + a, n, sk);
     } else {
         // rare: very long tile lists sort in place in global memory (same network)
         __syncthreads();
@@ -535,35 +690,51 @@ __global__ __launch_bounds__(256) void render_kernel(
         for (int c = 0; c < m; c += 64) {
             if (__all(done)) break;  // wave-uniform
             unsigned long long hits = __ballot((c + lane < m) && (s_q[c + lane] & qbit));
-            if (!hits) continue;
-            // software pipeline: the next survivor's record is fetched from LDS while this one blends
-            int jn = c + __builtin_ctzll(hits);
-            float4 n0 = s0[jn], n1 = s1[jn], n2 = s2[jn];
+            // survivors are taken two at a time: the two exponent/exp chains are independent (ILP),
+            // the blend itself stays strictly sequential in list order
             while (hits) {
-                const int j = jn;
-                const float4 g0 = n0, g1 = n1, g2 = n2;
+                const int ja = c + __builtin_ctzll(hits);
                 hits &= hits - 1;
-                if (hits) {
-                    jn = c + __builtin_ctzll(hits);
-                    n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
+                const bool two = hits != 0;
+                const int jb = two ? c + __builtin_ctzll(hits) : ja;
+                hits &= hits - 1;  // (0 & -1 == 0 when there was no second survivor)
+                const float4 a0 = s0[ja], a1 = s1[ja], a2 = s2[ja];
+                const float4 b0 = s0[jb], b1 = s1[jb], b2 = s2[jb];
+                const float dxa = a0.x - pfx, dya = a0.y - pfy;
+                const float dxb = b0.x - pfx, dyb = b0.y - pfy;
+                const float pa = fmaf(a0.z * dxa, dxa, fmaf(a0.w * dya, dya, (a1.x * dxa) * dya));
+                const float pb = fmaf(b0.z * dxb, dxb, fmaf(b0.w * dyb, dyb, (b1.x * dxb) * dyb));
+                const bool ca = !done && pa <= 0.0f && pa >= a1.z;
+                const bool cb = two && !done && pb <= 0.0f && pb >= b1.z;
+                if (!__any(ca || cb)) continue;  // wave-uniform
+                const float ala = fminf(0.99f, a1.y * fs_exp(pa));
+                const float alb = fminf(0.99f, b1.y * fs_exp(pb));
+                {   // first survivor
+                    const float test_T = T_ * (1.0f - ala);
+                    const bool vis = ca && ala >= 1.0f / 255.0f;
+                    const bool ok = vis && test_T >= 0.0001f;
+                    done = done || (vis && !ok);
+                    const float wgt = ok ? ala * T_ : 0.0f;
+                    C0 = ok ? fmaf(a2.x, wgt, C0) : C0;
+                    C1 = ok ? fmaf(a2.y, wgt, C1) : C1;
+                    C2 = ok ? fmaf(a2.z, wgt, C2) : C2;
+                    D = ok ? fmaf(a1.w, wgt, D) : D;
+                    T_ = ok ? test_T : T_;
+                    last = ok ? (r << 8) + ja + 1 : last;
                 }
-                const float dx = g0.x - pfx, dy = g0.y - pfy;
-                const float power = fmaf(g0.z * dx, dx, fmaf(g0.w * dy, dy, (g1.x * dx) * dy));
-                const bool cand = !done && power <= 0.0f && power >= g1.z;
-                if (!__any(cand)) continue;  // wave-uniform
-                // straight-line from here: per-lane decisions become selects, not exec-mask branches
-                const float alpha = fminf(0.99f, g1.y * fs_exp(power));
-                const float test_T = T_ * (1.0f - alpha);
-                const bool vis = cand && alpha >= 1.0f / 255.0f;
-                const bool ok = vis && test_T >= 0.0001f;
-                done = done || (vis && !ok);
-                const float wgt = alpha * T_;
-                C0 = ok ? fmaf(g2.x, wgt, C0) : C0;
-                C1 = ok ? fmaf(g2.y, wgt, C1) : C1;
-                C2 = ok ? fmaf(g2.z, wgt, C2) : C2;
-                D = ok ? fmaf(g1.w, wgt, D) : D;
-                T_ = ok ? test_T : T_;
-                last = ok ? (r << 8) + j + 1 : last;
+                {   // second survivor (sees the transmittance / done state the first one left)
+                    const float test_T = T_ * (1.0f - alb);
+                    const bool vis = cb && !done && alb >= 1.0f / 255.0f;
+                    const bool ok = vis && test_T >= 0.0001f;
+                    done = done || (vis && !ok);
+                    const float wgt = ok ? alb * T_ : 0.0f;
+                    C0 = ok ? fmaf(b2.x, wgt, C0) : C0;
+                    C1 = ok ? fmaf(b2.y, wgt, C1) : C1;
+                    C2 = ok ? fmaf(b2.z, wgt, C2) : C2;
+                    D = ok ? fmaf(b1.w, wgt, D) : D;
+                    T_ = ok ? test_T : T_;
+                    last = ok ? (r << 8) + jb + 1 : last;
+                }
             }
         }
     }
