@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""Secondary benchmark (not the headline metric): the encoder-side rows of SURVEY.md section 8 --
+plane-sweep cost volume and one PTF fold -- on the shipped native shapes, with the reference-pinned
+CPU oracles timed beside them.  Prints one JSON line per workload.
+
+  python bench_encoder.py [--steps 20 --warmup 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48):
+    import inputs
+    from freesplat_amd import _lib
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    from oracle import cost_volume_oracle as cvo
+    torch.manual_seed(0)
+    m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=1)
+    sd = {k.replace(".", "__"): v for k, v in m.state_dict().items()}
+    mg = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                 mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    mg.load_state_dict(m.state_dict())
+    mg = mg.to(dev)
+    args = {k: v.to(dev) for k, v in kw.items()}
+    with torch.no_grad():
+        out = mg(**args).cpu()
+        _lib.profile_collect(); _lib.profile_enable(True)
+        dt = timed(lambda: mg(**args), steps, warmup)
+        _lib.profile_enable(False)
+        ms, cnt = _lib.profile_collect()["cost_volume"]
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    ref = cvo.cost_volume(kw["cur_feats"], kw["src_feats"], kw["src_extrinsics"], kw["src_Ks"], kw["cur_invK"],
+                          kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
+    t_cpu = time.perf_counter() - t0
+    torch.set_num_threads(8)
+    e = (out - ref).abs()
+    err = float(e.max())
+    n_out = int((e > 1e-4).sum())
+    flops = V * h4 * w4 * D * (480 * K + 5248)
+    kern = ms / max(cnt, 1) * 1e-3
+    return {"metric": f"cost-volume views/sec @ {h4}x{w4} match res, D={D}, K={K}", "value": V / dt, "unit": "views/s",
+            "ms_per_call": dt * 1e3, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cv_native", "views": V, "sources": K, "channels": C},
+            "roofline": {"bound": "mfma", "kernel": "cost_volume (relayout + sweep)", "achieved": flops / kern / 1e12,
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": flops / kern / 1e12 / 157.3,
+                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern * 1e3, "traffic": None},
+            "cpu_baseline": {"value": V / t_cpu, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                             "sample": "1 call of oracle/cost_volume_oracle.py (torch CPU, vectorised over D)"},
+            "parity": {"max_abs_err_vs_oracle": err, "cells_above_1e-4": n_out, "cells": e.numel()}}
+
+
+def bench_ptf(dev, steps, warmup, V=2, h=384, w=512):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_ptf_hip import _scene
+    from freesplat_amd import _lib
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    from oracle import ptf_oracle as po
+    E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=5)
+    torch.manual_seed(1)
+    m = PixelwiseTripletFusion()
+    params = {k: v.detach().clone() for k, v in m.gru.state_dict().items()}
+    m = m.to(dev)
+    d = lambda t: t.to(dev)
+    a = ([d(lat)], [d(coords)], d(dens), d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))
+    with torch.no_grad():
+        out = [x.cpu() for x in m.fuse_gaussians(*a)]
+        _lib.profile_collect(); _lib.profile_enable(True)
+        dt = timed(lambda: m.fuse_gaussians(*a), steps, warmup)
+        _lib.profile_enable(False)
+        ms, cnt = _lib.profile_collect()["ptf"]
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w))
+        t_cpu = time.perf_counter() - t0
+    torch.set_num_threads(8)
+    err = max(float((x - y).abs().max()) for x, y in zip(out, ref))
+    M_in, M_out = V * h * w, out[0].shape[1]
+    return {"metric": f"PTF folds/sec, {V} views @ {h}x{w}", "value": 1.0 / dt, "unit": "folds/s", "ms_per_call": dt * 1e3,
+            "dtype": "f32 / int64 indices", "data": "synthetic",
+            "config": {"workload": "ptf_native", "views": V, "gaussians_in": M_in, "gaussians_out": M_out},
+            "match_step_ms": ms / max(cnt, 1),
+            "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "folds/s", "cores": os.cpu_count(), "kind": "port",
+                             "sample": "1 fold through oracle/ptf_oracle.py (numpy match + torch CPU GRU)"},
+            "parity": {"max_abs_err_vs_oracle": err, "same_count": bool(out[0].shape == ref[0].shape)}}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    print(json.dumps(bench_cost_volume(dev, a.steps, a.warmup)), flush=True)
+    print(json.dumps(bench_cost_volume(dev, a.steps, a.warmup, V=3, K=2, h4=242, w4=324)), flush=True)
+    print(json.dumps(bench_ptf(dev, a.steps, a.warmup)), flush=True)
+    print(json.dumps(bench_ptf(dev, max(2, a.steps // 4), 1, V=10)), flush=True)

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
     const float ry = iK[4] * ux + iK[5] * vy + iK[6];
     const float rz = iK[8] * ux + iK[9] * vy + iK[10];
 
+    const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
     const int dchunk = (D + 3) / 4;
     const int d0 = wave * dchunk, d1 = min(D, d0 + dchunk);
 
@@ -126,8 +127,14 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
             const float qz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
             const float zz = qz + 1e-8f;                                  // :84
             const float sc = (fabsf(qz) > 1e-8f) ? 1.0f / zz : 1.0f;       // :83,85
-            // grid_sample(align_corners=False) of uv = 2*pix/size - 1  ->  source index = pix - 0.5
-            const float ix = qx * sc - 0.5f, iy = qy * sc - 0.5f;
+            // cost_volume.py:536: uv = 2 * pix * (1/size) - 1, then grid_sample(align_corners=False)
+            // un-normalises with ((uv + 1) * size - 1) / 2 (= pix - 0.5 in exact arithmetic).  The
+            // reference's rounding sequence is mirrored op by op (no contraction): whether a tap is just
+            // inside or outside the source image decides `dot != 0`, i.e. the validity count.
+            const float uvx = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qx, sc)), inv_w), 1.0f);
+            const float uvy = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qy, sc)), inv_h), 1.0f);
+            const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvx, 1.0f), (float)w), 1.0f), 0.5f);
+            const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvy, 1.0f), (float)h), 1.0f), 0.5f);
             const float fx0 = floorf(ix), fy0 = floorf(iy);
             const float tx = ix - fx0, ty = iy - fy0;
             // NaN/inf coordinates sample nothing (comparisons false)

@@ -83,6 +83,26 @@ def test_ragged_shapes_vs_oracle(hip_device, V, K, h4, w4, D, behind):
     assert (out - ref).abs().max().item() <= ATOL
 
 
+def test_c3_scale_border_validity_flips_are_rare(hip_device):
+    """242x324 (= 968x1296 / 4), K=2.  The reference's `dot != 0` validity count is discontinuous where
+    a bilinear tap is a rounding error inside / outside the source image; different (all fp32-valid)
+    projection roundings can flip it for isolated (pixel, plane) cells.  Everything else must agree."""
+    import inputs
+    from oracle import cost_volume_oracle as cvo
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    V, K, h4, w4, D = 3, 2, 242, 324, 64
+    torch.manual_seed(0)
+    m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=48)
+    kw = inputs.cv_inputs(V, K, h4, w4, 48, seed=1)
+    sd = {k.replace(".", "__"): v for k, v in m.state_dict().items()}
+    ref = cvo.cost_volume(kw["cur_feats"], kw["src_feats"], kw["src_extrinsics"], kw["src_Ks"], kw["cur_invK"],
+                          kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
+    err = (_run(m.to(hip_device), kw, hip_device) - ref).abs()
+    assert int((err > ATOL).sum()) <= max(1, err.numel() // 1_000_000)
+    assert float(err.flatten().kthvalue(err.numel() - err.numel() // 1_000_000 - 1).values) <= ATOL
+
+
 def test_zero_features_exact_zero_semantics(hip_device):
     """All-zero source features: every dot is exactly 0 -> no valid source -> MLP of the zero vector."""
     import inputs
