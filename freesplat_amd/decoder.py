@@ -183,7 +183,24 @@ class _RenderViews(torch.autograd.Function):
                                             out=(color[i], depth[i], alpha[i]))
             return rs
 
-        states = [launch(i, cap) for i in range(v)]
+        n_streams = min(R.NUM_STREAMS, v)
+        if n_streams > 1:
+            main = torch.cuda.current_stream()
+            while len(st.side_streams) < n_streams:
+                st.side_streams.append(torch.cuda.Stream(device=dev))
+            ready = torch.cuda.Event()
+            ready.record(main)
+            states = []
+            for i in range(v):
+                s = st.side_streams[i % n_streams]
+                if i < n_streams:
+                    s.wait_event(ready)     # inputs and output buffers were produced on `main`
+                with torch.cuda.stream(s):
+                    states.append(launch(i, cap))
+            for s in st.side_streams[:n_streams]:
+                main.wait_stream(s)
+        else:
+            states = [launch(i, cap) for i in range(v)]
         if deferred:
             _pending_checks.append(states)
         else:
