@@ -66,12 +66,45 @@ class _CostVolumeFn(torch.autograd.Function):
                                             p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
                                             p(w1), p(b1), p(w2), p(b2), p(w3), p(b3), p(ws), p(out),
                                             _lib.current_stream()), "fs_cost_volume_forward")
+        ctx.save_for_backward(cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, w1, b1, w2, b2, w3)
+        ctx.strides, ctx.D = strides, D
         return out
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("freesplat_amd cost volume: backward kernel not built yet "
-                                  "(forward-only this round; there is no torch fallback)")
+        cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, w1, b1, w2, b2, w3 = ctx.saved_tensors
+        B, K, C, h, w = src_feats.shape
+        D, strides = ctx.D, ctx.strides
+        dev = g.device
+        L = _lib.lib()
+        pts = B * D * h * w
+        ws = torch.empty(L.fs_cost_volume_backward_workspace_bytes(B, K, C, h, w, D), dtype=torch.uint8, device=dev)
+        d_cur, d_src = torch.empty_like(cur_feats), torch.empty_like(src_feats)
+        DZ1 = torch.empty(pts, 32, device=dev)
+        XP = torch.empty(pts, C + 2, device=dev)
+        DZ2 = torch.empty(pts, 32, device=dev)
+        H1 = torch.empty(pts, 32, device=dev)
+        d_w3 = torch.empty(1, 32, device=dev)
+        d_b3 = torch.empty(1, device=dev)
+        p = _lib.ptr
+        _lib.check(L.fs_cost_volume_backward(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
+                                             p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
+                                             p(w1.detach()), p(b1.detach()), p(w2.detach()), p(b2.detach()),
+                                             p(w3.detach()), p(g.contiguous()), p(ws), p(d_cur), p(d_src), p(DZ1),
+                                             p(XP), p(DZ2), p(H1), p(d_w3), p(d_b3), _lib.current_stream()),
+                   "fs_cost_volume_backward")
+        # weight gradients = sums of outer products over all points: four plain GEMMs / reductions
+        HC = C // 2
+        dW1p = DZ1.t() @ XP                                        # [32, 2*(HC+1)], columns [parity][slot]
+        dW1p = dW1p.view(32, 2, HC + 1)
+        d_w1 = torch.empty(32, C + 1, device=dev)
+        d_w1[:, 0:C:2] = dW1p[:, 0, :HC]
+        d_w1[:, 1:C:2] = dW1p[:, 1, :HC]
+        d_w1[:, C] = dW1p[:, 0, HC]
+        d_b1 = dW1p[:, 1, HC].contiguous()
+        d_w2 = DZ2.t() @ H1
+        d_b2 = DZ2.sum(0)
+        return d_cur, d_src, None, None, None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
 
 
 def _dev32(t: Tensor, name: str) -> Tensor:

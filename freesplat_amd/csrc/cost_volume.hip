@@ -198,6 +198,301 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
     }
 }
 
+
+// ==========================================================================================
+// Backward.  Same work decomposition as the forward (a wavefront = 32 pixels x a chunk of planes,
+// lane = (pixel, channel parity)); the forward is recomputed per plane, then
+//   dz2 = g * w3 * lrelu'(z2);  dh1^T = W2^T dz2^T (16 MFMA);  dz1 = dh1 * lrelu'(z1);
+//   dx^T = W1^T dz1^T with the rows of W1^T permuted so that every lane receives the gradient of
+//   exactly the channels it owns (2 x 16 MFMA) -- again no cross-lane traffic;
+//   d warped_k = valid_k/cnt * df + m_k/cnt * ddot * cur   -> scattered to the source maps with
+//   float atomics through the same 4 bilinear taps;  d cur += m_k/cnt * ddot * warped_k.
+// The MLP's weight gradients are sums of outer products over ALL (pixel, plane) points; the kernel
+// writes the per-point factors (dz1, permuted x, dz2, h1) to HBM and the host finishes them with
+// four plain GEMMs (rocBLAS) -- 584 B/point, 1.8 GB at the native 96x128x128x2 (HBM is 288 GB).
+// ==========================================================================================
+__global__ __launch_bounds__(256) void cv_relayout_back_kernel(const float* __restrict__ srcT,
+                                                               float* __restrict__ dst, int C, int hw,
+                                                               int n_maps)
+{
+    const long long total = (long long)n_maps * hw * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int pix = (int)(e % hw);
+        const long long r = e / hw;
+        const int c = (int)(r % C);
+        const long long map = r / C;
+        dst[(map * C + c) * hw + pix] = srcT[(map * hw + pix) * C + (size_t)(c & 1) * (C / 2) + (c >> 1)];
+    }
+}
+
+template <int HC>
+struct SrcWarp {
+    float wv[HC];
+    float wt[4];
+    size_t off[4];
+    bool ok[4];
+    float zz;
+};
+
+template <int HC>
+__device__ __forceinline__ void warp_source(SrcWarp<HC>& W, const float* __restrict__ srcT, int b, int k, int K,
+                                            int h, int w, int hf, bool live, float depth, float rx, float ry,
+                                            float rz, const float* __restrict__ src_extrinsics,
+                                            const float* __restrict__ src_Ks, float inv_w, float inv_h)
+{
+    constexpr int C = 2 * HC;
+    const int hw = h * w;
+    const float* Ks = src_Ks + ((size_t)b * K + k) * 16;
+    const float* Tx = src_extrinsics + ((size_t)b * K + k) * 16;
+    float P[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            P[4 * i + j] = Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] +
+                           Ks[4 * i + 3] * Tx[12 + j];
+    const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+    const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+    const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+    const float qz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+    W.zz = qz + 1e-8f;
+    const float sc = (fabsf(qz) > 1e-8f) ? 1.0f / W.zz : 1.0f;
+    const float uvx = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qx, sc)), inv_w), 1.0f);
+    const float uvy = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qy, sc)), inv_h), 1.0f);
+    const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvx, 1.0f), (float)w), 1.0f), 0.5f);
+    const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvy, 1.0f), (float)h), 1.0f), 0.5f);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float tx = ix - fx0, ty = iy - fy0;
+    const bool xin0 = fx0 >= 0.0f && fx0 <= (float)(w - 1), xin1 = fx0 >= -1.0f && fx0 <= (float)(w - 2);
+    const bool yin0 = fy0 >= 0.0f && fy0 <= (float)(h - 1), yin1 = fy0 >= -1.0f && fy0 <= (float)(h - 2);
+    const int x0 = xin0 || xin1 ? (int)fx0 : 0, y0 = yin0 || yin1 ? (int)fy0 : 0;
+#pragma unroll
+    for (int s = 0; s < HC; ++s) W.wv[s] = 0.0f;
+    const size_t base = (((size_t)b * K + k) * hw) * C + (size_t)hf * HC;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+        const int ox = tap & 1, oy = tap >> 1;
+        W.ok[tap] = live && (ox ? xin1 : xin0) && (oy ? yin1 : yin0);
+        W.wt[tap] = (ox ? tx : 1.0f - tx) * (oy ? ty : 1.0f - ty);
+        W.off[tap] = base + ((size_t)(y0 + oy) * w + (x0 + ox)) * C;
+        if (W.ok[tap]) {
+            const float4* q = (const float4*)(srcT + W.off[tap]);
+#pragma unroll
+            for (int s = 0; s < HC / 4; ++s) {
+                const float4 v = q[s];
+                W.wv[4 * s] += W.wt[tap] * v.x; W.wv[4 * s + 1] += W.wt[tap] * v.y;
+                W.wv[4 * s + 2] += W.wt[tap] * v.z; W.wv[4 * s + 3] += W.wt[tap] * v.w;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float dlrelu(float z) { return z > 0.0f ? 1.0f : 0.01f; }
+
+// channel slot (16*blk + r) held by row `i` of the permuted W1^T block: row i belongs to lane half
+// (i>>2)&1 as accumulator register r = (i&3) + 4*(i>>3)
+__device__ __forceinline__ constexpr int row_reg(int i) { return (i & 3) + 4 * (i >> 3); }
+__device__ __forceinline__ constexpr int row_half(int i) { return (i >> 2) & 1; }
+
+template <int HC>
+__global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
+    int B, int K, int h, int w, int D, const float* __restrict__ curT, const float* __restrict__ srcT,
+    const float* __restrict__ src_extrinsics, const float* __restrict__ src_Ks,
+    const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
+    long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
+    const float* __restrict__ g_out, float* __restrict__ d_curT, float* __restrict__ d_srcT,
+    float* __restrict__ DZ1, float* __restrict__ XP, float* __restrict__ DZ2, float* __restrict__ H1,
+    float* __restrict__ gw3, float* __restrict__ gb3)
+{
+    constexpr int C = 2 * HC;
+    constexpr int NBLK = (HC + 1 + 15) / 16;  // row blocks of the permuted W1^T
+    constexpr int XW = 2 * (HC + 1);          // row width of XP
+    const int hw = h * w;
+    const int groups = (hw + 31) / 32;
+    const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane & 31, hf = lane >> 5;
+    const int pix = grp * 32 + p;
+    const bool live = pix < hw;
+    const int pu = live ? pix % w : 0, pv = live ? pix / w : 0;
+
+    float a1[HC + 1];
+#pragma unroll
+    for (int s = 0; s < HC; ++s) a1[s] = w1[p * (C + 1) + 2 * s + hf];
+    a1[HC] = hf ? b1[p] : w1[p * (C + 1) + C];
+    float a2[16], a2t[16], w3r[16], b2r[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        a2[s] = w2[p * 32 + acc_row(s, hf)];
+        a2t[s] = w2[acc_row(s, hf) * 32 + p];  // (W2^T)[i = p][k = unit acc_row(s, hf)]
+        w3r[s] = w3[acc_row(s, hf)];
+        b2r[s] = b2[acc_row(s, hf)];
+    }
+    // permuted W1^T: block blk, row i = p  ->  feature of slot sl = 16*blk + row_reg(p), parity row_half(p)
+    float a1t[NBLK][16];
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+        const int sl = 16 * blk + row_reg(p), ph = row_half(p);
+        int feat = -1;
+        if (sl < HC) feat = 2 * sl + ph;
+        else if (sl == HC && ph == 0) feat = C;  // the dot feature
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a1t[blk][s] = feat >= 0 ? w1[acc_row(s, hf) * (C + 1) + feat] : 0.0f;
+    }
+
+    float cur[HC], dcur[HC];
+    {
+        const float4* q = (const float4*)(curT + ((size_t)b * hw + (live ? pix : 0)) * C + (size_t)hf * HC);
+#pragma unroll
+        for (int s = 0; s < HC / 4; ++s) {
+            const float4 v = q[s];
+            cur[4 * s] = v.x; cur[4 * s + 1] = v.y; cur[4 * s + 2] = v.z; cur[4 * s + 3] = v.w;
+        }
+#pragma unroll
+        for (int s = 0; s < HC; ++s) dcur[s] = 0.0f;
+    }
+    const float* iK = cur_invK + (size_t)b * 16;
+    const float ux = (float)pu + 0.5f, vy = (float)pv + 0.5f;
+    const float rx = iK[0] * ux + iK[1] * vy + iK[2];
+    const float ry = iK[4] * ux + iK[5] * vy + iK[6];
+    const float rz = iK[8] * ux + iK[9] * vy + iK[10];
+    const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
+    const int dchunk = (D + 3) / 4;
+    const int d0 = wave * dchunk, d1 = min(D, d0 + dchunk);
+    float gw3r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gw3r[r] = 0.0f;
+    float gb3r = 0.0f;
+    SrcWarp<HC> W;
+
+    for (int d = d0; d < d1; ++d) {
+        const float depth = planes[b * ps_b + d * ps_d + (live ? pix : 0) * ps_p];
+        const size_t pt = ((size_t)b * D + d) * hw + (live ? pix : 0);
+        const float go = live ? g_out[pt] : 0.0f;
+        // ---- forward recompute ----
+        float favg[HC];
+#pragma unroll
+        for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
+        float dot_sum = 0.0f, cnt = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, src_extrinsics, src_Ks, inv_w, inv_h);
+            float part = 0.0f;
+#pragma unroll
+            for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
+            float dotk = part + __shfl_xor(part, 32, 64);
+            dotk = (W.zz > 0.0f) ? dotk : 0.0f;
+            if (dotk != 0.0f) {
+                cnt += 1.0f;
+                dot_sum += dotk;
+#pragma unroll
+                for (int s = 0; s < HC; ++s) favg[s] += W.wv[s];
+            }
+        }
+        const float inv = 1.0f / (cnt + 1e-8f);
+        f32x16 z1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z1[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < HC; ++s) z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], favg[s] * inv, z1, 0, 0, 0);
+        const float xlast = hf ? 1.0f : dot_sum * inv;
+        z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[HC], xlast, z1, 0, 0, 0);
+        f32x16 z2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z2[r] = b2r[r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) z2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], lrelu(z1[s]), z2, 0, 0, 0);
+        // ---- backward through the MLP ----
+        f32x16 dz2, dh1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gw3r[r] += go * lrelu(z2[r]);
+            dz2[r] = go * w3r[r] * dlrelu(z2[r]);
+            dh1[r] = 0.0f;
+        }
+        if (hf == 0) gb3r += go;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2t[s], dz2[s], dh1, 0, 0, 0);
+        f32x16 dz1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz1[r] = dh1[r] * dlrelu(z1[r]);
+        float dfavg[HC];
+        float ddot = 0.0f;
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            f32x16 dx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(a1t[blk][s], dz1[s], dx, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (16 * blk + r < HC) dfavg[16 * blk + r] = dx[r];
+                else if (16 * blk + r == HC) ddot = dx[r];  // meaningful on the hf == 0 lane of the pixel
+            }
+        }
+        ddot = __shfl(ddot, p, 64);  // both parities of the pixel need it
+        // ---- per-point factors of the weight gradients ----
+        if (live) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const size_t o = pt * 32 + 8 * g4 + 4 * hf;  // accumulator rows 8g+4hf .. +3 are contiguous
+                *(float4*)(DZ1 + o) = make_float4(dz1[4 * g4], dz1[4 * g4 + 1], dz1[4 * g4 + 2], dz1[4 * g4 + 3]);
+                *(float4*)(DZ2 + o) = make_float4(dz2[4 * g4], dz2[4 * g4 + 1], dz2[4 * g4 + 2], dz2[4 * g4 + 3]);
+                *(float4*)(H1 + o) = make_float4(lrelu(z1[4 * g4]), lrelu(z1[4 * g4 + 1]), lrelu(z1[4 * g4 + 2]),
+                                                 lrelu(z1[4 * g4 + 3]));
+            }
+            float* xp = XP + pt * XW + (size_t)hf * (HC + 1);
+#pragma unroll
+            for (int s = 0; s < HC; ++s) xp[s] = favg[s] * inv;
+            xp[HC] = xlast;
+        }
+        // ---- back to the features ----
+        for (int k = 0; k < K; ++k) {
+            warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, src_extrinsics, src_Ks, inv_w, inv_h);
+            float part = 0.0f;
+#pragma unroll
+            for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
+            const float dotk = part + __shfl_xor(part, 32, 64);
+            const bool m = W.zz > 0.0f;
+            const bool valid = m && dotk != 0.0f;
+            const float cf = valid ? inv : 0.0f, cd = m ? inv * ddot : 0.0f;
+            float dwv[HC];
+#pragma unroll
+            for (int s = 0; s < HC; ++s) {
+                dwv[s] = cf * dfavg[s] + cd * cur[s];
+                dcur[s] += cd * W.wv[s];
+            }
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap)
+                if (W.ok[tap]) {
+                    float* q = d_srcT + W.off[tap];
+#pragma unroll
+                    for (int s = 0; s < HC; ++s) atomicAdd(q + s, W.wt[tap] * dwv[s]);
+                }
+        }
+    }
+    if (live) {
+        float* q = d_curT + ((size_t)b * hw + pix) * C + (size_t)hf * HC;
+#pragma unroll
+        for (int s = 0; s < HC; ++s) atomicAdd(q + s, dcur[s]);
+    }
+    // w3 / b3 gradients: reduce over the 32 pixels of each half, one atomic per unit per wavefront
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = gw3r[r];
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+        if (p == 0) atomicAdd(&gw3[acc_row(r, hf)], v);
+    }
+    {
+        float v = gb3r;
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+        if (lane == 0) atomicAdd(gb3, v);
+    }
+}
+
 }  // namespace fs
 
 using namespace fs;
@@ -245,5 +540,64 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
                                out);
     }
     FS_CHECK_LAUNCH("cost_volume");
+    return FS_OK;
+}
+
+FS_API size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w,
+                                                      int32_t D)
+{
+    if (B <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return 0;
+    const size_t hw = (size_t)h * w;
+    // pixel-major copies curT, srcT and their gradients d_curT, d_srcT
+    return align_up((size_t)B * (1 + (size_t)K) * C * hw * 2 * sizeof(float), 256);
+}
+
+FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                   const float* cur_feats, const float* src_feats,
+                                   const float* src_extrinsics, const float* src_Ks,
+                                   const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                                   int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                                   const float* b1, const float* w2, const float* b2, const float* w3,
+                                   const float* grad_out, void* workspace, float* d_cur_feats,
+                                   float* d_src_feats, float* DZ1, float* XP, float* DZ2, float* H1,
+                                   float* d_w3, float* d_b3, void* stream_)
+{
+    if (B <= 0 || K <= 0 || h <= 0 || w <= 0 || D <= 0) return FS_ERR_INVALID_ARG;
+    if (!cur_feats || !src_feats || !src_extrinsics || !src_Ks || !cur_invK || !planes || !w1 || !b1 || !w2 ||
+        !b2 || !w3 || !grad_out || !workspace || !d_cur_feats || !d_src_feats || !DZ1 || !XP || !DZ2 || !H1 ||
+        !d_w3 || !d_b3)
+        return FS_ERR_INVALID_ARG;
+    if (C != 48 && C != 16) return FS_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream_;
+    const int hw = h * w;
+    const size_t n_cur = (size_t)B * hw * C, n_src = n_cur * K;
+    float* curT = (float*)workspace;
+    float* srcT = curT + n_cur;
+    float* d_curT = srcT + n_src;
+    float* d_srcT = d_curT + n_cur;
+    ScopedStage prof_(kStCostVolume, st);
+    if (hipMemsetAsync(d_curT, 0, (n_cur + n_src) * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_w3, 0, 32 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_b3, 0, sizeof(float), st) != hipSuccess) {
+        set_last_error("cost volume backward memset", hipGetLastError());
+        return FS_ERR_LAUNCH;
+    }
+    auto blocks = [](size_t n) { return dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)); };
+    hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_cur), dim3(256), 0, st, cur_feats, curT, C, hw, B);
+    hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_src), dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
+    const int groups = (hw + 31) / 32;
+    if (C == 48)
+        hipLaunchKernelGGL(cost_volume_bwd_kernel<24>, dim3(B * groups), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
+                           src_extrinsics, src_Ks, cur_invK, planes, (long long)plane_stride_b,
+                           (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
+                           d_curT, d_srcT, DZ1, XP, DZ2, H1, d_w3, d_b3);
+    else
+        hipLaunchKernelGGL(cost_volume_bwd_kernel<8>, dim3(B * groups), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
+                           src_extrinsics, src_Ks, cur_invK, planes, (long long)plane_stride_b,
+                           (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
+                           d_curT, d_srcT, DZ1, XP, DZ2, H1, d_w3, d_b3);
+    hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_cur), dim3(256), 0, st, d_curT, d_cur_feats, C, hw, B);
+    hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_src), dim3(256), 0, st, d_srcT, d_src_feats, C, hw, B * K);
+    FS_CHECK_LAUNCH("cost_volume_backward");
     return FS_OK;
 }
