@@ -56,11 +56,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    # FS_DIST_BACKEND=gloo + FS_SHARE_GPU=1 exercise the N>1 control flow on a single-GPU box (tests only)
+    backend = os.environ.get("FS_DIST_BACKEND", "nccl")
+    if os.environ.get("FS_SHARE_GPU") == "1":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from freesplat_amd import _lib, synthetic
     from freesplat_amd.decoder import check_deferred, render_views
@@ -80,7 +87,7 @@ def main():
         for t in g.values():
             t.requires_grad_(True)
         target = torch.rand(len(mine), 3, H, W, device=dev)
-    gather = AsyncViewGather(n_total_views, device=dev) if (world > 1 and not args.no_gather) else None
+    gather = AsyncViewGather(n_total_views, device=dev) if (world > 1 and not args.no_gather and not train) else None
 
     def step():
         if train:
@@ -152,7 +159,8 @@ def main():
             "config": {"workload": args.workload, "mode": args.mode, "image_hw": [H, W], "gaussians": N,
                        "sh_degree": 2, "views_per_step_per_gpu": args.views,
                        "instances_per_view": int(n_inst),
-                       "parallelism": f"view-sharded x{world}" + (" + all_gather(color,depth)" if gather else "")},
+                       "parallelism": f"view-sharded x{world}" + (" + all_reduce(gaussian grads)" if (train and world > 1) else
+                                                                  " + all_gather(color,depth)" if gather else "")},
         }
         if stages:
             key = "render_bwd" if train else "render"
