@@ -192,6 +192,36 @@ int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const float*
                  int64_t* keep_idx, int64_t* fuse_idx, int64_t* fuse_pix, int64_t* append_pix,
                  int32_t* counts, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * Gaussian adapter steps either side of PTF                                             *
+ * ------------------------------------------------------------------------------------ */
+
+/* GaussianAdapter.forward(fusion=True) / Create_from_depth_map.project (gaussian_adapter.py:36-79,
+ * 174-188): depths[V,h*w] -> world xyz[V,h*w,3] = c2w_v @ ((u-cx)/fx z, (v-cy)/fy z, z, 1) with integer
+ * pixel coordinates; extrinsics[V,16] c2w row-major, k0_pix[4] = {fx,fy,cx,cy} of view 0 in pixels
+ * (the reference uses view 0's intrinsics for every view, :177-181).  Backward: g_xyz -> g_depths. */
+int fs_unproject_forward(int32_t V, int32_t h, int32_t w, const float* depths, const float* extrinsics,
+                         const float* k0_pix, float* xyz, void* stream);
+int fs_unproject_backward(int32_t V, int32_t h, int32_t w, const float* extrinsics, const float* k0_pix,
+                          const float* g_xyz, float* g_depths, void* stream);
+
+/* GaussianAdapter.forward(fusion=False, coords given) (gaussian_adapter.py:151-172, 191-201;
+ * common/gaussians.py:8-44): raw[M,34] = (scale 3, rotation xyzw 4, SH 27 as (xyz, d_sh)), depths[M],
+ * extrinsics[M,16] (blended c2w; only the 3x3 block is used), multiplier[m * mult_stride]
+ * (get_scale_multiplier, :203-214; stride 0 = one scalar), sh_mask[9] ->
+ * cov[M,9] = Rc (R S S^T R^T) Rc^T, harmonics[M,27] = SH * mask, scales[M,3], rotations[M,4] (unit).
+ * Backward: g_cov / g_harmonics / g_scales / g_rotations (each may be NULL = zero) ->
+ * g_raw[M,34], g_depths[M], g_extrinsics[M,16]. */
+int fs_gaussian_head_forward(int64_t M, const float* raw, const float* depths, const float* extrinsics,
+                             const float* multiplier, int64_t mult_stride, const float* sh_mask,
+                             float scale_min, float scale_max, float* cov, float* harmonics, float* scales,
+                             float* rotations, void* stream);
+int fs_gaussian_head_backward(int64_t M, const float* raw, const float* depths, const float* extrinsics,
+                              const float* multiplier, int64_t mult_stride, const float* sh_mask,
+                              float scale_min, float scale_max, const float* g_cov, const float* g_harmonics,
+                              const float* g_scales, const float* g_rotations, float* g_raw, float* g_depths,
+                              float* g_extrinsics, void* stream);
+
 /* Debug/test accessors into the opaque buffers (device pointers, no copies). */
 const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t H, int32_t W);  /* [T+1] offsets */
 const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] (id << 4) | 8x8-quadrant mask */
