@@ -5,7 +5,7 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W    (N>1, one rank per GPU)
 
-A "step" renders `--views` target views (default 4) of the synthetic 1.0 M-Gaussian scene at
+A "step" renders `--views` target views (default 8) of the synthetic 1.0 M-Gaussian scene at
 968x1296 on every rank (weak scaling, view-sharded: rank r renders its own block of the N*views
 target cameras) and, for N>1, all-gathers the rendered colour+depth images over RCCL on a side
 stream, overlapped with the next step.  Inputs are resident in HBM before the timed region.
@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--views", type=int, default=4, help="target views per step per GPU")
+    ap.add_argument("--views", type=int, default=8, help="target views per step per GPU")
     ap.add_argument("--workload", default="c3_968x1296_1M",
                     help="c3_968x1296_1M (metric config) | c2_640x480_300k | c1_256x256_plumbing")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],

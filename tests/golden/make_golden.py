@@ -13,6 +13,7 @@ Fixtures (fp32, torch.manual_seed, sizes per SURVEY.md 8(c)):
   cv_native_stat.json                  96x128, D=128 summary statistics + SHA-256 of the output
   ptf_small.npz / ptf_tie.npz          EncoderFreeSplat.fuse_gaussians (encoder_freesplat.py:431-522)
   adapter_small.npz                    GaussianAdapter.forward fusion=True / False (gaussian_adapter.py:135-201)
+  glue_small.npz                       calculate_distance_matrix (encoder_freesplat.py:50-60)
   framing.npz                          get_fov / get_projection_matrix + render_cuda's matrices
                                        (projection.py:233-247, cuda_splatting.py:17-87)
 """
@@ -188,8 +189,18 @@ def gen_framing():
          tan=(0.5 * fov).tan(), campos=Es[:, :3, 3])
 
 
+def gen_glue():
+    """calculate_distance_matrix (encoder_freesplat.py:50-60) on a 6-view pose set."""
+    from src.model.encoder.encoder_freesplat import calculate_distance_matrix
+    E, _ = cameras(6, 10, 10, baseline=1.5, seed=4)
+    E[3, :3, 3] += torch.tensor([0.4, 0.0, 0.2])
+    d = calculate_distance_matrix(E[None])
+    save("glue_small.npz", extrinsics=E, dist=d)
+
+
 if __name__ == "__main__":
     install_shim()
+    gen_glue()
     gen_framing()
     gen_cost_volume()
     gen_ptf_and_adapter()

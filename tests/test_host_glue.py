@@ -1,0 +1,63 @@
+"""CPU tests of the host-side plumbing against the reference's golden vectors: camera framing
+(decoder.py vs cuda_splatting.py:17-87 / projection.py:233-247) and the encoder -> cost-volume glue
+(encoder_glue.py vs encoder_freesplat.py:40-60, 216-288)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def _load(name):
+    z = np.load(os.path.join(HERE, "golden", name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def test_framing_matches_reference():
+    from freesplat_amd.decoder import _frame, get_fov, get_projection_matrix
+    g = _load("framing.npz")
+    np.testing.assert_allclose(get_fov(g["intrinsics"]).numpy(), g["fov"].numpy(), rtol=1e-6)
+    extr, scale, tx, ty, view, full = _frame(g["extrinsics"], g["intrinsics"], g["near"], g["far"], True)
+    np.testing.assert_allclose(torch.stack([tx, ty], -1).numpy(), g["tan"].numpy(), rtol=1e-6)
+    np.testing.assert_allclose(view.numpy(), g["view"].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(full.numpy(), g["full"].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(extr[:, :3, 3].numpy(), g["campos"].numpy(), rtol=1e-6)
+    P = get_projection_matrix(g["near"] * scale, g["far"] * scale, g["fov"][:, 0], g["fov"][:, 1])
+    np.testing.assert_allclose(P.numpy(), g["projection"].numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_distance_matrix_matches_reference_and_selection():
+    from freesplat_amd.encoder_glue import calculate_distance_matrix, select_source_views
+    g = _load("glue_small.npz")
+    E = g["extrinsics"]
+    d = calculate_distance_matrix(E[None])
+    np.testing.assert_allclose(d.numpy(), g["dist"].numpy(), rtol=1e-5, atol=1e-6)
+    V = E.shape[0]
+    all_other = select_source_views(E[None], num_context_views=V)
+    assert all_other.shape == (1, V, V - 1)
+    for i in range(V):
+        assert all_other[0, i].tolist() == [j for j in range(V) if j != i]
+    near3 = select_source_views(E[None], num_context_views=3)
+    assert near3.shape == (1, V, 2)
+    for i in range(V):
+        order = sorted(range(V), key=lambda j: (float(g["dist"][i, j]), j))
+        assert sorted(near3[0, i].tolist()) == sorted([j for j in order[:3] if j != i])
+        assert near3[0, i].tolist() == sorted(near3[0, i].tolist())
+
+
+def test_cost_volume_inputs_consistent_with_golden_generator():
+    """prepare_cost_volume_inputs reproduces the inputs the golden cost-volume fixtures were generated with."""
+    import inputs
+    from freesplat_amd.encoder_glue import prepare_cost_volume_inputs
+    V, h4, w4, C = 3, 12, 16, 48
+    kw = inputs.cv_inputs(V, 2, h4, w4, C, seed=203, behind=True)
+    E, Kn = inputs.cameras(V, h4, w4, seed=203)
+    E[-1, :3, 3] += torch.tensor([0.0, 0.0, 1.2])
+    E[-1, :3, :3] = E[-1, :3, :3] @ torch.tensor([[-1.0, 0, 0], [0, 1, 0], [0, 0, -1.0]])
+    out = prepare_cost_volume_inputs(E[None], Kn[None], kw["cur_feats"], torch.full((1, V), 0.5), torch.full((1, V), 15.0),
+                                     (h4 * 4, w4 * 4), num_context_views=V)
+    for k in ("src_feats", "src_extrinsics", "src_poses", "src_Ks", "cur_invK", "min_depth", "max_depth"):
+        np.testing.assert_allclose(out[k].numpy(), kw[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
