@@ -200,6 +200,86 @@ __global__ __launch_bounds__(256) void ptf_emit_kernel(int M, int P, int nbM, co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Inference-path data movement of one fold step (encoder_freesplat.py:485-519), fused:
+//   ptf_gru_inputs  builds the GRU's concatenated input rows [hid | he | x | xe] (networks.py:201-206,
+//                   positional encodings of encoder_freesplat.py:62-77, 485-486) straight from the
+//                   state / view arrays through the index lists -- replaces ~12 index_select / cat /
+//                   sin / cos launches;
+//   ptf_write_state writes the next global state in its final order
+//                   [kept (copied) | fused (GRU output + density-weighted blends) | appended pixels]
+//                   -- replaces ~40 boolean-mask / cat launches and O(M) temporaries per field.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pos_enc2(float a, float b, float* __restrict__ out)  // 24 floats
+{
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float f = (float)(1 << k);
+        out[2 * k] = sinf(a * f); out[2 * k + 1] = cosf(a * f);
+        out[12 + 2 * k] = sinf(b * f); out[12 + 2 * k + 1] = cosf(b * f);
+    }
+}
+
+// one 16-lane group per fused pair: lanes 0..15 move the two 64-float latents as float4, lane 0/1 the encodings
+__global__ __launch_bounds__(256) void ptf_gru_inputs_kernel(int n_fuse, const long long* __restrict__ fuse_idx,
+                                                            const long long* __restrict__ fuse_pix,
+                                                            const float* __restrict__ G, const float* __restrict__ R,
+                                                            const float* __restrict__ O, const float* __restrict__ g_i,
+                                                            const float* __restrict__ rho_i,
+                                                            const float* __restrict__ om_i, float* __restrict__ cat)
+{
+    const int t = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
+    if (t >= n_fuse) return;
+    const long long m = fuse_idx[t], p = fuse_pix[t];
+    float* row = cat + (size_t)t * 176;
+    ((float4*)row)[c] = ((const float4*)(G + m * 64))[c];                 // hid      [0,64)
+    ((float4*)(row + 88))[c] = ((const float4*)(g_i + p * 64))[c];        // x        [88,152)
+    if (c == 0) pos_enc2(rho_i[p], O[m], row + 64);                        // he       [64,88)   :486
+    if (c == 1) pos_enc2(R[m], om_i[p], row + 152);                        // xe       [152,176) :485
+}
+
+struct PtfState { float *G, *X, *R, *O, *E, *D; };
+
+__global__ __launch_bounds__(256) void ptf_write_state_kernel(
+    int n_keep, int n_fuse, int n_app, const long long* __restrict__ keep_idx, const long long* __restrict__ fuse_idx,
+    const long long* __restrict__ fuse_pix, const long long* __restrict__ app_pix, PtfState s, const float* __restrict__ g_i,
+    const float* __restrict__ x_i, const float* __restrict__ rho_i, const float* __restrict__ om_i,
+    const float* __restrict__ d_i, const float* __restrict__ E_i, const float* __restrict__ fused, PtfState o)
+{
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
+    const int n_out = n_keep + n_fuse + n_app;
+    if (row >= n_out) return;
+    float4* oG = (float4*)(o.G + (size_t)row * 64);
+    if (row < n_keep) {                                                     // global[~mask]          :492
+        const long long m = keep_idx[row];
+        oG[c] = ((const float4*)(s.G + m * 64))[c];
+        if (c < 4) ((float4*)(o.E + (size_t)row * 16))[c] = ((const float4*)(s.E + m * 16))[c];
+        if (c == 4) { o.X[3 * (size_t)row] = s.X[3 * m]; o.X[3 * (size_t)row + 1] = s.X[3 * m + 1]; o.X[3 * (size_t)row + 2] = s.X[3 * m + 2]; }
+        if (c == 5) { o.R[row] = s.R[m]; o.O[row] = s.O[m]; o.D[row] = s.D[m]; }
+    } else if (row < n_keep + n_fuse) {                                     // fused entries          :493-506
+        const int t = row - n_keep;
+        const long long m = fuse_idx[t], p = fuse_pix[t];
+        oG[c] = ((const float4*)(fused + (size_t)t * 64))[c];
+        const float w0 = s.R[m], w1 = rho_i[p], ws = w0 + w1;
+        if (c < 4) {
+            const float4 a = ((const float4*)(s.E + m * 16))[c], b = ((const float4*)E_i)[c];
+            ((float4*)(o.E + (size_t)row * 16))[c] = make_float4((a.x * w0 + b.x * w1) / ws, (a.y * w0 + b.y * w1) / ws,
+                                                                  (a.z * w0 + b.z * w1) / ws, (a.w * w0 + b.w * w1) / ws);
+        }
+        if (c == 4) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.X[3 * (size_t)row + k] = (s.X[3 * m + k] * w0 + x_i[3 * p + k] * w1) / ws;
+        }
+        if (c == 5) { o.R[row] = ws; o.O[row] = s.O[m] + om_i[p]; o.D[row] = (s.D[m] * w0 + d_i[p] * w1) / ws; }
+    } else {                                                                // ~fusion_mask pixels    :508-519
+        const long long p = app_pix[row - n_keep - n_fuse];
+        oG[c] = ((const float4*)(g_i + p * 64))[c];
+        if (c < 4) ((float4*)(o.E + (size_t)row * 16))[c] = ((const float4*)E_i)[c];
+        if (c == 4) { o.X[3 * (size_t)row] = x_i[3 * p]; o.X[3 * (size_t)row + 1] = x_i[3 * p + 1]; o.X[3 * (size_t)row + 2] = x_i[3 * p + 2]; }
+        if (c == 5) { o.R[row] = rho_i[p]; o.O[row] = om_i[p]; o.D[row] = d_i[p]; }
+    }
+}
+
 __host__ __device__ inline size_t ptf_scratch_layout(int M, int P, size_t off[7])
 {
     const int nbM = (M + kScanBlock - 1) / kScanBlock, nbP = (P + kScanBlock - 1) / kScanBlock;
@@ -258,5 +338,46 @@ FS_API int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const
     hipLaunchKernelGGL(ptf_emit_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, P, nbM, win, app, pix_of, blocks,
                        (long long*)keep_idx, (long long*)fuse_idx, (long long*)fuse_pix, (long long*)append_pix);
     FS_CHECK_LAUNCH("ptf_match");
+    return FS_OK;
+}
+
+FS_API int fs_ptf_gru_inputs(int32_t n_fuse, const int64_t* fuse_idx, const int64_t* fuse_pix, const float* G,
+                             const float* R, const float* O, const float* g_i, const float* rho_i,
+                             const float* om_i, float* cat, void* stream_)
+{
+    if (n_fuse < 0) return FS_ERR_INVALID_ARG;
+    if (n_fuse == 0) return FS_OK;
+    if (!fuse_idx || !fuse_pix || !G || !R || !O || !g_i || !rho_i || !om_i || !cat) return FS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    ScopedStage prof_(kStPtf, st);
+    hipLaunchKernelGGL(ptf_gru_inputs_kernel, dim3((n_fuse + 15) / 16), dim3(256), 0, st, n_fuse,
+                       (const long long*)fuse_idx, (const long long*)fuse_pix, G, R, O, g_i, rho_i, om_i, cat);
+    FS_CHECK_LAUNCH("ptf_gru_inputs");
+    return FS_OK;
+}
+
+FS_API int fs_ptf_write_state(int32_t n_keep, int32_t n_fuse, int32_t n_app, const int64_t* keep_idx,
+                              const int64_t* fuse_idx, const int64_t* fuse_pix, const int64_t* append_pix,
+                              const float* G, const float* X, const float* R, const float* O, const float* E,
+                              const float* D, const float* g_i, const float* x_i, const float* rho_i,
+                              const float* om_i, const float* d_i, const float* E_i, const float* fused,
+                              float* oG, float* oX, float* oR, float* oO, float* oE, float* oD, void* stream_)
+{
+    if (n_keep < 0 || n_fuse < 0 || n_app < 0) return FS_ERR_INVALID_ARG;
+    const long long n_out = (long long)n_keep + n_fuse + n_app;
+    if (n_out == 0) return FS_OK;
+    if (!g_i || !x_i || !rho_i || !om_i || !d_i || !E_i || !oG || !oX || !oR || !oO || !oE || !oD)
+        return FS_ERR_INVALID_ARG;
+    if ((n_keep || n_fuse) && (!G || !X || !R || !O || !E || !D)) return FS_ERR_INVALID_ARG;
+    if (n_fuse && (!fused || !fuse_idx || !fuse_pix)) return FS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    ScopedStage prof_(kStPtf, st);
+    PtfState s{const_cast<float*>(G), const_cast<float*>(X), const_cast<float*>(R), const_cast<float*>(O),
+               const_cast<float*>(E), const_cast<float*>(D)};
+    PtfState o{oG, oX, oR, oO, oE, oD};
+    hipLaunchKernelGGL(ptf_write_state_kernel, dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
+                       n_app, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
+                       (const long long*)append_pix, s, g_i, x_i, rho_i, om_i, d_i, E_i, fused, o);
+    FS_CHECK_LAUNCH("ptf_write_state");
     return FS_OK;
 }

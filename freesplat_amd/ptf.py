@@ -82,12 +82,68 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
     return keep[:nk], fuse[:nf], fpix[:nf], app[:na]
 
 
+def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
+                          depth_thres):
+    """Inference path (no autograd): per view fs_ptf_match -> fs_ptf_gru_inputs -> 6 GEMMs (rocBLAS) ->
+    fs_ptf_write_state.  Same results and order as the differentiable path below."""
+    L = _lib.lib()
+    p = _lib.ptr
+    h, w = image_shape
+    V = gaussians[0].shape[1]
+    f = lambda t: t.detach().float().contiguous()
+    lat = f(gaussians[0][0])                      # [V,P,64]
+    xs = f(coords[0][0, :, :, 0, 0])              # [V,P,3]
+    rho = f(densities[0, :, :, 0, 0])             # [V,P]
+    om = f(weight_emb[0, :, :, 0, 0])
+    dep = f(depths.reshape(V, -1))
+    Es = f(extrinsics[0])                         # [V,4,4]
+    dev = lat.device
+    P = h * w
+    G, X, R, O, D = lat[0], xs[0], rho[0], om[0], dep[0]
+    E = Es[0].reshape(1, 16).repeat(P, 1)
+    for i in range(1, V):
+        K = intrinsics[0, i].clone()
+        K[:1, :] *= w
+        K[1:2, :] *= h
+        kpix = torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+        w2c = torch.linalg.inv_ex(Es[i]).inverse
+        keep, fuse, fpix, app = match_view(X, w2c, kpix, dep[i], h, w, depth_thres)
+        nk, nf, na = keep.numel(), fuse.numel(), app.numel()
+        fused = None
+        if nf > 0:
+            cat = torch.empty(nf, 176, device=dev)
+            _lib.check(L.fs_ptf_gru_inputs(nf, p(fuse), p(fpix), p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]),
+                                           p(cat), _lib.current_stream()), "fs_ptf_gru_inputs")
+            hid = cat[:, :64]
+            r = torch.sigmoid(gru.mlp_r(cat))
+            z = torch.sigmoid(gru.mlp_z(cat))
+            q = torch.tanh(gru.mlp_n(torch.cat((r * hid, cat[:, 88:]), dim=-1)))
+            fused = ((1 - z) * hid + z * q).contiguous()
+        n_out = nk + nf + na
+        nG, nX = torch.empty(n_out, 64, device=dev), torch.empty(n_out, 3, device=dev)
+        nR, nO, nD = (torch.empty(n_out, device=dev) for _ in range(3))
+        nE = torch.empty(n_out, 16, device=dev)
+        _lib.check(L.fs_ptf_write_state(nk, nf, na, p(keep), p(fuse), p(fpix), p(app), p(G), p(X), p(R), p(O), p(E), p(D),
+                                        p(lat[i]), p(xs[i]), p(rho[i]), p(om[i]), p(dep[i]), p(Es[i].contiguous()),
+                                        p(fused), p(nG), p(nX), p(nR), p(nO), p(nE), p(nD), _lib.current_stream()),
+                   "fs_ptf_write_state")
+        G, X, R, O, E, D = nG, nX, nR, nO, nE, nD
+    return G[None], X[None], E.view(1, -1, 4, 4), D[None]
+
+
 def fuse_gaussians(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
                    depth_thres=0.1):
     """Same contract as EncoderFreeSplat.fuse_gaussians (encoder_freesplat.py:431-522); `self` only
     needs a `.gru` attribute.  gaussians = [latents [1,V,P,64]], coords = [[1,V,P,1,1,3]],
     densities / weight_emb [1,V,P,1,1], depths [V,1,h,w], extrinsics [1,V,4,4], intrinsics [1,V,3,3].
-    Returns (latents [1,M,64], xyz [1,M,3], extrinsics [1,M,4,4], depths [1,M])."""
+    Returns (latents [1,M,64], xyz [1,M,3], extrinsics [1,M,4,4], depths [1,M]).
+    Without autograd (eval / torch.no_grad) the fold runs through the fused HIP data-movement kernels."""
+    needs_grad = torch.is_grad_enabled() and (
+        any(t.requires_grad for t in (gaussians[0], coords[0], densities, weight_emb, depths))
+        or any(q.requires_grad for q in self.gru.parameters()))
+    if not needs_grad and gaussians[0].shape[0] == 1:
+        return _fuse_gaussians_fused(self.gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics,
+                                     image_shape, depth_thres)
     length = gaussians[0].shape[1]
     G = gaussians[0][:, 0]
     R = densities[:, 0]

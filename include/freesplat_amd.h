@@ -192,6 +192,24 @@ int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const float*
                  int64_t* keep_idx, int64_t* fuse_idx, int64_t* fuse_pix, int64_t* append_pix,
                  int32_t* counts, void* stream);
 
+/* Inference-path data movement of the same fold step (encoder_freesplat.py:485-519), given the lists of
+ * fs_ptf_match.  State arrays: G[M,64] latents, X[M,3], R[M] densities, O[M] weights, E[M,16], D[M]
+ * depths; view-i arrays g_i[P,64], x_i[P,3], rho_i[P], om_i[P], d_i[P], E_i[16].
+ *   fs_ptf_gru_inputs: cat[n_fuse,176] = [G[m] | PE6(rho_i[p], O[m]) | g_i[p] | PE6(R[m], om_i[p])]
+ *                      (the GRU's concatenated input, networks.py:201-206; its linears are the
+ *                      caller's GEMMs);
+ *   fs_ptf_write_state: next state o* of n_keep+n_fuse+n_app rows in the reference's order
+ *                      [kept | fused (fused[n_fuse,64] = GRU output, density-weighted blends) | appended]. */
+int fs_ptf_gru_inputs(int32_t n_fuse, const int64_t* fuse_idx, const int64_t* fuse_pix, const float* G,
+                      const float* R, const float* O, const float* g_i, const float* rho_i, const float* om_i,
+                      float* cat, void* stream);
+int fs_ptf_write_state(int32_t n_keep, int32_t n_fuse, int32_t n_app, const int64_t* keep_idx,
+                       const int64_t* fuse_idx, const int64_t* fuse_pix, const int64_t* append_pix,
+                       const float* G, const float* X, const float* R, const float* O, const float* E,
+                       const float* D, const float* g_i, const float* x_i, const float* rho_i,
+                       const float* om_i, const float* d_i, const float* E_i, const float* fused, float* oG,
+                       float* oX, float* oR, float* oO, float* oE, float* oD, void* stream);
+
 /* ------------------------------------------------------------------------------------ *
  * Gaussian adapter steps either side of PTF                                             *
  * ------------------------------------------------------------------------------------ */

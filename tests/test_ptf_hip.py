@@ -81,13 +81,33 @@ def _run_fold(g, gru_params, dev):
                                d(g["extrinsics"])[None], d(g["intrinsics"])[None], (int(g["h"]), int(g["w"])))
 
 
+@pytest.mark.parametrize("grad", [False, True])
 @pytest.mark.parametrize("name", ["ptf_small.npz", "ptf_tie.npz"])
-def test_fold_matches_reference_golden(hip_device, name):
+def test_fold_matches_reference_golden(hip_device, name, grad):
+    """grad=False: fused HIP data-movement path; grad=True: differentiable torch-op path."""
     g, gru = _load(name)
-    _, out = _run_fold(g, gru, hip_device)
+    with torch.set_grad_enabled(grad):
+        _, out = _run_fold(g, gru, hip_device)
     for got, key in zip(out, ("out_latent", "out_xyz", "out_extrinsics", "out_depths")):
         assert got.shape == g[key].shape, key
-        assert (got.cpu() - g[key]).abs().max().item() <= 1e-4, key
+        assert (got.detach().cpu() - g[key]).abs().max().item() <= 1e-4, key
+
+
+@pytest.mark.parametrize("V,h,w", [(2, 96, 128), (5, 48, 64)])
+def test_fused_inference_path_equals_differentiable_path(hip_device, V, h, w):
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=60 + V)
+    torch.manual_seed(2)
+    m = PixelwiseTripletFusion().to(hip_device)
+    d = lambda t: t.to(hip_device)
+    a = ([d(lat)], [d(coords)], d(dens), d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))
+    with torch.no_grad():
+        fused = m.fuse_gaussians(*a)
+    ref = m.fuse_gaussians(*a)   # GRU parameters require grad -> differentiable path
+    assert ref[0].requires_grad and not fused[0].requires_grad
+    for x, y, name in zip(fused, ref, ("latent", "xyz", "extrinsics", "depths")):
+        assert x.shape == y.shape, name
+        assert (x - y.detach()).abs().max().item() <= 2e-5, name
 
 
 @pytest.mark.parametrize("V,h,w", [(2, 96, 128), (4, 48, 64)])
