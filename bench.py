@@ -168,8 +168,10 @@ def main():
             per = ms / max(cnt, 1) * 1e-3
             alg = alg_bwd if train else alg_fwd
             ach = alg / per / 1e9 if per > 0 else 0.0
+            traffic, traffic_src = committed_traffic("fs::" + key + "_kernel") if args.workload.startswith("c3") else (None, None)
             out["roofline"] = {"bound": "hbm", "kernel": key + "_kernel", "achieved": ach, "peak": 8000.0,
-                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": per * 1e3,
                                "launches": cnt}
             out["kernel_ms_per_view"] = {k: v[0] / max(v[1], 1) for k, v in stages.items() if v[1]}
@@ -178,6 +180,21 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def committed_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary under profiles/
+    (FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/run_rocprof.sh); PMC counters cannot be
+    collected from inside the timed run.  (None, None) if no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return (float(k["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)) if k else (None, None)
+    except Exception:
+        return None, None
 
 
 def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload):
