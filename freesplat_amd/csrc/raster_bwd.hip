@@ -133,11 +133,19 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
         const int m = min(256, min(n, maxlast) - (r << 8));
         for (int c = (m - 1) & ~63; c >= 0; c -= 64) {
           unsigned long long hits = __ballot((c + lane < m) && (s_id[c + lane] & qbit));
+          if (!hits) continue;
+          // software pipeline: fetch the next survivor's record from LDS while this one is processed
+          int jn = c + 63 - __builtin_clzll(hits);
+          float4 n0 = s0[jn], n1 = s1[jn], n2 = s2[jn];
           while (hits) {
-            const int j = c + 63 - __builtin_clzll(hits);  // back to front
+            const int j = jn;  // back to front
+            const float4 g0 = n0, g1 = n1, g2 = n2;
             hits &= ~(1ull << (j - c));
+            if (hits) {
+                jn = c + 63 - __builtin_clzll(hits);
+                n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
+            }
             const int contributor = (r << 8) + j + 1;
-            const float4 g0 = s0[j], g1 = s1[j];
             const float dx = g0.x - pfx, dy = g0.y - pfy;
             const float power = fmaf(g0.z * dx, dx, fmaf(g0.w * dy, dy, (g1.x * dx) * dy));
             bool on = contributor <= last && power <= 0.0f && power >= g1.z;
@@ -147,11 +155,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
                 alpha = fminf(0.99f, g1.y * G);
                 on = alpha >= 1.0f / 255.0f;
             }
-            if (!__any(on)) continue;
+            const unsigned long long onmask = __ballot(on);
+            if (!onmask) continue;
             float v_mx = 0, v_my = 0, v_ca = 0, v_cb = 0, v_cc = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_z = 0;
             if (on) {
-                const float4 g2 = s2[j];
-                T_ = T_ / (1.0f - alpha);
+                // 1 - alpha >= 0.01: one reciprocal (1 ulp) serves both divisions of the reference formula
+                const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T_ = T_ * rinv;
                 const float w = alpha * T_;
                 float dL_dalpha = 0.0f;
                 acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0; lc0 = g2.x; dL_dalpha += (g2.x - acc0) * gc0;
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
                 v_r = w * gc0; v_g = w * gc1; v_b = w * gc2; v_z = w * gd;
                 dL_dalpha *= T_;
                 last_alpha = alpha;
-                dL_dalpha += (-Tf / (1.0f - alpha)) * bgdot;
+                dL_dalpha -= Tf * rinv * bgdot;
                 const float dL_dG = g1.y * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 const float cA = -2.0f * g0.z, cC = -2.0f * g0.w, cB = -g1.x;
