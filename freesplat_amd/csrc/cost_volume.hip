@@ -44,7 +44,19 @@ __global__ __launch_bounds__(256) void cv_relayout_kernel(const float* __restric
     }
 }
 
-__device__ __forceinline__ float lrelu(float x) { return x > 0.0f ? x : 0.01f * x; }
+// P = (K_src @ T_src<-cur)[:3, :] per (b, k)  (geometry_utils.py:78-80): computed once per call
+__global__ void cv_proj_kernel(int n, const float* __restrict__ src_Ks, const float* __restrict__ src_extrinsics,
+                               float* __restrict__ P)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * 12) return;
+    const int m = e / 12, i = (e % 12) / 4, j = e % 4;
+    const float* Ks = src_Ks + (size_t)m * 16;
+    const float* Tx = src_extrinsics + (size_t)m * 16;
+    P[e] = Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] + Ks[4 * i + 3] * Tx[12 + j];
+}
+
+__device__ __forceinline__ float lrelu(float x) { return fmaxf(x, 0.01f * x); }  // slope < 1: max picks the right branch
 
 // accumulator row held by (reg r, half hf) of a 32x32 MFMA result (guide, "Fragment layout")
 __device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
@@ -52,7 +64,7 @@ __device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3)
 template <int HC>  // HC = C/2 channels per lane
 __global__ __launch_bounds__(256) void cost_volume_kernel(
     int B, int K, int h, int w, int D, const float* __restrict__ curT, const float* __restrict__ srcT,
-    const float* __restrict__ src_extrinsics, const float* __restrict__ src_Ks,
+    const float* __restrict__ Pmat,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
@@ -100,8 +112,9 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
     const float rz = iK[8] * ux + iK[9] * vy + iK[10];
 
     const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
-    const int dchunk = (D + 3) / 4;
-    const int d0 = wave * dchunk, d1 = min(D, d0 + dchunk);
+    // planes [d0, d1) of this wavefront: gridDim.y * 4 wavefronts share the D planes of a pixel group
+    const int dchunk = (D + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4);
+    const int d0 = min(D, ((int)blockIdx.y * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
 
     for (int d = d0; d < d1; ++d) {
         const float depth = planes[b * ps_b + d * ps_d + (live ? pix : 0) * ps_p];
@@ -110,16 +123,7 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
         for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
         float dot_sum = 0.0f, cnt = 0.0f;
         for (int k = 0; k < K; ++k) {
-            // P = (K_src @ T_src<-cur)[:3, :]  (geometry_utils.py:78-80); uniform per (b,k)
-            const float* Ks = src_Ks + ((size_t)b * K + k) * 16;
-            const float* Tx = src_extrinsics + ((size_t)b * K + k) * 16;
-            float P[12];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    P[4 * i + j] = Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] +
-                                   Ks[4 * i + 3] * Tx[12 + j];
+            const float* P = Pmat + ((size_t)b * K + k) * 12;  // wave-uniform: scalar loads
             // world point = depth * r (homogeneous 1): geometry_utils.py:56-58
             const float X = depth * rx, Y = depth * ry, Z = depth * rz;
             const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
@@ -237,20 +241,11 @@ struct SrcWarp {
 template <int HC>
 __device__ __forceinline__ void warp_source(SrcWarp<HC>& W, const float* __restrict__ srcT, int b, int k, int K,
                                             int h, int w, int hf, bool live, float depth, float rx, float ry,
-                                            float rz, const float* __restrict__ src_extrinsics,
-                                            const float* __restrict__ src_Ks, float inv_w, float inv_h)
+                                            float rz, const float* __restrict__ Pmat, float inv_w, float inv_h)
 {
     constexpr int C = 2 * HC;
     const int hw = h * w;
-    const float* Ks = src_Ks + ((size_t)b * K + k) * 16;
-    const float* Tx = src_extrinsics + ((size_t)b * K + k) * 16;
-    float P[12];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            P[4 * i + j] = Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] +
-                           Ks[4 * i + 3] * Tx[12 + j];
+    const float* P = Pmat + ((size_t)b * K + k) * 12;
     const float X = depth * rx, Y = depth * ry, Z = depth * rz;
     const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
     const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
@@ -297,7 +292,7 @@ __device__ __forceinline__ constexpr int row_half(int i) { return (i >> 2) & 1; 
 template <int HC>
 __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     int B, int K, int h, int w, int D, const float* __restrict__ curT, const float* __restrict__ srcT,
-    const float* __restrict__ src_extrinsics, const float* __restrict__ src_Ks,
+    const float* __restrict__ Pmat,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
@@ -358,8 +353,8 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     const float ry = iK[4] * ux + iK[5] * vy + iK[6];
     const float rz = iK[8] * ux + iK[9] * vy + iK[10];
     const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
-    const int dchunk = (D + 3) / 4;
-    const int d0 = wave * dchunk, d1 = min(D, d0 + dchunk);
+    const int dchunk = (D + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4);
+    const int d0 = min(D, ((int)blockIdx.y * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
     float gw3r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) gw3r[r] = 0.0f;
@@ -376,7 +371,7 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
         for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
         float dot_sum = 0.0f, cnt = 0.0f;
         for (int k = 0; k < K; ++k) {
-            warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, src_extrinsics, src_Ks, inv_w, inv_h);
+            warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, Pmat, inv_w, inv_h);
             float part = 0.0f;
 #pragma unroll
             for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
@@ -449,7 +444,7 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
         }
         // ---- back to the features ----
         for (int k = 0; k < K; ++k) {
-            warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, src_extrinsics, src_Ks, inv_w, inv_h);
+            warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, Pmat, inv_w, inv_h);
             float part = 0.0f;
 #pragma unroll
             for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
@@ -497,10 +492,19 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
 
 using namespace fs;
 
+// Number of plane slices (grid.y): enough wavefronts for ~6+ rounds over the chip's 1024 SIMDs x 2 slots,
+// but at least 4 planes per wavefront so the per-wavefront weight loads stay amortised.
+static int cv_plane_split(int B, int groups, int D)
+{
+    int split = 1;
+    while (split * 4 * 4 < D && (long long)B * groups * 4 * split < 12288) split *= 2;
+    return split;
+}
+
 FS_API size_t fs_cost_volume_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w)
 {
     if (B < 0 || K < 0 || C <= 0 || h <= 0 || w <= 0) return 0;
-    return align_up((size_t)B * (1 + (size_t)K) * C * h * w * sizeof(float), 256);
+    return align_up((size_t)B * (1 + (size_t)K) * C * h * w * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256);
 }
 
 FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
@@ -520,8 +524,11 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
     const int hw = h * w;
     float* curT = (float*)workspace;
     float* srcT = curT + (size_t)B * hw * C;
+    float* Pmat = (float*)((char*)workspace + align_up((size_t)B * (1 + (size_t)K) * C * hw * sizeof(float), 256));
     {
         ScopedStage prof_(kStCostVolume, st);
+        hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics,
+                           Pmat);
         const long long tot1 = (long long)B * hw * C, tot2 = tot1 * K;
         hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot1 + 255) / 256, 65536)),
                            dim3(256), 0, st, cur_feats, curT, C, hw, B);
@@ -529,13 +536,13 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
                            dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
         const int groups = (hw + 31) / 32;
         if (C == 48)
-            hipLaunchKernelGGL(cost_volume_kernel<24>, dim3(B * groups), dim3(256), 0, st, B, K, h, w, D, curT,
-                               srcT, src_extrinsics, src_Ks, cur_invK, planes, (long long)plane_stride_b,
+            hipLaunchKernelGGL(cost_volume_kernel<24>, dim3(B * groups, cv_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT,
+                               srcT, Pmat, cur_invK, planes, (long long)plane_stride_b,
                                (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3,
                                out);
         else
-            hipLaunchKernelGGL(cost_volume_kernel<8>, dim3(B * groups), dim3(256), 0, st, B, K, h, w, D, curT,
-                               srcT, src_extrinsics, src_Ks, cur_invK, planes, (long long)plane_stride_b,
+            hipLaunchKernelGGL(cost_volume_kernel<8>, dim3(B * groups, cv_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT,
+                               srcT, Pmat, cur_invK, planes, (long long)plane_stride_b,
                                (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3,
                                out);
     }
@@ -549,7 +556,7 @@ FS_API size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int3
     if (B <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return 0;
     const size_t hw = (size_t)h * w;
     // pixel-major copies curT, srcT and their gradients d_curT, d_srcT
-    return align_up((size_t)B * (1 + (size_t)K) * C * hw * 2 * sizeof(float), 256);
+    return align_up((size_t)B * (1 + (size_t)K) * C * hw * 2 * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256);
 }
 
 FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
@@ -575,7 +582,9 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
     float* srcT = curT + n_cur;
     float* d_curT = srcT + n_src;
     float* d_srcT = d_curT + n_cur;
+    float* Pmat = (float*)((char*)workspace + align_up((n_cur + n_src) * 2 * sizeof(float), 256));
     ScopedStage prof_(kStCostVolume, st);
+    hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics, Pmat);
     if (hipMemsetAsync(d_curT, 0, (n_cur + n_src) * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(d_w3, 0, 32 * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(d_b3, 0, sizeof(float), st) != hipSuccess) {
@@ -587,13 +596,13 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
     hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_src), dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
     const int groups = (hw + 31) / 32;
     if (C == 48)
-        hipLaunchKernelGGL(cost_volume_bwd_kernel<24>, dim3(B * groups), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
-                           src_extrinsics, src_Ks, cur_invK, planes, (long long)plane_stride_b,
+        hipLaunchKernelGGL(cost_volume_bwd_kernel<24>, dim3(B * groups, cv_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
+                           Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
                            d_curT, d_srcT, DZ1, XP, DZ2, H1, d_w3, d_b3);
     else
-        hipLaunchKernelGGL(cost_volume_bwd_kernel<8>, dim3(B * groups), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
-                           src_extrinsics, src_Ks, cur_invK, planes, (long long)plane_stride_b,
+        hipLaunchKernelGGL(cost_volume_bwd_kernel<8>, dim3(B * groups, cv_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
+                           Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
                            d_curT, d_srcT, DZ1, XP, DZ2, H1, d_w3, d_b3);
     hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_cur), dim3(256), 0, st, d_curT, d_cur_feats, C, hw, B);
