@@ -1,0 +1,191 @@
+"""BASELINE.json config 1 ("2 views, 1 scene, 256x256, CPU-only ... plumbing") as an end-to-end chain of
+every hot-path stage in the order EncoderFreeSplat.forward / DecoderSplattingCUDA.forward call them
+(encoder_freesplat.py:216-427, decoder_splatting_cuda.py:35-75):
+
+  glue -> cost volume -> [depth head stand-in] -> unprojection -> PTF -> Gaussian head -> rasterizer
+
+* CPU test: the chain through the ORACLES only (no GPU) -- shapes, dtypes and hand-over contracts.
+* GPU test: the same chain through the PRODUCT modules (HIP kernels behind the reference's interfaces),
+  compared stage by stage and at the final image with the oracle chain.
+The CNN pieces between the stages (backbone, CV encoder, depth decoder, to_gaussians weights) are out of
+scope; deterministic torch stand-ins with fixed seeds feed both chains identically.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+H = W = 256
+V, D, C = 2, 16, 48
+NEAR, FAR = 0.5, 15.0
+
+
+def _inputs():
+    import inputs
+    g = torch.Generator().manual_seed(1234)
+    E, Kn = inputs.cameras(V, H, W, baseline=0.3, seed=5)
+    feats = torch.randn(V, C, H // 4, W // 4, generator=g)
+    latents = torch.randn(1, V, H * W, 64, generator=g)
+    dens = torch.sigmoid(torch.randn(1, V, H * W, 1, 1, generator=g))
+    wts = torch.sigmoid(torch.randn(1, V, H * W, 1, 1, generator=g))
+    lin = torch.nn.Linear(64, 36)
+    with torch.no_grad():
+        lin.weight.copy_(0.3 * torch.randn(36, 64, generator=g))
+        lin.bias.copy_(0.1 * torch.randn(36, generator=g))
+    tgt = inputs.cameras(2, H, W, baseline=0.2, seed=9)[0]
+    return dict(E=E, Kn=Kn, feats=feats, latents=latents, dens=dens, wts=wts, lin=lin, tgt=tgt)
+
+
+def _depth_from_cost_volume(cv: torch.Tensor, planes: torch.Tensor) -> torch.Tensor:
+    """Stand-in for CVEncoder + DepthDecoder (out of scope): softmax over the planes of the raw cost volume,
+    expected depth, bilinear x4.  Smooth in cv, so both chains see (almost) the same depth."""
+    p = torch.softmax(-cv * 0.0 + cv, dim=1)
+    depth = (p * planes.view(1, -1, 1, 1)).sum(1, keepdim=True)
+    depth = 1.5 + 0.05 * (depth - depth.mean())          # keep the scene in front of every camera
+    return torch.nn.functional.interpolate(depth, scale_factor=4, mode="bilinear", align_corners=True)
+
+
+def _oracle_chain(x):
+    from oracle import adapter_oracle as ao
+    from oracle import cost_volume_oracle as cvo
+    from oracle import ptf_oracle as po
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    from freesplat_amd.encoder_glue import prepare_cost_volume_inputs
+    from freesplat_amd.ptf import GRU
+    out = {}
+    torch.manual_seed(77)
+    cvm = AVGFeatureVolumeManager(H // 4, W // 4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    gru = GRU()
+    kw = prepare_cost_volume_inputs(x["E"][None], x["Kn"][None], x["feats"], torch.full((1, V), NEAR),
+                                    torch.full((1, V), FAR), (H, W), num_context_views=V)
+    sd = {k.replace(".", "__"): v for k, v in cvm.state_dict().items()}
+    cv = cvo.cost_volume(kw["cur_feats"], kw["src_feats"], kw["src_extrinsics"], kw["src_Ks"], kw["cur_invK"],
+                         kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
+    out["cv"] = cv
+    depth = _depth_from_cost_volume(cv, cvo.depth_planes(NEAR, FAR, D))
+    out["depth"] = depth
+    K0 = x["Kn"][0].clone(); K0[0] *= W; K0[1] *= H
+    k0 = torch.stack([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2]])
+    xyz = ao.unproject(depth.reshape(V, -1), x["E"], k0, H, W)
+    out["xyz"] = xyz
+    gp = {k: v.detach() for k, v in gru.state_dict().items()}
+    lat, X, Ex, Dp = po.fuse_gaussians(gp, x["latents"], xyz[None, :, :, None, None, :], x["dens"], x["wts"], depth,
+                                       x["E"][None], x["Kn"][None], (H, W))
+    out["ptf"] = (lat, X, Ex, Dp)
+    raw = x["lin"](torch.relu(lat[0])).detach()
+    mult = ao.scale_multiplier(x["Kn"][0], H, W)
+    mask = torch.tensor([1.0] + [0.025] * 3 + [0.00625] * 5)
+    cov, sh, _, _ = ao.gaussian_head(raw[:, 2:], Dp[0], Ex[0], mult, mask)
+    opac = torch.sigmoid(raw[:, 0])
+    out["gaussians"] = (X[0], cov, sh, opac)
+    out["state"] = dict(cvm=cvm.state_dict(), gru=gru.state_dict())
+    return out
+
+
+def _render_oracle(x, g):
+    from freesplat_amd.decoder import _frame
+    from oracle import raster_oracle as ro
+    means, cov, sh, opac = g
+    n = x["tgt"].shape[0]
+    extr, scale, tx, ty, view, full = _frame(x["tgt"], x["Kn"][:1].expand(n, 3, 3), torch.full((n,), NEAR),
+                                             torch.full((n,), FAR), True)
+    r, c = torch.triu_indices(3, 3)
+    imgs = []
+    for i in range(n):
+        s = scale[i]
+        st = ro.forward(H, W, float(tx[i]), float(ty[i]), np.zeros(3, np.float32), view[i].numpy(), full[i].numpy(), 2,
+                        extr[i, :3, 3].numpy(), (means * s).numpy(), (cov * s * s)[:, r, c].numpy(), opac.numpy(),
+                        shs=sh.transpose(-1, -2).contiguous().numpy())
+        imgs.append(st["color"])
+    return np.stack(imgs)
+
+
+def test_c1_plumbing_oracle_chain_cpu():
+    x = _inputs()
+    o = _oracle_chain(x)
+    assert o["cv"].shape == (V, D, H // 4, W // 4)
+    assert o["depth"].shape == (V, 1, H, W) and (o["depth"] > 0.2).all()
+    lat, X, Ex, Dp = o["ptf"]
+    M = lat.shape[1]
+    assert H * W <= M < V * H * W and X.shape == (1, M, 3) and Ex.shape == (1, M, 4, 4) and Dp.shape == (1, M)
+    means, cov, sh, opac = o["gaussians"]
+    assert cov.shape == (M, 3, 3) and sh.shape == (M, 3, 9) and opac.shape == (M,)
+    assert torch.allclose(cov, cov.transpose(1, 2), atol=1e-7)
+    img = _render_oracle(x, o["gaussians"])
+    assert img.shape == (2, 3, H, W) and np.isfinite(img).all() and img.max() > 0.05
+
+
+@pytest.mark.gpu
+def test_c1_pipeline_product_vs_oracle(hip_device):
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    from freesplat_amd.decoder import DecoderSplattingCUDA, Gaussians
+    from freesplat_amd.encoder_glue import prepare_cost_volume_inputs
+    from freesplat_amd.gaussian_adapter import GaussianAdapter, GaussianAdapterCfg
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    from oracle import cost_volume_oracle as cvo
+    x = _inputs()
+    o = _oracle_chain(x)
+    dev = hip_device
+    d = lambda t: t.to(dev)
+    with torch.no_grad():
+        cvm = AVGFeatureVolumeManager(H // 4, W // 4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+        cvm.load_state_dict(o["state"]["cvm"]); cvm = cvm.to(dev)
+        kw = prepare_cost_volume_inputs(d(x["E"])[None], d(x["Kn"])[None], d(x["feats"]), torch.full((1, V), NEAR, device=dev),
+                                        torch.full((1, V), FAR, device=dev), (H, W), num_context_views=V)
+        cv = cvm(**kw)
+        assert (cv.cpu() - o["cv"]).abs().max().item() <= 1e-4
+        depth = _depth_from_cost_volume(cv, d(cvo.depth_planes(NEAR, FAR, D)))
+        assert (depth.cpu() - o["depth"]).abs().max().item() <= 1e-5
+        ad = GaussianAdapter(GaussianAdapterCfg(0.5, 15.0, 2)).to(dev)
+        xyz = ad(d(x["E"])[None, :, None, None, None], d(x["Kn"])[None, :, None, None, None], None,
+                 depth.reshape(1, V, H * W, 1, 1), None, None, (H, W), fusion=True)
+        assert (xyz[0, :, :, 0, 0].cpu() - o["xyz"]).abs().max().item() <= 1e-5
+        ptf = PixelwiseTripletFusion(); ptf.gru.load_state_dict(o["state"]["gru"]); ptf = ptf.to(dev)
+        ad_args = (d(x["dens"]), d(x["wts"]))
+
+        def head_and_render(lat, X, Ex, Dp):
+            lin = x["lin"].to(dev)
+            raw = lin(torch.relu(lat))                                            # [1,M,36]
+            M = raw.shape[1]
+            g = ad(Ex.view(1, 1, M, 1, 1, 4, 4), d(x["Kn"])[0].view(1, 1, 1, 1, 1, 3, 3).expand(1, 1, M, 1, 1, 3, 3), None,
+                   Dp.view(1, 1, M, 1, 1), torch.sigmoid(raw[..., :1]).view(1, 1, M, 1, 1),
+                   raw[..., 2:].view(1, 1, M, 1, 1, 34), (H, W), fusion=False, coords=X.view(1, 1, M, 1, 1, 3))
+            gs = Gaussians(g.means.reshape(1, M, 3), g.covariances.reshape(1, M, 3, 3), g.harmonics.reshape(1, M, 3, 9),
+                           g.opacities.reshape(1, M))
+            dec = DecoderSplattingCUDA((0.0, 0.0, 0.0)).to(dev)
+            n = x["tgt"].shape[0]
+            out = dec(gs, d(x["tgt"])[None], d(x["Kn"][:1]).expand(n, 3, 3)[None], torch.full((1, n), NEAR, device=dev),
+                      torch.full((1, n), FAR, device=dev), (H, W), depth_mode="depth")
+            return g, out.color[0].cpu().numpy()
+
+        ref = _render_oracle(x, o["gaussians"])
+
+        def psnr(img):
+            mse = float(((img.clip(0, 1) - ref.clip(0, 1)) ** 2).mean())
+            return 99.0 if mse == 0 else -10 * np.log10(mse)
+
+        # (1) every stage on the ORACLE's upstream outputs: stage-wise parity without the chaos of discrete
+        #     matching decisions propagating (a 1e-6 depth change can flip a round-half pixel in PTF)
+        xyz_ref = d(o["xyz"])[None, :, :, None, None, :]
+        lat, X, Ex, Dp = ptf.fuse_gaussians([d(x["latents"])], [xyz_ref], *ad_args, d(o["depth"]), d(x["E"])[None],
+                                            d(x["Kn"])[None], (H, W))
+        for got, want, tol in zip((lat, X, Ex, Dp), o["ptf"], (1e-5, 1e-6, 1e-6, 1e-6)):
+            assert got.shape == want.shape and (got.cpu() - want).abs().max().item() <= tol
+        g, img = head_and_render(lat, X, Ex, Dp)
+        M = lat.shape[1]
+        assert (g.covariances.reshape(M, 3, 3).cpu() - o["gaussians"][1]).abs().max().item() <= 1e-8
+        assert (g.harmonics.reshape(M, 3, 9).cpu() - o["gaussians"][2]).abs().max().item() <= 1e-5
+        assert psnr(img) > 80.0 and np.median(np.abs(img - ref)) < 1e-6
+        # (2) free-running chain (product stages feed each other): same Gaussian count up to borderline
+        #     matches, image close to the oracle chain's
+        lat, X, Ex, Dp = ptf.fuse_gaussians([d(x["latents"])], [xyz], *ad_args, depth, d(x["E"])[None], d(x["Kn"])[None],
+                                            (H, W))
+        M_ref = o["ptf"][0].shape[1]
+        assert abs(lat.shape[1] - M_ref) <= max(2, M_ref // 1000)
+        _, img = head_and_render(lat, X, Ex, Dp)
+        assert psnr(img) > 30.0
