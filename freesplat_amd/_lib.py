@@ -25,6 +25,7 @@ class RasterDims(C.Structure):
 
 
 RASTER_TILE_CULL = 1
+RASTER_SH_FP16 = 2
 
 
 def build(force: bool = False) -> str:

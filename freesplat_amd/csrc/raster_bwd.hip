@@ -350,7 +350,17 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 const float dox = p.x - campos[0], doy = p.y - campos[1], doz = p.z - campos[2];
                 const float len = sqrtf(dox * dox + doy * doy + doz * doz);
                 const float x = dox / len, y = doy / len, z = doz / len;
-                const float* sh = shs + (size_t)i * per_sh;
+                float shbuf[48];
+                const float* sh = shbuf;
+                if (d.flags & FS_RASTER_SH_FP16) {
+                    const _Float16* hsrc = (const _Float16*)shs + (size_t)i * per_sh;
+#pragma unroll
+                    for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? (float)hsrc[k] : 0.0f;
+                } else {
+                    const float* fsrc = shs + (size_t)i * per_sh;
+#pragma unroll
+                    for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? fsrc[k] : 0.0f;
+                }
                 float gdv[3];
                 switch (d.sh_degree) {
                     case 0: sh_backward<0>(sh, x, y, z, gr, gsh, gdv); break;

@@ -176,6 +176,15 @@ __device__ __forceinline__ BinBox block_bin_box(int* s_box, bool valid, ushort4 
     return b;
 }
 
+// same for fp16-stored rows (FS_RASTER_SH_FP16: storage-only half precision, fp32 math)
+__device__ __forceinline__ void stage_rows_half(float* lds, const _Float16* __restrict__ src, size_t base, int cnt,
+                                                int per)
+{
+    const _Float16* s = src + base * per;
+    const int total = cnt * per;
+    for (int k = threadIdx.x; k < total; k += blockDim.x) lds[k] = (float)s[k];
+}
+
 __global__ __launch_bounds__(256) void preprocess_kernel(
     fs_raster_dims d, const float* __restrict__ means3D, const float* __restrict__ cov3D,
     const float* __restrict__ shs, const float* __restrict__ colors,
@@ -194,7 +203,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float* l_sh = lds;                                   // [256 * per_sh] (+pad to 4)
     float* l_cov = l_sh + ((256 * per_sh + 3) & ~3);     // [256 * 6]
     float* l_mean = l_cov + 256 * 6;                     // [256 * 3]
-    if (shs) stage_rows(l_sh, shs, base, cnt, per_sh);
+    if (shs) {
+        if (d.flags & FS_RASTER_SH_FP16) stage_rows_half(l_sh, (const _Float16*)shs, base, cnt, per_sh);
+        else stage_rows(l_sh, shs, base, cnt, per_sh);
+    }
     stage_rows(l_cov, cov3D, base, cnt, 6);
     stage_rows(l_mean, means3D, base, cnt, 3);
     __syncthreads();

@@ -176,7 +176,7 @@ class _RenderViews(torch.autograd.Function):
         s0 = GaussianRasterizationSettings(h, w, 0.0, 0.0, None, 1.0, None, None, degree, None, False, False)
 
         def launch(i, cap_i):
-            dims = R.make_dims(N, shs.shape[1], s0)
+            dims = R.make_dims(N, shs.shape[1], s0, sh_fp16=shs.dtype == torch.float16)
             rs, _, _, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i], fulls[i],
                                             campos[i], cap_i, tanfov=tanfov[i],
                                             scale=None if scale is None else scale[i],
@@ -228,7 +228,8 @@ class _RenderViews(torch.autograd.Function):
             gc = None if g_color is None else g_color[i]
             gd = None if g_depth is None else g_depth[i]
             out = R.rasterize_backward(rs, means, cov6, shs, None, gc, gd, out=out, accumulate=i > 0)
-        return (out["means3D"], out["cov3D"], out["shs"], out["opacities"]) + (None,) * 10
+        g_shs = out["shs"] if shs.dtype == torch.float32 else out["shs"].to(shs.dtype)
+        return (out["means3D"], out["cov3D"], g_shs, out["opacities"]) + (None,) * 10
 
 
 def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,

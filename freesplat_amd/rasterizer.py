@@ -130,22 +130,24 @@ def _launch_forward(dims: _lib.RasterDims, means3D, cov3D, shs, colors, opacitie
     return rs, color, depth, alpha
 
 
-def _f32c(t: Tensor, name: str) -> Tensor:
+def _f32c(t: Tensor, name: str, allow_half: bool = False) -> Tensor:
     if t.device.type != "cuda":
         raise RuntimeError(f"freesplat_amd rasterizer: `{name}` must live on a HIP device "
                            f"(got {t.device}); there is no CPU path")
+    if allow_half and t.dtype == torch.float16:
+        return t.contiguous()
     if t.dtype != torch.float32:
         raise RuntimeError(f"freesplat_amd rasterizer: `{name}` must be float32 (got {t.dtype})")
     return t.contiguous()
 
 
-def make_dims(N, M, settings: GaussianRasterizationSettings) -> _lib.RasterDims:
+def make_dims(N, M, settings: GaussianRasterizationSettings, sh_fp16: bool = False) -> _lib.RasterDims:
     d = _lib.RasterDims()
     d.N, d.M = int(N), int(M)
     d.H, d.W = int(settings.image_height), int(settings.image_width)
     d.sh_degree = int(settings.sh_degree)
     d.tanfovx, d.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
-    d.flags = _lib.RASTER_TILE_CULL if TILE_CULL else 0
+    d.flags = (_lib.RASTER_TILE_CULL if TILE_CULL else 0) | (_lib.RASTER_SH_FP16 if sh_fp16 else 0)
     return d
 
 
@@ -181,7 +183,7 @@ def rasterize_backward(rs: RasterState, means3D, cov3D, shs, colors, g_color, g_
             means3D=torch.empty(N, 3, dtype=torch.float32, device=dev),
             means2D=torch.empty(N, 3, dtype=torch.float32, device=dev),
             cov3D=torch.empty(N, 6, dtype=torch.float32, device=dev),
-            shs=None if shs is None else torch.empty_like(shs),
+            shs=None if shs is None else torch.empty(shs.shape, dtype=torch.float32, device=dev),
             colors=None if colors is None else torch.empty(N, 3, dtype=torch.float32, device=dev),
             opacities=torch.empty(N, dtype=torch.float32, device=dev),
         )
@@ -206,7 +208,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, settings):
         N = means3D.shape[0]
         M = 0 if shs is None else shs.shape[1]
-        dims = make_dims(N, M, settings)
+        dims = make_dims(N, M, settings, sh_fp16=shs is not None and shs.dtype == torch.float16)
         bg = _f32c(settings.bg, "bg")
         view = _f32c(settings.viewmatrix, "viewmatrix")
         proj = _f32c(settings.projmatrix, "projmatrix")
@@ -229,7 +231,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if g_color is None and g_depth is None:
             return (None,) * 7
         g = rasterize_backward(ctx.rs, means3D, cov3D, shs, colors, g_color, g_depth)
-        return g["means3D"], g["means2D"], g["shs"], g["colors"], g["opacities"], g["cov3D"], None
+        g_shs = g["shs"] if (shs is None or shs.dtype == torch.float32) else g["shs"].to(shs.dtype)
+        return g["means3D"], g["means2D"], g_shs, g["colors"], g["opacities"], g["cov3D"], None
 
 
 def build_cov3d(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
@@ -268,7 +271,7 @@ class GaussianRasterizer(nn.Module):
         cov3D = _f32c(cov3D_precomp, "cov3D_precomp").reshape(N, 6)
         opac = _f32c(opacities, "opacities").reshape(N)
         if shs is not None:
-            shs = _f32c(shs, "shs")
+            shs = _f32c(shs, "shs", allow_half=True)   # fp16 = storage-only SH (FS_RASTER_SH_FP16)
             if shs.dim() != 3 or shs.shape[0] != N or shs.shape[2] != 3:
                 raise RuntimeError(f"shs must be [N, M, 3], got {tuple(shs.shape)}")
             if (int(s.sh_degree) + 1) ** 2 > shs.shape[1] or int(s.sh_degree) > 3:

@@ -72,6 +72,9 @@ typedef struct fs_raster_dims {
  * with and without; without it the tile lists equal the reference's 3-sigma-square lists, with it
  * they are an order-preserving subsequence. */
 #define FS_RASTER_TILE_CULL 1
+/* `shs` holds IEEE half-precision values ([N,M,3] fp16, 94 instead of 148 input bytes per Gaussian at degree 2):
+ * storage only -- they are widened on load and all math stays fp32 (BASELINE config 5).  Gradients stay fp32. */
+#define FS_RASTER_SH_FP16 2
 
 /* Byte sizes of the four caller-owned device buffers for (N, H, W, instance capacity):
  *   out[0] geom    : per-Gaussian screen-space state            (saved for backward)

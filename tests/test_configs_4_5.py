@@ -1,0 +1,77 @@
+"""Parity cases for BASELINE.json configs 4 and 5 (the multi-view configs; sizes scaled so the oracles
+finish in seconds): 10 context views with the 9 pose-nearest as cost-volume sources (K = 8) and a 10-view
+PTF fold; a 30-view long-sequence fold; fp16-stored SH coefficients in the rasterizer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_cost_volume_10_views_9_nearest(hip_device):
+    import inputs
+    from oracle import cost_volume_oracle as cvo
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    from freesplat_amd.encoder_glue import prepare_cost_volume_inputs
+    V, h4, w4, D, C = 10, 24, 32, 16, 48
+    E, Kn = inputs.cameras(V, h4, w4, baseline=1.2, seed=11)
+    feats = torch.randn(V, C, h4, w4, generator=torch.Generator().manual_seed(2))
+    kw = prepare_cost_volume_inputs(E[None], Kn[None], feats, torch.full((1, V), 0.5), torch.full((1, V), 15.0),
+                                    (4 * h4, 4 * w4), num_context_views=9)
+    assert kw["src_feats"].shape == (V, 8, C, h4, w4)
+    torch.manual_seed(3)
+    m = AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    sd = {k.replace(".", "__"): v for k, v in m.state_dict().items()}
+    ref = cvo.cost_volume(kw["cur_feats"], kw["src_feats"], kw["src_extrinsics"], kw["src_Ks"], kw["cur_invK"],
+                          kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
+    with torch.no_grad():
+        out = m.to(hip_device)(**{k: v.to(hip_device) for k, v in kw.items()}).cpu()
+    err = (out - ref).abs()
+    assert int((err > 1e-4).sum()) <= 2 and float(err.median()) < 1e-5   # (validity flips at image borders aside)
+
+
+@pytest.mark.parametrize("V,h,w", [(10, 48, 64), (30, 24, 32)])
+def test_config4_5_long_sequence_fold(hip_device, V, h, w):
+    from oracle import ptf_oracle as po
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    from test_ptf_hip import _scene
+    E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=80 + V)
+    torch.manual_seed(4)
+    m = PixelwiseTripletFusion()
+    params = {k: v.detach().clone() for k, v in m.gru.state_dict().items()}
+    ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w))
+    m = m.to(hip_device)
+    d = lambda t: t.to(hip_device)
+    with torch.no_grad():
+        out = m.fuse_gaussians([d(lat)], [d(coords)], d(dens), d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))
+    assert out[0].shape == ref[0].shape and out[0].shape[1] < V * h * w // 2   # sub-linear growth
+    for a, b, name in zip(out, ref, ("latent", "xyz", "extrinsics", "depths")):
+        assert (a.cpu() - b.detach()).abs().max().item() <= 1e-4, name
+
+
+def test_config5_fp16_sh_storage(hip_device):
+    """fp16 SH = storage only: the image equals the fp32 path fed the fp16-rounded coefficients bit for bit,
+    and the gradients agree."""
+    from util_raster import hip_forward, small_scene, view_inputs
+    H, W = 64, 80
+    scene, cams = small_scene(N=1500, H=H, W=W, seed=12)
+    vi = view_inputs(scene, cams, 0, H, W, bg=(0.1, 0.2, 0.3))
+    vi32 = dict(vi); vi32["shs"] = vi["shs"].half().float()
+    vi16 = dict(vi); vi16["shs"] = vi["shs"].half()
+    (c32, _, d32, _), l32 = hip_forward(vi32, hip_device, requires_grad=True)
+    (c16, _, d16, _), l16 = hip_forward(vi16, hip_device, requires_grad=True)
+    assert torch.equal(c32, c16) and torch.equal(d32, d16)
+    w = torch.randn_like(c32)
+    (c32 * w).sum().backward()
+    (c16 * w).sum().backward()
+    assert l16["shs"].grad.dtype == torch.float16
+    for k in ("means3D", "cov3D", "opacities"):
+        s = l32[k].grad.abs().max().item()
+        assert (l32[k].grad - l16[k].grad).abs().max().item() <= 2e-4 * s, k
+    s = l32["shs"].grad.abs().max().item()
+    assert (l32["shs"].grad - l16["shs"].grad.float()).abs().max().item() <= 2e-3 * s   # fp16 rounding of the grad
