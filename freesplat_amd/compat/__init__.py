@@ -1,4 +1,10 @@
-"""Import-compatibility for an unmodified FreeSplat tree."""
+"""Import-compatibility for an unmodified FreeSplat tree.
+
+    import freesplat_amd.compat as compat
+    compat.install()            # before `import src.main`: provides `diff_gaussian_rasterization_depth`
+    compat.patch_reference()    # after `src` is importable: swaps the hot-path classes for the HIP ones
+"""
+import importlib
 import sys
 
 
@@ -7,3 +13,36 @@ def install() -> None:
     src/model/decoder/cuda_splatting.py:5) as an alias of freesplat_amd.rasterizer."""
     from . import diff_gaussian_rasterization_depth as m
     sys.modules.setdefault("diff_gaussian_rasterization_depth", m)
+
+
+def patch_reference(decoder: bool = True) -> dict:
+    """Rebind, inside the already importable reference package `src`, every name on the hot path to its
+    MI355X implementation (same constructor / call signatures and state-dict keys, so configs and
+    checkpoints are untouched):
+      src.model.encoder.modules.cost_volume.AVGFeatureVolumeManager   (cost_volume.py:384)
+      src.model.encoder.encoder_freesplat.{AVGFeatureVolumeManager, GaussianAdapter, GRU}
+      src.model.encoder.encoder_freesplat.EncoderFreeSplat.fuse_gaussians       (:431)
+      src.model.decoder.DECODERS["splatting_cuda"]                              (decoder/__init__.py:5-13)
+    Returns {dotted name: replacement} for logging."""
+    from .. import cost_volume, gaussian_adapter, ptf
+    from ..decoder import DecoderSplattingCUDA
+    done = {}
+    cvm = importlib.import_module("src.model.encoder.modules.cost_volume")
+    cvm.AVGFeatureVolumeManager = cost_volume.AVGFeatureVolumeManager
+    done["src.model.encoder.modules.cost_volume.AVGFeatureVolumeManager"] = cost_volume.AVGFeatureVolumeManager
+    enc = importlib.import_module("src.model.encoder.encoder_freesplat")
+    enc.AVGFeatureVolumeManager = cost_volume.AVGFeatureVolumeManager
+    enc.GaussianAdapter = gaussian_adapter.GaussianAdapter
+    enc.GRU = ptf.GRU
+    enc.EncoderFreeSplat.fuse_gaussians = ptf.fuse_gaussians
+    for n in ("AVGFeatureVolumeManager", "GaussianAdapter", "GRU"):
+        done[f"src.model.encoder.encoder_freesplat.{n}"] = getattr(enc, n)
+    done["src.model.encoder.encoder_freesplat.EncoderFreeSplat.fuse_gaussians"] = ptf.fuse_gaussians
+    if decoder:
+        try:
+            dec = importlib.import_module("src.model.decoder")
+            dec.DECODERS["splatting_cuda"] = lambda cfg, dataset_cfg: DecoderSplattingCUDA(dataset_cfg.background_color)
+            done['src.model.decoder.DECODERS["splatting_cuda"]'] = DecoderSplattingCUDA
+        except Exception as e:  # the decoder package drags in the dataset package; report, don't hide
+            done["src.model.decoder (not patched)"] = repr(e)
+    return done
