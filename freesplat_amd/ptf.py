@@ -82,10 +82,58 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
     return keep[:nk], fuse[:nf], fpix[:nf], app[:na]
 
 
+_table_cache: dict = {}
+
+
+def gru_tables(gru: "GRU") -> Tensor:
+    """The GRU's weights and biases in the MFMA operand order of csrc/ptf_gru.hip: rows of 64 lanes,
+    lane l = (p = l & 31, hf = l >> 5).  Cached per parameter version."""
+    params = [gru.mlp_r[0].weight, gru.mlp_r[0].bias, gru.mlp_r[2].weight, gru.mlp_r[2].bias,
+              gru.mlp_z[0].weight, gru.mlp_z[0].bias, gru.mlp_z[2].weight, gru.mlp_z[2].bias,
+              gru.mlp_n[0].weight, gru.mlp_n[0].bias, gru.mlp_n[2].weight, gru.mlp_n[2].bias]
+    key = (id(gru), tuple((q.data_ptr(), q._version) for q in params))
+    hit = _table_cache.get(id(gru))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    dev = params[0].device
+    with torch.no_grad():
+        Wr1, br1, Wr2, br2, Wz1, bz1, Wz2, bz2, Wn1, bn1, Wn2, bn2 = [q.detach().float() for q in params]
+        lane = torch.arange(64, device=dev)
+        pp, hf = lane & 31, lane >> 5
+        acc_row = lambda q, h: (q & 3) + 8 * (q >> 2) + 4 * h
+        unit = lambda s: acc_row(s[:, None] & 15, hf[None, :]) + 32 * (s[:, None] >> 4)      # [steps, 64]
+
+        def l1(W):   # [64,176]: step s <-> input s + 88*hf
+            s = torch.arange(88, device=dev)
+            col = s[:, None] + 88 * hf[None, :]
+            return torch.stack([W[32 * b + pp[None, :].expand_as(col), col] for b in range(2)])
+
+        def l2(W):   # [64,64]: step s <-> hidden unit of accumulator register s & 15, block s >> 4
+            col = unit(torch.arange(32, device=dev))
+            return torch.stack([W[32 * b + pp[None, :].expand_as(col), col] for b in range(2)])
+
+        def n1(W):   # [64,152]: steps 0..31 <-> r*hid units, 32..75 <-> x|xe input 64 + (s-32) + 44*hf
+            s = torch.arange(44, device=dev)
+            col = torch.cat([unit(torch.arange(32, device=dev)), 64 + s[:, None] + 44 * hf[None, :]])
+            return torch.stack([W[32 * b + pp[None, :].expand_as(col), col] for b in range(2)])
+
+        def bias(bv):  # [64] -> [2,16,64]
+            q = torch.arange(16, device=dev)
+            return torch.stack([bv[acc_row(q[:, None], hf[None, :]) + 32 * b] for b in range(2)])
+
+        tab = torch.cat([t.reshape(-1, 64) for t in (l1(Wr1), l1(Wz1), l2(Wr2), l2(Wz2), n1(Wn1), l2(Wn2),
+                                                     bias(br1), bias(bz1), bias(br2), bias(bz2), bias(bn1),
+                                                     bias(bn2))]).contiguous()
+    assert tab.shape[0] == _lib.lib().fs_ptf_gru_table_rows()
+    _table_cache[id(gru)] = (key, tab)
+    return tab
+
+
 def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
                           depth_thres):
-    """Inference path (no autograd): per view fs_ptf_match -> fs_ptf_gru_inputs -> 6 GEMMs (rocBLAS) ->
-    fs_ptf_write_state.  Same results and order as the differentiable path below."""
+    """Inference path (no autograd): per view fs_ptf_match -> fs_ptf_gru_inputs -> fs_ptf_gru_forward (GRU
+    on the fp32 matrix cores) -> fs_ptf_write_state: HIP kernels only.  Same results and order as the
+    differentiable path below."""
     L = _lib.lib()
     p = _lib.ptr
     h, w = image_shape
@@ -114,11 +162,9 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
             cat = torch.empty(nf, 176, device=dev)
             _lib.check(L.fs_ptf_gru_inputs(nf, p(fuse), p(fpix), p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]),
                                            p(cat), _lib.current_stream()), "fs_ptf_gru_inputs")
-            hid = cat[:, :64]
-            r = torch.sigmoid(gru.mlp_r(cat))
-            z = torch.sigmoid(gru.mlp_z(cat))
-            q = torch.tanh(gru.mlp_n(torch.cat((r * hid, cat[:, 88:]), dim=-1)))
-            fused = ((1 - z) * hid + z * q).contiguous()
+            fused = torch.empty(nf, 64, device=dev)
+            _lib.check(L.fs_ptf_gru_forward(nf, p(cat), p(gru_tables(gru)), p(fused), _lib.current_stream()),
+                       "fs_ptf_gru_forward")
         n_out = nk + nf + na
         nG, nX = torch.empty(n_out, 64, device=dev), torch.empty(n_out, 3, device=dev)
         nR, nO, nD = (torch.empty(n_out, device=dev) for _ in range(3))

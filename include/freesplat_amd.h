@@ -213,6 +213,13 @@ int fs_ptf_write_state(int32_t n_keep, int32_t n_fuse, int32_t n_app, const int6
                        const float* om_i, const float* d_i, const float* E_i, const float* fused, float* oG,
                        float* oX, float* oR, float* oO, float* oE, float* oD, void* stream);
 
+/* The GRU of the fold step on the fp32 matrix cores (networks.py:188-214): cat[n,176] rows from
+ * fs_ptf_gru_inputs -> fused[n,64].  `tables` = the six weight matrices and biases pre-arranged in MFMA
+ * operand order, fs_ptf_gru_table_rows() rows of 64 floats (layout: csrc/ptf_gru.hip; builder:
+ * freesplat_amd/ptf.py:gru_tables). */
+int32_t fs_ptf_gru_table_rows(void);
+int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, float* fused, void* stream);
+
 /* ------------------------------------------------------------------------------------ *
  * Gaussian adapter steps either side of PTF                                             *
  * ------------------------------------------------------------------------------------ */
