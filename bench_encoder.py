@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Secondary benchmark (not the headline metric): the encoder-side rows of SURVEY.md section 8 --
-plane-sweep cost volume and one PTF fold -- on the shipped native shapes, with the reference-pinned
+plane-sweep cost volume, one PTF fold and the depth-regression tail -- on the shipped native shapes, with the reference-pinned
 CPU oracles timed beside them.  Prints one JSON line per workload.
 
   python bench_encoder.py [--steps 20 --warmup 3]
@@ -108,6 +108,46 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512):
             "parity": {"max_abs_err_vs_oracle": err, "same_count": bool(out[0].shape == ref[0].shape)}}
 
 
+def bench_depth_tail(dev, steps, warmup, V=2, D=128, h2=192, w2=256):
+    """Regression tail of the finest DepthDecoder scale (networks.py:130-152), forward and forward+backward,
+    against the same op chain in torch on this GPU (rocm eager) and on the host (the oracle)."""
+    from freesplat_amd.depth_tail import depth_regression_tail
+    from oracle.depth_tail_oracle import depth_tail
+    g = torch.Generator().manual_seed(2)
+    logits = 3.0 * torch.randn(V, D, h2, w2, generator=g)
+    cand = torch.log(torch.tensor(0.5)) + torch.linspace(0, 1, D) * torch.log(torch.tensor(30.0))
+    lg, cd = logits.to(dev).requires_grad_(True), cand.to(dev)
+
+    def both(fn):
+        o = fn(lg, cd, True)
+        (o["depth_map"].sum() + o["depth_weights"].sum() + o["depth"].sum()).backward()
+        lg.grad = None
+
+    with torch.no_grad():
+        dt = timed(lambda: depth_regression_tail(lg, cd, True), steps, warmup)
+        dt_eager = timed(lambda: depth_tail(lg, cd, True), steps, warmup)
+    dt_fb = timed(lambda: both(depth_regression_tail), steps, warmup)
+    dt_fb_eager = timed(lambda: both(depth_tail), steps, warmup)
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        got = depth_regression_tail(lg, cd, True)
+        t0 = time.perf_counter()
+        ref = depth_tail(logits, cand, True)
+        t_cpu = time.perf_counter() - t0
+    torch.set_num_threads(8)
+    err = max(float((got[k].cpu() - ref[k]).abs().max()) for k in ref)
+    nbytes = logits.numel() * 4 + 2 * V * 4 * h2 * w2 * 4       # read the logits once, write the two x2 maps
+    return {"metric": f"depth-regression tails/sec, {V} views x {D} planes @ {h2}x{w2}", "value": V / dt, "unit": "views/s",
+            "ms_per_call": dt * 1e3, "ms_fwd_bwd": dt_fb * 1e3, "torch_eager_ms": dt_eager * 1e3,
+            "torch_eager_fwd_bwd_ms": dt_fb_eager * 1e3, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "depth_tail_native", "views": V, "planes": D},
+            "roofline": {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": nbytes / dt / 8e12, "traffic": None, "note": "wall clock per call, 2 kernels"},
+            "cpu_baseline": {"value": V / t_cpu, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                             "sample": "1 call of oracle/depth_tail_oracle.py (torch CPU)"},
+            "parity": {"max_abs_err_vs_oracle": err}}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -118,3 +158,4 @@ if __name__ == "__main__":
     print(json.dumps(bench_cost_volume(dev, a.steps, a.warmup, V=3, K=2, h4=242, w4=324)), flush=True)
     print(json.dumps(bench_ptf(dev, a.steps, a.warmup)), flush=True)
     print(json.dumps(bench_ptf(dev, max(2, a.steps // 4), 1, V=10)), flush=True)
+    print(json.dumps(bench_depth_tail(dev, a.steps, a.warmup)), flush=True)

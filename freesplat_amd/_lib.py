@@ -64,6 +64,8 @@ SIGNATURES = {
     "fs_ptf_write_state": (C.c_int, [C.c_int32] * 3 + [_VP] * 24),
     "fs_ptf_gru_table_rows": (C.c_int32, []),
     "fs_ptf_gru_forward": (C.c_int, [C.c_int32] + [_VP] * 4),
+    "fs_depth_tail_forward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 7),
+    "fs_depth_tail_backward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 13),
     "fs_raster_tile_ranges": (_VP, [_VP, C.c_int32, C.c_int32]),
     "fs_raster_point_list": (_VP, [_VP, C.c_int32, C.c_int32]),
     "fs_raster_geom_records": (_VP, [_VP]),

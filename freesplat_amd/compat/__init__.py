@@ -22,9 +22,10 @@ def patch_reference(decoder: bool = True) -> dict:
       src.model.encoder.modules.cost_volume.AVGFeatureVolumeManager   (cost_volume.py:384)
       src.model.encoder.encoder_freesplat.{AVGFeatureVolumeManager, GaussianAdapter, GRU}
       src.model.encoder.encoder_freesplat.EncoderFreeSplat.fuse_gaussians       (:431)
+      src.model.encoder.modules.networks.DepthDecoder.forward                   (networks.py:108-154)
       src.model.decoder.DECODERS["splatting_cuda"]                              (decoder/__init__.py:5-13)
     Returns {dotted name: replacement} for logging."""
-    from .. import cost_volume, gaussian_adapter, ptf
+    from .. import cost_volume, depth_tail, gaussian_adapter, ptf
     from ..decoder import DecoderSplattingCUDA
     done = {}
     cvm = importlib.import_module("src.model.encoder.modules.cost_volume")
@@ -38,6 +39,9 @@ def patch_reference(decoder: bool = True) -> dict:
     for n in ("AVGFeatureVolumeManager", "GaussianAdapter", "GRU"):
         done[f"src.model.encoder.encoder_freesplat.{n}"] = getattr(enc, n)
     done["src.model.encoder.encoder_freesplat.EncoderFreeSplat.fuse_gaussians"] = ptf.fuse_gaussians
+    net = importlib.import_module("src.model.encoder.modules.networks")
+    net.DepthDecoder.forward = depth_tail.depth_decoder_forward
+    done["src.model.encoder.modules.networks.DepthDecoder.forward"] = depth_tail.depth_decoder_forward
     if decoder:
         try:
             dec = importlib.import_module("src.model.decoder")

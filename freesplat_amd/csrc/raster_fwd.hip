@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint32_t* _
 // and walks only the survivors (s_ff1 over the ballot): entries that cannot touch the quadrant
 // cost 1/64 of a VALU test instead of a full per-pixel evaluation.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void render_kernel(
+__global__ __launch_bounds__(256) void render_kernel_v1(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
     const float* __restrict__ bg, const uint32_t* __restrict__ counters,
@@ -762,6 +762,197 @@ __global__ __launch_bounds__(256) void render_kernel(
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+
+// fs_exp() of two arguments in [-80, 0], bit-identical to the scalar form: rint(m) = (m + 1.5*2^23) - 1.5*2^23
+// for |m| < 2^22, and the low bits of the biased sum are the integer for the exponent (ldexpf == integer add on
+// the exponent field while the result stays normal).  Arguments outside the range give garbage, never a trap.
+__device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
+{
+    const f32x2 magic = splat2(12582912.0f);
+    const f32x2 t = x * splat2(1.44269504088896341f) + magic;
+    const f32x2 n = t - magic;
+    f32x2 r = fma2(n, splat2(-0.693145751953125f), x);
+    r = fma2(n, splat2(-1.42860676533018e-6f), r);
+    f32x2 q = fma2(r, splat2(1.0f / 720.0f), splat2(1.0f / 120.0f));
+    q = fma2(r, q, splat2(1.0f / 24.0f));
+    q = fma2(r, q, splat2(1.0f / 6.0f));
+    q = fma2(r, q, splat2(0.5f));
+    q = fma2(r, q, splat2(1.0f));
+    q = fma2(r, q, splat2(1.0f));
+    const i32x2 e = __builtin_bit_cast(i32x2, q) + (__builtin_bit_cast(i32x2, t) << 23);
+    return __builtin_bit_cast(f32x2, e);
+}
+
+// Blend loop, second form.  Each wavefront owns one 8x8 quadrant of the tile and is fully independent of the
+// other three (no workgroup barrier anywhere):
+//   * it walks the tile's sorted list 64 entries at a time, reading the 32-bit list words itself (two batches
+//     ahead) and the 48-byte records of the entries whose quadrant bit is set (one batch ahead), so the global
+//     latency of batch i+1 / i+2 is covered by the blending of batch i;
+//   * the survivors of a batch are COMPACTED into a wavefront-private LDS area, two per slot with their fields
+//     interleaved ([x_a x_b y_a y_b] ...), so that the walk reads register PAIRS straight from LDS
+//     (6 ds_read_b128 per two survivors, the next slot prefetched) and the exponent, the exp and alpha of both
+//     run on packed fp32 (v_pk_{add,mul,fma}_f32): ~50 VALU per two survivors instead of ~90 in render_kernel_v1.
+// Arithmetic per pixel is the same sequence of IEEE operations as v1 / the oracle => same bits.
+constexpr int kPairQuads = 6;  // float4 per slot of two survivors
+#ifdef FS_RENDER_TRACE
+__device__ unsigned long long g_render_trace[4 * 8192];
+#endif
+__global__ __launch_bounds__(256) void render_kernel(
+    int H, int W, int T, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+    const float* __restrict__ bg, const uint32_t* __restrict__ counters,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, int32_t* __restrict__ n_contrib)
+{
+    __shared__ float4 s_pair[4][33 * kPairQuads];  // (+1 slot: the prefetch of "the next slot" may run one past)
+    if (counters[1]) return;
+    const int chunk = (T + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+    const int gx = (W + kTile - 1) / kTile;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const f32x2 pfx = splat2((float)px), pfy = splat2((float)py);
+    const uint32_t qbit = 1u << wave;
+    float4* const cp = s_pair[wave];
+
+    const uint32_t a = offsets[tile];
+    const int n = (int)(offsets[tile + 1] - a);
+    const uint32_t* const pl = point_list + a;
+#ifdef FS_RENDER_TRACE
+    const unsigned long long t_begin = wall_clock64();
+#endif
+
+    float T_ = 1.0f;
+    f32x2 C01 = splat2(0.0f), C2D = splat2(0.0f);
+    int last = 0;
+    bool done = !inside;
+
+    // software pipeline: list words two batches ahead, records one batch ahead
+    uint32_t w_cur = lane < n ? pl[lane] : 0u;
+    uint32_t w_nxt = 64 + lane < n ? pl[64 + lane] : 0u;
+    float4 r0 = {}, r1 = {}, r2 = {};
+    if (w_cur & qbit) {
+        const float4* q = rec + 3 * (size_t)(w_cur >> 4);
+        r0 = q[0]; r1 = q[1]; r2 = q[2];
+    }
+    for (int c = 0; c < n; c += 64) {
+        if (__all(done)) break;  // wave-uniform
+        const bool hit = (w_cur & qbit) != 0;
+        const unsigned long long hits = __ballot(hit);
+        const float4 a0 = r0, a1 = r1, a2 = r2;
+        w_cur = w_nxt;
+        if (w_cur & qbit) {
+            const float4* q = rec + 3 * (size_t)(w_cur >> 4);
+            r0 = q[0]; r1 = q[1]; r2 = q[2];
+        }
+        w_nxt = c + 128 + lane < n ? pl[c + 128 + lane] : 0u;
+        if (!hits) continue;
+        const int cnt = __popcll(hits);
+        if (hit) {
+            const int k = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0));
+            float* d = (float*)(cp + (k >> 1) * kPairQuads) + (k & 1);
+            d[0] = a0.x; d[2] = a0.y;                   // [x_a x_b y_a y_b]
+            d[4] = a0.z; d[6] = a0.w;                   // [A_a A_b C_a C_b]   (A = -a/2, C = -c/2)
+            d[8] = a1.x; d[10] = a1.z;                  // [B_a B_b thr_a thr_b] (B = -b)
+            d[12] = a1.y; d[14] = __int_as_float(c + lane + 1);  // [op_a op_b pos_a pos_b]
+            cp[(k >> 1) * kPairQuads + 4 + (k & 1)] = make_float4(a2.x, a2.y, a2.z, a1.w);  // [r g b depth]
+            // odd count: the unused half of the last slot gets weight 0; its colour must still be finite
+            if (k == cnt - 1) {
+                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const int s = k >> 1;
+                if (!(k & 1)) cp[s * kPairQuads + 5] = z;
+                if (!(s & 1)) { cp[(s + 1) * kPairQuads + 4] = z; cp[(s + 1) * kPairQuads + 5] = z; }  // unused second slot of the step
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // Two slots (four survivors) per step: the two packed exponent/exp chains are independent, so the
+        // scheduler interleaves them (no dependent-issue bubbles); the blend itself stays strictly in list order.
+        const int nslots = (cnt + 1) >> 1;
+#define FS_BLEND_ONE(COND, AL, OM, KR, POS)                                                         \
+        {                                                                                           \
+            const float test_T = T_ * (OM);                                                         \
+            const bool vis = (COND) & !done & ((AL) >= 1.0f / 255.0f);                              \
+            const bool ok = vis & (test_T >= 0.0001f);                                              \
+            done = done | (vis ^ ok);                                                               \
+            const f32x2 wgt = splat2(ok ? (AL) * T_ : 0.0f); /* weight 0: sums unchanged (finite colours) */ \
+            C01 = fma2((f32x2){(KR).x, (KR).y}, wgt, C01);                                          \
+            C2D = fma2((f32x2){(KR).z, (KR).w}, wgt, C2D);                                          \
+            T_ = ok ? test_T : T_;                                                                  \
+            last = ok ? __float_as_int(POS) : last;                                                 \
+        }
+        for (int p = 0; p < nslots; p += 2) {
+            const float4* q = cp + p * kPairQuads;
+            const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+            const float4 e0 = q[6], e1 = q[7], e2 = q[8], e3 = q[9];
+            const bool has_b = 2 * p + 1 < cnt, has_c = 2 * p + 2 < cnt, has_d = 2 * p + 3 < cnt;
+            const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
+            const f32x2 ex = (f32x2){e0.x, e0.y} - pfx, ey = (f32x2){e0.z, e0.w} - pfy;
+            const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx,
+                                  fma2((f32x2){c1.z, c1.w} * dy, dy, ((f32x2){c2.x, c2.y} * dx) * dy));
+            const f32x2 pv = fma2((f32x2){e1.x, e1.y} * ex, ex,
+                                  fma2((f32x2){e1.z, e1.w} * ey, ey, ((f32x2){e2.x, e2.y} * ex) * ey));
+            const bool ca = (pw.x <= 0.0f) & (pw.x >= c2.z);
+            const bool cb = has_b & (pw.y <= 0.0f) & (pw.y >= c2.w);
+            const bool cc = has_c & (pv.x <= 0.0f) & (pv.x >= e2.z);
+            const bool cd = has_d & (pv.y <= 0.0f) & (pv.y >= e2.w);
+            if (__builtin_amdgcn_ballot_w64(((ca | cb) | (cc | cd)) & !done) == 0) continue;  // wave-uniform
+            const float4 ka = q[4], kb = q[5], kc = q[10], kd = q[11];
+            const f32x2 ew = fs_exp2_nonpos(pw), ev = fs_exp2_nonpos(pv);
+            const f32x2 ow = (f32x2){c3.x, c3.y} * ew, ov = (f32x2){e3.x, e3.y} * ev;
+            const f32x2 aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
+            const f32x2 av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
+            const f32x2 mw = splat2(1.0f) - aw, mv = splat2(1.0f) - av;
+            FS_BLEND_ONE(ca, aw.x, mw.x, ka, c3.z)
+            FS_BLEND_ONE(cb, aw.y, mw.y, kb, c3.w)
+            FS_BLEND_ONE(cc, av.x, mv.x, kc, e3.z)
+            FS_BLEND_ONE(cd, av.y, mv.y, kd, e3.w)
+        }
+#undef FS_BLEND_ONE
+        // (the next batch's compaction overwrites the slots: DS operations of one wavefront execute in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        final_T[pix] = T_;
+        n_contrib[pix] = last;
+        out_color[pix] = fmaf(T_, bg[0], C01.x);
+        out_color[HW + pix] = fmaf(T_, bg[1], C01.y);
+        out_color[2 * HW + pix] = fmaf(T_, bg[2], C2D.x);
+        out_depth[pix] = C2D.y;
+        out_alpha[pix] = 1.0f - T_;
+    }
+#ifdef FS_RENDER_TRACE
+    if (lane == 0 && tile < 8192) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (wave == 0) { g_render_trace[4 * tile] = t_begin; g_render_trace[4 * tile + 2] = ((unsigned long long)n << 32) | hwid; }
+        const unsigned long long t_end = wall_clock64();
+        atomicMax(&g_render_trace[4 * tile + 1], t_end);
+        atomicMax(&g_render_trace[4 * tile + 3], ~t_end);
+    }
+#endif
+}
+#ifdef FS_RENDER_TRACE
+}
+extern "C" __attribute__((visibility("default"))) int fs_debug_render_trace(unsigned long long* dst, int reset)
+{
+    if (reset) { static unsigned long long z[4 * 8192]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(fs::g_render_trace), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fs::g_render_trace), sizeof(unsigned long long) * 4 * 8192);
+}
+namespace fs {
+#endif
+
 }  // namespace fs
 
 // ============================================================================================
@@ -868,8 +1059,9 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     FS_CHECK_LAUNCH("tile_sort");
     {
         ScopedStage prof_(kStRender, st);
-        hipLaunchKernelGGL(render_kernel, dim3(8 * chunk), dim3(256), 0, st, d.H, d.W, T, offsets,
-                           point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T,
+        static const bool v1 = [] { const char* e = getenv("FREESPLAT_RENDER_V1"); return e && e[0] == '1'; }();
+        hipLaunchKernelGGL(v1 ? render_kernel_v1 : render_kernel, dim3(8 * chunk), dim3(256), 0, st, d.H, d.W, T,
+                           offsets, point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T,
                            n_contrib);
     }
     FS_CHECK_LAUNCH("render");

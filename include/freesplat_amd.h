@@ -250,6 +250,27 @@ int fs_gaussian_head_backward(int64_t M, const float* raw, const float* depths, 
                               const float* g_scales, const float* g_rotations, float* g_raw, float* g_depths,
                               float* g_extrinsics, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * Depth-regression tail of the DepthDecoder (networks.py:130-152)                       *
+ * ------------------------------------------------------------------------------------ */
+
+/* logits[B,D,h2,w2], candidates[D] -> stats[B,2,h2*w2] (softmax max / sum, saved for backward),
+ * coarse[B,h2*w2] = sum_d cand_d softmax(logits)_d, depth = exp(coarse) (log_planes) | 1/coarse, and, when
+ * depth_map / depth_weights / argmax are non-NULL (all three together), at [B,2h2,2w2]:
+ * depth_map = exp | 1/ of the x2 align_corners bilinear of coarse, depth_weights = max_d of the
+ * x2-upsampled probabilities, argmax = that plane (saved for backward). */
+int fs_depth_tail_forward(int32_t B, int32_t D, int32_t h2, int32_t w2, const float* logits,
+                          const float* candidates, int32_t log_planes, float* stats, float* coarse,
+                          float* depth, float* depth_map, float* depth_weights, int32_t* argmax, void* stream);
+/* g_coarse / g_depth [B,h2*w2], g_map / g_weights [B,2h2,2w2] (each may be NULL) -> g_logits[B,D,h2,w2].
+ * scratch_gE [B,h2*w2] is needed with g_map or g_weights, scratch_gprob [B,D,h2*w2] with g_weights. */
+int fs_depth_tail_backward(int32_t B, int32_t D, int32_t h2, int32_t w2, const float* logits,
+                           const float* candidates, int32_t log_planes, const float* stats,
+                           const float* coarse, const float* depth, const float* depth_map,
+                           const int32_t* argmax, const float* g_coarse, const float* g_depth,
+                           const float* g_map, const float* g_weights, float* scratch_gE,
+                           float* scratch_gprob, float* g_logits, void* stream);
+
 /* Debug/test accessors into the opaque buffers (device pointers, no copies). */
 const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t H, int32_t W);  /* [T+1] offsets */
 const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] (id << 4) | 8x8-quadrant mask */

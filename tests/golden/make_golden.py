@@ -13,6 +13,7 @@ Fixtures (fp32, torch.manual_seed, sizes per SURVEY.md 8(c)):
   cv_native_stat.json                  96x128, D=128 summary statistics + SHA-256 of the output
   ptf_small.npz / ptf_tie.npz          EncoderFreeSplat.fuse_gaussians (encoder_freesplat.py:431-522)
   adapter_small.npz                    GaussianAdapter.forward fusion=True / False (gaussian_adapter.py:135-201)
+  depth_tail_{log,inv}.npz             DepthDecoder tail (networks.py:130-152) on the real module's logits
   glue_small.npz                       calculate_distance_matrix (encoder_freesplat.py:50-60)
   framing.npz                          get_fov / get_projection_matrix + render_cuda's matrices
                                        (projection.py:233-247, cuda_splatting.py:17-87)
@@ -198,8 +199,39 @@ def gen_glue():
     save("glue_small.npz", extrinsics=E, dist=d)
 
 
+def gen_depth_tail():
+    """The real DepthDecoder (networks.py:19-154) on random feature pyramids; the fixture keeps the finest
+    scale's plane logits (conv_depth['0'] of output_pred_s0) and the tail's outputs (:130-152)."""
+    from src.model.encoder.modules.networks import DepthDecoder
+    for name, log_planes in (("depth_tail_log.npz", True), ("depth_tail_inv.npz", False)):
+        torch.manual_seed(600 + int(log_planes))
+        dd = DepthDecoder([24, 64, 128, 256, 384], num_output_channels=1 + 64, near=0.5, far=15.0, num_samples=32,
+                          log_planes=log_planes).eval()
+        feats = [torch.randn(2, c, 32 >> i, 48 >> i) for i, c in enumerate([24, 64, 128, 256, 384])]
+        with torch.no_grad():
+            out = dd(feats)
+            logits = dd.conv_depth["0"](out["output_pred_s0_b1hw"]) * 4.0   # (scaled: sharper softmax)
+            # re-run the tail on the scaled logits with the reference's own ops (lines 131-152)
+            import torch.nn.functional as F
+            planes = F.softmax(logits, dim=1)
+            coarse = (dd.depth_candi_curr * planes).sum(dim=1, keepdim=True)
+            fine = F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True)
+            wts = F.interpolate(planes, scale_factor=2, mode="bilinear", align_corners=True).max(dim=1, keepdim=True)[0]
+            depth = torch.exp(coarse) if log_planes else 1.0 / coarse
+            dmap = torch.exp(fine) if log_planes else 1.0 / fine
+            # and check that un-scaled logits reproduce the module's own outputs exactly
+            p0 = F.softmax(dd.conv_depth["0"](out["output_pred_s0_b1hw"]), dim=1)
+            c0 = (dd.depth_candi_curr * p0).sum(dim=1, keepdim=True)
+            assert torch.equal(c0, out["log_depth_pred_s0_b1hw"])
+        save(name, logits=logits, candidates=dd.depth_candi_curr.reshape(-1), log_planes=int(log_planes), coarse=coarse,
+             depth=depth, depth_map=dmap, depth_weights=wts, module_logits=dd.conv_depth["0"](out["output_pred_s0_b1hw"]).detach(),
+             module_log_depth=out["log_depth_pred_s0_b1hw"], module_depth_map=out["depth_pred_s-1_b1hw"],
+             module_depth_weights=out["depth_weights"])
+
+
 if __name__ == "__main__":
     install_shim()
+    gen_depth_tail()
     gen_glue()
     gen_framing()
     gen_cost_volume()

@@ -29,7 +29,9 @@ def test_patch_reference_rebinds_hot_path():
     assert enc.AVGFeatureVolumeManager is cost_volume.AVGFeatureVolumeManager
     assert enc.GaussianAdapter is gaussian_adapter.GaussianAdapter
     assert enc.EncoderFreeSplat.fuse_gaussians is ptf.fuse_gaussians
-    assert len(done) >= 5
+    from freesplat_amd import depth_tail
+    assert sys.modules["src.model.encoder.modules.networks"].DepthDecoder.forward is depth_tail.depth_decoder_forward
+    assert len(done) >= 6
     # same state-dict keys as the reference modules they replace (checkpoint compatibility)
     import importlib
     ref_cv = importlib.reload(importlib.import_module("src.model.encoder.modules.cost_volume"))
