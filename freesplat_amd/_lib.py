@@ -26,6 +26,8 @@ class RasterDims(C.Structure):
 
 RASTER_TILE_CULL = 1
 RASTER_SH_FP16 = 2
+RASTER_SH_CHANNEL_MAJOR = 4
+RASTER_COV_FULL = 8
 
 
 def build(force: bool = False) -> str:
@@ -64,6 +66,7 @@ SIGNATURES = {
     "fs_ptf_write_state": (C.c_int, [C.c_int32] * 3 + [_VP] * 24),
     "fs_ptf_gru_table_rows": (C.c_int32, []),
     "fs_ptf_gru_forward": (C.c_int, [C.c_int32] + [_VP] * 4),
+    "fs_frame_views": (C.c_int, [C.c_int32] + [_VP] * 4 + [C.c_int32] + [_VP] * 6),
     "fs_depth_tail_forward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 7),
     "fs_depth_tail_backward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 13),
     "fs_raster_tile_ranges": (_VP, [_VP, C.c_int32, C.c_int32]),

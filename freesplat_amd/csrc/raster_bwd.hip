@@ -260,6 +260,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const int i = base + t;
     const int per_sh = d.M * 3;
     const bool have_sh = shs != nullptr;
+    const bool sh_cm = (d.flags & FS_RASTER_SH_CHANNEL_MAJOR) != 0, cov_full = (d.flags & FS_RASTER_COV_FULL) != 0;
+    constexpr int kTriu[6] = {0, 1, 2, 4, 5, 8};
     const float tanfovx = tanfov_dev ? tanfov_dev[0] : d.tanfovx;
     const float tanfovy = tanfov_dev ? tanfov_dev[1] : d.tanfovy;
     const float wscale = scale_dev ? scale_dev[0] : 1.0f;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             const float fx = (float)d.W / (2.0f * tanfovx), fy = (float)d.H / (2.0f * tanfovy);
             float c3[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) c3[k] = cov3D[6 * (size_t)i + k];
+            for (int k = 0; k < 6; ++k) c3[k] = cov_full ? cov3D[9 * (size_t)i + kTriu[k]] : cov3D[6 * (size_t)i + k];
             if (scale_dev) {
                 const float s2 = wscale * wscale;
 #pragma unroll
@@ -355,11 +357,11 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 if (d.flags & FS_RASTER_SH_FP16) {
                     const _Float16* hsrc = (const _Float16*)shs + (size_t)i * per_sh;
 #pragma unroll
-                    for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? (float)hsrc[k] : 0.0f;
+                    for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? (float)hsrc[sh_cm ? (k % 3) * d.M + k / 3 : k] : 0.0f;
                 } else {
                     const float* fsrc = shs + (size_t)i * per_sh;
 #pragma unroll
-                    for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? fsrc[k] : 0.0f;
+                    for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? fsrc[sh_cm ? (k % 3) * d.M + k / 3 : k] : 0.0f;
                 }
                 float gdv[3];
                 switch (d.sh_degree) {
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             gm2x += dL_dmeans2D[3 * (size_t)i];
             gm2y += dL_dmeans2D[3 * (size_t)i + 1];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) gcov[k] += dL_dcov3D[6 * (size_t)i + k];
+            for (int k = 0; k < 6; ++k) gcov[k] += cov_full ? dL_dcov3D[9 * (size_t)i + kTriu[k]] : dL_dcov3D[6 * (size_t)i + k];
             gop += dL_dopac[i];
             if (!have_sh) {
 #pragma unroll
@@ -401,13 +403,19 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         dL_dmeans2D[3 * (size_t)i + 1] = gm2y;
         dL_dmeans2D[3 * (size_t)i + 2] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = gcov[k];
+        for (int k = 0; k < 6; ++k) {
+            if (cov_full) dL_dcov3D[9 * (size_t)i + kTriu[k]] = gcov[k];
+            else dL_dcov3D[6 * (size_t)i + k] = gcov[k];
+        }
+        if (cov_full) {  // the reference reads the upper triangle only (cuda_splatting.py:126): no gradient below it
+            dL_dcov3D[9 * (size_t)i + 3] = 0.0f; dL_dcov3D[9 * (size_t)i + 6] = 0.0f; dL_dcov3D[9 * (size_t)i + 7] = 0.0f;
+        }
         dL_dopac[i] = gop;
         if (have_sh) {
             // gsh[] beyond the active degree is still zero; static indices keep it in registers
 #pragma unroll
             for (int k = 0; k < 48; ++k)
-                if (k < per_sh) lds[t * per_sh + k] = gsh[k];
+                if (k < per_sh) lds[t * per_sh + (sh_cm ? (k % 3) * d.M + k / 3 : k)] = gsh[k];
         } else {
 #pragma unroll
             for (int k = 0; k < 3; ++k) dL_dcolors[3 * (size_t)i + k] = gcol[k];

@@ -29,17 +29,18 @@ namespace fs {
 // ------------------------------------------------------------------------------------------
 template <int DEG>
 __device__ __forceinline__ void eval_sh(const float* __restrict__ sh, float3 dir, float* rgb,
-                                        uint8_t& clampbits)
-{
+                                        uint8_t& clampbits, int cs, int ks)
+{   // coefficient k of channel c sits at sh[k * ks + c * cs]: (ks, cs) = (3, 1) for [M][3] rows, (1, M) for [3][M]
     float b[16];
     sh_basis<DEG>(dir.x, dir.y, dir.z, b);
     constexpr int NB = (DEG + 1) * (DEG + 1);
     clampbits = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float acc = b[0] * sh[c];
+        const float* s = sh + c * cs;
+        float acc = b[0] * s[0];
 #pragma unroll
-        for (int k = 1; k < NB; ++k) acc = acc + b[k] * sh[3 * k + c];
+        for (int k = 1; k < NB; ++k) acc = acc + b[k] * s[k * ks];
         acc = acc + 0.5f;
         if (acc < 0.0f) clampbits |= (uint8_t)(1u << c);
         rgb[c] = fmaxf(acc, 0.0f);
@@ -200,14 +201,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const int base = blockIdx.x * 256;
     const int cnt = min(256, d.N - base);
     const int per_sh = d.M * 3;
+    const bool sh_cm = (d.flags & FS_RASTER_SH_CHANNEL_MAJOR) != 0;
+    const int sh_cs = sh_cm ? d.M : 1, sh_ks = sh_cm ? 1 : 3;
+    const int per_cov = (d.flags & FS_RASTER_COV_FULL) ? 9 : 6;
     float* l_sh = lds;                                   // [256 * per_sh] (+pad to 4)
-    float* l_cov = l_sh + ((256 * per_sh + 3) & ~3);     // [256 * 6]
-    float* l_mean = l_cov + 256 * 6;                     // [256 * 3]
+    float* l_cov = l_sh + ((256 * per_sh + 3) & ~3);     // [256 * per_cov]
+    float* l_mean = l_cov + 256 * 9;                     // [256 * 3]
     if (shs) {
         if (d.flags & FS_RASTER_SH_FP16) stage_rows_half(l_sh, (const _Float16*)shs, base, cnt, per_sh);
         else stage_rows(l_sh, shs, base, cnt, per_sh);
     }
-    stage_rows(l_cov, cov3D, base, cnt, 6);
+    stage_rows(l_cov, cov3D, base, cnt, per_cov);
     stage_rows(l_mean, means3D, base, cnt, 3);
     __syncthreads();
     const int t = threadIdx.x;
@@ -229,8 +233,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         const float ndcx = ph.x * pw, ndcy = ph.y * pw;
         const float fx = (float)d.W / (2.0f * tanfovx), fy = (float)d.H / (2.0f * tanfovy);
         float c3[6];
+        if (per_cov == 9) {  // row-major 3x3, upper triangle
+            const float* cr = l_cov + 9 * t;
+            c3[0] = cr[0]; c3[1] = cr[1]; c3[2] = cr[2]; c3[3] = cr[4]; c3[4] = cr[5]; c3[5] = cr[8];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c3[k] = l_cov[6 * t + k];
+            for (int k = 0; k < 6; ++k) c3[k] = l_cov[6 * t + k];
+        }
         if (scale_dev) {
             const float s2 = wscale * wscale;
 #pragma unroll
@@ -265,10 +274,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                     dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
                     const float* sh = l_sh + (size_t)t * per_sh;
                     switch (d.sh_degree) {
-                        case 0: eval_sh<0>(sh, dir, rgb, cb); break;
-                        case 1: eval_sh<1>(sh, dir, rgb, cb); break;
-                        case 2: eval_sh<2>(sh, dir, rgb, cb); break;
-                        default: eval_sh<3>(sh, dir, rgb, cb); break;
+                        case 0: eval_sh<0>(sh, dir, rgb, cb, sh_cs, sh_ks); break;
+                        case 1: eval_sh<1>(sh, dir, rgb, cb, sh_cs, sh_ks); break;
+                        case 2: eval_sh<2>(sh, dir, rgb, cb, sh_cs, sh_ks); break;
+                        default: eval_sh<3>(sh, dir, rgb, cb, sh_cs, sh_ks); break;
                     }
                 }
                 const float op = opacities[i];
@@ -1026,7 +1035,7 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     }
     const int M = shs ? d.M : 0;
     if (d.N > 0) {
-        size_t lds = (size_t)(((256 * M * 3 + 3) & ~3) + 256 * 6 + 256 * 3) * sizeof(float);
+        size_t lds = (size_t)(((256 * M * 3 + 3) & ~3) + 256 * 9 + 256 * 3) * sizeof(float);
         if (lds < (size_t)(16 + kBinLds) * 4) lds = (size_t)(16 + kBinLds) * 4;
         {
             ScopedStage prof_(kStPreprocess, st);

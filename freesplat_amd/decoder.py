@@ -97,6 +97,23 @@ def _frame(extrinsics, intrinsics, near, far, scale_invariant: bool):
     return extrinsics, scale, tan_fov_x, tan_fov_y, view.contiguous(), full.contiguous()
 
 
+def frame_views(extrinsics, intrinsics, near, far, scale_invariant: bool = True):
+    """`_frame` for v views in one HIP launch (fs_frame_views): returns (campos [v,3], scale [v], tanfov [v,2],
+    view [v,4,4], full [v,4,4]), all on the device -- nothing of it is needed on the host by render_views."""
+    v = extrinsics.shape[0]
+    dev = extrinsics.device
+    if dev.type != "cuda":
+        raise RuntimeError(f"freesplat_amd frame_views: tensors must live on a HIP device (got {dev}); no CPU path")
+    f = lambda t: t.detach().to(torch.float32).contiguous()
+    out = [torch.empty(v, n, dtype=torch.float32, device=dev) for n in (16, 16, 3, 2)] + [torch.empty(v, dtype=torch.float32, device=dev)]
+    view, full, campos, tanfov, scale = out
+    p = R._lib.ptr
+    R._lib.check(R._lib.lib().fs_frame_views(v, p(f(extrinsics)), p(f(intrinsics)), p(f(near)), p(f(far)),
+                                             1 if scale_invariant else 0, p(view), p(full), p(campos), p(tanfov),
+                                             p(scale), R._lib.current_stream()), "fs_frame_views")
+    return campos, scale, tanfov, view.view(v, 4, 4), full.view(v, 4, 4)
+
+
 def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                 image_shape: tuple[int, int], background_color: Tensor, gaussian_means: Tensor,
                 gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
@@ -165,6 +182,7 @@ class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, cov6, shs, opac, views, fulls, campos, bgs, tanfov, scale, h, w, degree,
                 deferred):
+        # cov6 = covariances [G,3,3], shs = harmonics [G,3,d_sh]: the reference's own layouts, read in place
         v = views.shape[0]
         N = means.shape[0]
         dev = means.device
@@ -176,7 +194,7 @@ class _RenderViews(torch.autograd.Function):
         s0 = GaussianRasterizationSettings(h, w, 0.0, 0.0, None, 1.0, None, None, degree, None, False, False)
 
         def launch(i, cap_i):
-            dims = R.make_dims(N, shs.shape[1], s0, sh_fp16=shs.dtype == torch.float16)
+            dims = R.make_dims(N, shs.shape[2], s0, sh_fp16=shs.dtype == torch.float16, native_layout=True)
             rs, _, _, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i], fulls[i],
                                             campos[i], cap_i, tanfov=tanfov[i],
                                             scale=None if scale is None else scale[i],
@@ -243,16 +261,16 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     the instance-capacity check: check="now" (default) does it at the end of the call and re-renders
     overflowed views; check="deferred" leaves it to decoder.check_deferred() so that back-to-back
     calls keep the GPU queue full."""
-    extr, scale, tan_x, tan_y, view, full = _frame(extrinsics, intrinsics, near, far, scale_invariant)
-    tanfov = torch.stack([tan_x, tan_y], dim=-1).contiguous()
+    campos, scale, tanfov, view, full = frame_views(extrinsics, intrinsics, near, far, scale_invariant)
+    if not scale_invariant:
+        scale = None
     degree = isqrt(sh_coefficients.shape[-1]) - 1
-    shs = sh_coefficients.transpose(-1, -2).contiguous()
-    k = _consts(means.device)
-    cov6 = covariances[:, k["triu_row"], k["triu_col"]].contiguous()
     h, w = image_shape
-    color, depth = _RenderViews.apply(means.contiguous(), cov6, shs, opacities.contiguous(), view, full,
-                                      extr[:, :3, 3].contiguous(), background_color.contiguous(), tanfov,
-                                      None if scale is None else scale.contiguous(), h, w, degree,
+    # harmonics [G,3,d_sh] and covariances [G,3,3] go to the kernels as they are (FS_RASTER_SH_CHANNEL_MAJOR |
+    # FS_RASTER_COV_FULL): no transposed / gathered copies per call (cuda_splatting.py:78, :126)
+    color, depth = _RenderViews.apply(means.contiguous(), covariances.contiguous(), sh_coefficients.contiguous(),
+                                      opacities.contiguous(), view, full,
+                                      campos, background_color.contiguous(), tanfov, scale, h, w, degree,
                                       check == "deferred")
     return color, depth.unsqueeze(1)
 

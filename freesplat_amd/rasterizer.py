@@ -141,13 +141,17 @@ def _f32c(t: Tensor, name: str, allow_half: bool = False) -> Tensor:
     return t.contiguous()
 
 
-def make_dims(N, M, settings: GaussianRasterizationSettings, sh_fp16: bool = False) -> _lib.RasterDims:
+def make_dims(N, M, settings: GaussianRasterizationSettings, sh_fp16: bool = False, native_layout: bool = False) -> _lib.RasterDims:
+    """`native_layout`: shs is the reference's harmonics [N,3,M] and cov3D its covariances [N,3,3]
+    (FS_RASTER_SH_CHANNEL_MAJOR | FS_RASTER_COV_FULL) instead of the rasterizer API's [N,M,3] / [N,6]."""
     d = _lib.RasterDims()
     d.N, d.M = int(N), int(M)
     d.H, d.W = int(settings.image_height), int(settings.image_width)
     d.sh_degree = int(settings.sh_degree)
     d.tanfovx, d.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
     d.flags = (_lib.RASTER_TILE_CULL if TILE_CULL else 0) | (_lib.RASTER_SH_FP16 if sh_fp16 else 0)
+    if native_layout:
+        d.flags |= _lib.RASTER_SH_CHANNEL_MAJOR | _lib.RASTER_COV_FULL
     return d
 
 
@@ -182,7 +186,7 @@ def rasterize_backward(rs: RasterState, means3D, cov3D, shs, colors, g_color, g_
         out = dict(
             means3D=torch.empty(N, 3, dtype=torch.float32, device=dev),
             means2D=torch.empty(N, 3, dtype=torch.float32, device=dev),
-            cov3D=torch.empty(N, 6, dtype=torch.float32, device=dev),
+            cov3D=torch.empty(cov3D.shape, dtype=torch.float32, device=dev),
             shs=None if shs is None else torch.empty(shs.shape, dtype=torch.float32, device=dev),
             colors=None if colors is None else torch.empty(N, 3, dtype=torch.float32, device=dev),
             opacities=torch.empty(N, dtype=torch.float32, device=dev),

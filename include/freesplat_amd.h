@@ -75,6 +75,14 @@ typedef struct fs_raster_dims {
 /* `shs` holds IEEE half-precision values ([N,M,3] fp16, 94 instead of 148 input bytes per Gaussian at degree 2):
  * storage only -- they are widened on load and all math stays fp32 (BASELINE config 5).  Gradients stay fp32. */
 #define FS_RASTER_SH_FP16 2
+/* Reference-native tensor layouts, so that the caller needs no transposed / gathered copies
+ * (src/model/types.py:7-12; cuda_splatting.py:78 `rearrange(... "b g xyz n -> b g n xyz")` and :126
+ * `gaussian_covariances[:, :, row, col]`):
+ * SH_CHANNEL_MAJOR: `shs` / `dL_dshs` rows are [3][M] (harmonics [G,3,d_sh]) instead of [M][3];
+ * COV_FULL: `cov3D` / `dL_dcov3D` rows are the row-major 3x3 matrix (9 floats), of which the upper triangle
+ * is read; the gradient goes to the upper triangle and the three entries below it are written as 0. */
+#define FS_RASTER_SH_CHANNEL_MAJOR 4
+#define FS_RASTER_COV_FULL 8
 
 /* Byte sizes of the four caller-owned device buffers for (N, H, W, instance capacity):
  *   out[0] geom    : per-Gaussian screen-space state            (saved for backward)
@@ -249,6 +257,20 @@ int fs_gaussian_head_backward(int64_t M, const float* raw, const float* depths, 
                               float scale_min, float scale_max, const float* g_cov, const float* g_harmonics,
                               const float* g_scales, const float* g_rotations, float* g_raw, float* g_depths,
                               float* g_extrinsics, void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * Camera framing of the decoder (cuda_splatting.py:17-44, :64-87; projection.py:233-247) *
+ * ------------------------------------------------------------------------------------ */
+
+/* v views: extrinsics [v,4,4] (camera-to-world), intrinsics [v,3,3] (normalised), near / far [v] ->
+ * view [v,16] and full [v,16] (the transposed world-to-camera / full-projection matrices exactly as
+ * GaussianRasterizationSettings.viewmatrix / projmatrix expect them), campos [v,3], tanfov [v,2]
+ * (tan(fov_x/2), tan(fov_y/2)) and scale [v] (1/near when scale_invariant, else 1): the device-resident
+ * per-view settings fs_raster_forward takes (tanfov_dev, scale_dev).  A singular matrix gives NaNs, as
+ * torch.linalg.inv_ex does without check. */
+int fs_frame_views(int32_t v, const float* extrinsics, const float* intrinsics, const float* near,
+                   const float* far, int32_t scale_invariant, float* view, float* full, float* campos,
+                   float* tanfov, float* scale, void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * Depth-regression tail of the DepthDecoder (networks.py:130-152)                       *

@@ -87,19 +87,29 @@ def _oracle_chain(x):
     return out
 
 
-def _render_oracle(x, g):
-    from freesplat_amd.decoder import _frame
+def _render_oracle(x, g, device=None):
+    """Oracle render of the target views.  device=None: framed by the torch mirror of the reference on the CPU;
+    with a device: framed by fs_frame_views there (what the product decoder uses).  The two framings differ in the
+    last bit of a few matrix entries, which is enough to reorder the near-coplanar Gaussians of this scene in depth
+    -- so image comparisons against the product must use ITS matrices (the framing itself is pinned to the
+    reference separately, tests/test_raster_hip.py::test_frame_views_matches_reference_framing)."""
+    from freesplat_amd.decoder import _frame, frame_views
     from oracle import raster_oracle as ro
     means, cov, sh, opac = g
     n = x["tgt"].shape[0]
-    extr, scale, tx, ty, view, full = _frame(x["tgt"], x["Kn"][:1].expand(n, 3, 3), torch.full((n,), NEAR),
-                                             torch.full((n,), FAR), True)
+    args = (x["tgt"], x["Kn"][:1].expand(n, 3, 3).contiguous(), torch.full((n,), NEAR), torch.full((n,), FAR))
+    if device is None:
+        extr, scale, tx, ty, view, full = _frame(*args, True)
+        campos = extr[:, :3, 3]
+    else:
+        campos, scale, tanfov, view, full = (t.cpu() for t in frame_views(*(a.to(device) for a in args), True))
+        tx, ty = tanfov[:, 0], tanfov[:, 1]
     r, c = torch.triu_indices(3, 3)
     imgs = []
     for i in range(n):
         s = scale[i]
         st = ro.forward(H, W, float(tx[i]), float(ty[i]), np.zeros(3, np.float32), view[i].numpy(), full[i].numpy(), 2,
-                        extr[i, :3, 3].numpy(), (means * s).numpy(), (cov * s * s)[:, r, c].numpy(), opac.numpy(),
+                        campos[i].numpy(), (means * s).numpy(), (cov * s * s)[:, r, c].numpy(), opac.numpy(),
                         shs=sh.transpose(-1, -2).contiguous().numpy())
         imgs.append(st["color"])
     return np.stack(imgs)
@@ -163,7 +173,7 @@ def test_c1_pipeline_product_vs_oracle(hip_device):
                       torch.full((1, n), FAR, device=dev), (H, W), depth_mode="depth")
             return g, out.color[0].cpu().numpy()
 
-        ref = _render_oracle(x, o["gaussians"])
+        ref = _render_oracle(x, o["gaussians"], device=dev)
 
         def psnr(img):
             mse = float(((img.clip(0, 1) - ref.clip(0, 1)) ** 2).mean())
