@@ -182,6 +182,25 @@ __host__ __device__ inline GeomView geom_view(void* base, int N)
     g.qmask = (unsigned long long*)p;
     return g;
 }
+// Tile -> workgroup order of the per-tile kernels (tile_sort, render, render_bwd).  Workgroup b runs on XCD b % 8
+// (hardware round-robin).  Tiles are grouped in 4x4 super-tiles -- neighbouring tiles share most of their
+// Gaussians, so their records stay in one L2 -- and super-tile s goes to XCD s % 8: every XCD gets super-tiles
+// from all over the image.  (One contiguous band of tiles per XCD left the XCDs up to 25 % apart in work and
+// the slowest one set the kernel time: profiles/render_trace.py.)
+__host__ __device__ inline int tile_grid_blocks(int gx, int gy)
+{
+    const int ns = ((gx + 3) >> 2) * ((gy + 3) >> 2);
+    return 8 * ((ns + 7) >> 3) * 16;
+}
+__device__ __forceinline__ int tile_for_block(int b, int gx, int gy)
+{
+    const int i = b >> 3;
+    const int s = (b & 7) + 8 * (i >> 4), w = i & 15;
+    const int sgx = (gx + 3) >> 2;
+    const int tx = (s % sgx) * 4 + (w & 3), ty = (s / sgx) * 4 + (w >> 2);
+    return (tx < gx && ty < gy) ? ty * gx + tx : -1;
+}
+
 // binning: [T+1] u32 tile offsets (exclusive scan of per-tile counts), then [cap] u32 ids.
 __host__ __device__ inline int num_tiles(int H, int W)
 {

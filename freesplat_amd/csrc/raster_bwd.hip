@@ -76,10 +76,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     __shared__ float s_acc[256 * 10];
     __shared__ int s_maxlast;
 
-    const int chunk = (T + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
-    const int gx = (W + kTile - 1) / kTile;
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const int tile = tile_for_block(blockIdx.x, gx, gy);  // same XCD-aware, balanced order as the forward
+    if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);   // same 8x8 quadrant per wavefront
@@ -468,10 +467,10 @@ FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, 
         set_last_error("memset grad scratch", hipGetLastError());
         return FS_ERR_LAUNCH;
     }
-    const int chunk = (T + 7) / 8;
+    const int nblk = tile_grid_blocks((d.W + kTile - 1) / kTile, (d.H + kTile - 1) / kTile);
     {
         ScopedStage prof_(kStRenderBwd, st);
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(8 * chunk), dim3(256), 0, st, d.H, d.W, T, offsets,
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(nblk), dim3(256), 0, st, d.H, d.W, T, offsets,
                            point_list, g.rec, bg, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
     }
     FS_CHECK_LAUNCH("render_bwd");

@@ -625,17 +625,15 @@ __device__ __forceinline__ void sort_tile_in_registers(const unsigned long long*
     }
 }
 
-__global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint32_t* __restrict__ offsets,
+__global__ __launch_bounds__(256) void tile_sort_kernel(int gx, int gy, const uint32_t* __restrict__ offsets,
                                                         unsigned long long* __restrict__ keys,
                                                         uint32_t* __restrict__ point_list,
                                                         const uint32_t* __restrict__ counters)
 {
     __shared__ unsigned long long sk[kSortLds];
     if (counters[1]) return;  // overflowed capacity: ranges are not backed by memory
-    // XCD-aware: workgroup b -> XCD b%8 gets the contiguous tile band [xcd*chunk, (xcd+1)*chunk)
-    const int chunk = (T + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+    const int tile = tile_for_block(blockIdx.x, gx, gy);  // XCD-aware, balanced (fs_common.h)
+    if (tile < 0) return;
     const uint32_t a = offsets[tile], b = offsets[tile + 1];
     const uint32_t n = b - a;
     if (n == 0) return;
@@ -662,115 +660,6 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint32_t* _
 // and walks only the survivors (s_ff1 over the ballot): entries that cannot touch the quadrant
 // cost 1/64 of a VALU test instead of a full per-pixel evaluation.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void render_kernel_v1(
-    int H, int W, int T, const uint32_t* __restrict__ offsets,
-    const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-    const float* __restrict__ bg, const uint32_t* __restrict__ counters,
-    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-    float* __restrict__ final_T, int32_t* __restrict__ n_contrib)
-{
-    __shared__ float4 s0[256], s1[256], s2[256];
-    __shared__ uint32_t s_q[256];
-    if (counters[1]) return;
-    const int chunk = (T + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
-    const int gx = (W + kTile - 1) / kTile;
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pfx = (float)px, pfy = (float)py;
-    const uint32_t qbit = 1u << wave;
-
-    const uint32_t a = offsets[tile], b = offsets[tile + 1];
-    const int n = (int)(b - a);
-    const int rounds = (n + 255) >> 8;
-
-    float T_ = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, D = 0.0f;
-    int last = 0;
-    bool done = !inside;
-
-    for (int r = 0; r < rounds; ++r) {
-        if (__syncthreads_and(done)) break;
-        const int idx = (r << 8) + tid;
-        uint32_t w = 0;
-        if (idx < n) {
-            w = point_list[a + idx];
-            if (w & 15u) {
-                const float4* q = rec + 3 * (size_t)(w >> 4);
-                s0[tid] = q[0];
-                s1[tid] = q[1];
-                s2[tid] = q[2];
-            }
-        }
-        s_q[tid] = w;
-        __syncthreads();
-        const int m = min(256, n - (r << 8));
-        for (int c = 0; c < m; c += 64) {
-            if (__all(done)) break;  // wave-uniform
-            unsigned long long hits = __ballot((c + lane < m) && (s_q[c + lane] & qbit));
-            // survivors are taken two at a time: the two exponent/exp chains are independent (ILP),
-            // the blend itself stays strictly sequential in list order
-            while (hits) {
-                const int ja = c + __builtin_ctzll(hits);
-                hits &= hits - 1;
-                const bool two = hits != 0;
-                const int jb = two ? c + __builtin_ctzll(hits) : ja;
-                hits &= hits - 1;  // (0 & -1 == 0 when there was no second survivor)
-                const float4 a0 = s0[ja], a1 = s1[ja], a2 = s2[ja];
-                const float4 b0 = s0[jb], b1 = s1[jb], b2 = s2[jb];
-                const float dxa = a0.x - pfx, dya = a0.y - pfy;
-                const float dxb = b0.x - pfx, dyb = b0.y - pfy;
-                const float pa = fmaf(a0.z * dxa, dxa, fmaf(a0.w * dya, dya, (a1.x * dxa) * dya));
-                const float pb = fmaf(b0.z * dxb, dxb, fmaf(b0.w * dyb, dyb, (b1.x * dxb) * dyb));
-                const bool ca = !done && pa <= 0.0f && pa >= a1.z;
-                const bool cb = two && !done && pb <= 0.0f && pb >= b1.z;
-                if (!__any(ca || cb)) continue;  // wave-uniform
-                const float ala = fminf(0.99f, a1.y * fs_exp(pa));
-                const float alb = fminf(0.99f, b1.y * fs_exp(pb));
-                {   // first survivor
-                    const float test_T = T_ * (1.0f - ala);
-                    const bool vis = ca && ala >= 1.0f / 255.0f;
-                    const bool ok = vis && test_T >= 0.0001f;
-                    done = done || (vis && !ok);
-                    const float wgt = ok ? ala * T_ : 0.0f;
-                    C0 = ok ? fmaf(a2.x, wgt, C0) : C0;
-                    C1 = ok ? fmaf(a2.y, wgt, C1) : C1;
-                    C2 = ok ? fmaf(a2.z, wgt, C2) : C2;
-                    D = ok ? fmaf(a1.w, wgt, D) : D;
-                    T_ = ok ? test_T : T_;
-                    last = ok ? (r << 8) + ja + 1 : last;
-                }
-                {   // second survivor (sees the transmittance / done state the first one left)
-                    const float test_T = T_ * (1.0f - alb);
-                    const bool vis = cb && !done && alb >= 1.0f / 255.0f;
-                    const bool ok = vis && test_T >= 0.0001f;
-                    done = done || (vis && !ok);
-                    const float wgt = ok ? alb * T_ : 0.0f;
-                    C0 = ok ? fmaf(b2.x, wgt, C0) : C0;
-                    C1 = ok ? fmaf(b2.y, wgt, C1) : C1;
-                    C2 = ok ? fmaf(b2.z, wgt, C2) : C2;
-                    D = ok ? fmaf(b1.w, wgt, D) : D;
-                    T_ = ok ? test_T : T_;
-                    last = ok ? (r << 8) + jb + 1 : last;
-                }
-            }
-        }
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        final_T[pix] = T_;
-        n_contrib[pix] = last;
-        out_color[pix] = fmaf(T_, bg[0], C0);
-        out_color[HW + pix] = fmaf(T_, bg[1], C1);
-        out_color[2 * HW + pix] = fmaf(T_, bg[2], C2);
-        out_depth[pix] = D;
-        out_alpha[pix] = 1.0f - T_;
-    }
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -796,7 +685,7 @@ __device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
     return __builtin_bit_cast(f32x2, e);
 }
 
-// Blend loop, second form.  Each wavefront owns one 8x8 quadrant of the tile and is fully independent of the
+// Blend loop.  Each wavefront owns one 8x8 quadrant of the tile and is fully independent of the
 // other three (no workgroup barrier anywhere):
 //   * it walks the tile's sorted list 64 entries at a time, reading the 32-bit list words itself (two batches
 //     ahead) and the 48-byte records of the entries whose quadrant bit is set (one batch ahead), so the global
@@ -804,7 +693,7 @@ __device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
 //   * the survivors of a batch are COMPACTED into a wavefront-private LDS area, two per slot with their fields
 //     interleaved ([x_a x_b y_a y_b] ...), so that the walk reads register PAIRS straight from LDS
 //     (6 ds_read_b128 per two survivors, the next slot prefetched) and the exponent, the exp and alpha of both
-//     run on packed fp32 (v_pk_{add,mul,fma}_f32): ~50 VALU per two survivors instead of ~90 in render_kernel_v1.
+//     run on packed fp32 (v_pk_{add,mul,fma}_f32): ~50 VALU per two survivors instead of ~90 with scalar fp32 and broadcast reads.
 // Arithmetic per pixel is the same sequence of IEEE operations as v1 / the oracle => same bits.
 constexpr int kPairQuads = 6;  // float4 per slot of two survivors
 #ifdef FS_RENDER_TRACE
@@ -819,10 +708,9 @@ __global__ __launch_bounds__(256) void render_kernel(
 {
     __shared__ float4 s_pair[4][33 * kPairQuads];  // (+1 slot: the prefetch of "the next slot" may run one past)
     if (counters[1]) return;
-    const int chunk = (T + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
-    const int gx = (W + kTile - 1) / kTile;
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const int tile = tile_for_block(blockIdx.x, gx, gy);  // XCD-aware, balanced (fs_common.h)
+    if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
@@ -1059,17 +947,16 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
         }
         FS_CHECK_LAUNCH("emit");
     }
-    const int chunk = (T + 7) / 8;
+    const int nblk = tile_grid_blocks(gx, (d.H + kTile - 1) / kTile);
     {
         ScopedStage prof_(kStTileSort, st);
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(8 * chunk), dim3(256), 0, st, T, offsets, keys,
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(nblk), dim3(256), 0, st, gx, (d.H + kTile - 1) / kTile, offsets, keys,
                            point_list, counters);
     }
     FS_CHECK_LAUNCH("tile_sort");
     {
         ScopedStage prof_(kStRender, st);
-        static const bool v1 = [] { const char* e = getenv("FREESPLAT_RENDER_V1"); return e && e[0] == '1'; }();
-        hipLaunchKernelGGL(v1 ? render_kernel_v1 : render_kernel, dim3(8 * chunk), dim3(256), 0, st, d.H, d.W, T,
+        hipLaunchKernelGGL(render_kernel, dim3(nblk), dim3(256), 0, st, d.H, d.W, T,
                            offsets, point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T,
                            n_contrib);
     }
