@@ -625,6 +625,49 @@ __device__ __forceinline__ void sort_tile_in_registers(const unsigned long long*
     }
 }
 
+// Lists a little longer than a power of two (the common case: C3 averages 1156 keys per tile) would pay the
+// whole next network for mostly padding.  Two-run form: the first 256*EA keys and the remaining <= 256*EB keys
+// (EB < EA) are sorted by their own, smaller networks, laid out back to back through LDS, and merged by the last
+// stage of the 512*EA network alone (one flip + its half-cleaners).  In steps x keys-per-thread this is
+// 55*4 + 36*1 + 11*8 = 344 instead of 66*8 = 528 for 1024 < n <= 1280.
+template <int EA, int EB>
+__device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __restrict__ keys,
+                                                   uint32_t* __restrict__ out, uint32_t n, unsigned long long* lds)
+{
+    static_assert(EB < EA, "second run must be the shorter one");
+    constexpr int E = 2 * EA, NA = 256 * EA, NB = 256 * EB;
+    const int t = threadIdx.x;
+    unsigned long long ka[EA], kb[EB];
+#pragma unroll
+    for (int e = 0; e < EA; ++e) ka[e] = keys[t * EA + e];  // n > NA
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        const uint32_t i = (uint32_t)(NA + t * EB + e);
+        kb[e] = i < n ? keys[i] : ~0ull;
+    }
+    Stages<EA, NA>::run(ka, t, lds);
+    Stages<EB, NB>::run(kb, t, lds);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EA; ++e) lds[t * EA + e] = ka[e];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) lds[NA + t * EB + e] = kb[e];
+    __syncthreads();
+    unsigned long long k[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = t * E + e;
+        k[e] = i < NA + NB ? lds[i] : ~0ull;
+    }
+    thread_exchange<E, 255, true>(k, t, lds);  // flip step of the last stage: i <-> i ^ (512*EA - 1)
+    Clean<E, 256 * E / 4>::run(k, t, lds);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)t * E + e;
+        if (i < n) out[i] = (uint32_t)k[e];
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_sort_kernel(int gx, int gy, const uint32_t* __restrict__ offsets,
                                                         unsigned long long* __restrict__ keys,
                                                         uint32_t* __restrict__ point_list,
@@ -639,10 +682,20 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(int gx, int gy, const ui
     if (n == 0) return;
     if (n <= 512u) {
         sort_tile_in_registers<2>(keys + a, point_list + a, n, sk);
+    } else if (n <= 768u) {
+        sort_tile_two_runs<2, 1>(keys + a, point_list + a, n, sk);
     } else if (n <= 1024u) {
         sort_tile_in_registers<4>(keys + a, point_list + a, n, sk);
+    } else if (n <= 1280u) {
+        sort_tile_two_runs<4, 1>(keys + a, point_list + a, n, sk);
+    } else if (n <= 1536u) {
+        sort_tile_two_runs<4, 2>(keys + a, point_list + a, n, sk);
     } else if (n <= 2048u) {
         sort_tile_in_registers<8>(keys + a, point_list + a, n, sk);
+    } else if (n <= 2560u) {
+        sort_tile_two_runs<8, 2>(keys + a, point_list + a, n, sk);
+    } else if (n <= 3072u) {
+        sort_tile_two_runs<8, 4>(keys + a, point_list + a, n, sk);
     } else if (n <= 4096u) {
         sort_tile_in_registers<16>(keys + a, point_list + a, n, sk);
     } else {

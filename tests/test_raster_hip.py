@@ -144,6 +144,25 @@ def test_long_tile_lists_global_sort_path(hip_device, monkeypatch):
     _check_lists(dbg, st, W, H, False)
 
 
+@pytest.mark.parametrize("N", [600, 1150, 1400, 1900, 2300, 2900, 3700])
+def test_tile_sort_size_classes(hip_device, monkeypatch, N):
+    """Every size class of the per-tile sort (single network at 2/4/8/16 keys per thread and the two-run forms
+    for lists a little above a power of two): N Gaussians that all cover the single 16x16 tile."""
+    _set_cull(monkeypatch, False)
+    H = W = 16
+    scene, cams = small_scene(N=N, H=H, W=W, seed=40 + N)
+    scene["covariances"] = scene["covariances"] * 400.0
+    scene["opacities"] = scene["opacities"] * 0.01
+    vi = view_inputs(scene, cams, 0, H, W)
+    st, _, _ = _check_forward(vi, hip_device)
+    n = int(st["ranges"][0, 1] - st["ranges"][0, 0])
+    lo, hi = {600: (513, 768), 1150: (1025, 1280), 1400: (1281, 1536), 1900: (1537, 2048), 2300: (2049, 2560),
+              2900: (2561, 3072), 3700: (3073, 4096)}[N]
+    assert lo <= n <= hi, n
+    dbg, _, _ = _internal_state(vi, hip_device)
+    _check_lists(dbg, st, W, H, False)
+
+
 def test_depth_ties_break_by_index(hip_device, monkeypatch):
     _set_cull(monkeypatch, False)
     H = W = 32
