@@ -109,19 +109,30 @@ def current_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def profile_enable(on: bool) -> None:
-    check(lib().fs_profile_enable(1 if on else 0), "fs_profile_enable")
-
-
-def profile_collect() -> dict:
-    """{stage name: (total ms, launches)} of the launches recorded since the last collect."""
+def profile_stage_names() -> list:
     L = lib()
     names = []
     while True:
         s = L.fs_profile_stage_name(len(names))
         if s is None:
-            break
+            return names
         names.append(s.decode())
+
+
+def profile_enable(on, stages=None) -> None:
+    """on=False: off.  on=True: time every stage, or only the named `stages` (each timed launch costs two event
+    records on the stream, so a throughput measurement should time as little as it needs)."""
+    mask = 0
+    if on:
+        names = profile_stage_names()
+        mask = -1 if stages is None else sum(1 << names.index(s) for s in stages)
+    check(lib().fs_profile_enable(mask), "fs_profile_enable")
+
+
+def profile_collect() -> dict:
+    """{stage name: (total ms, launches)} of the launches recorded since the last collect."""
+    L = lib()
+    names = profile_stage_names()
     n = len(names)
     ms = (C.c_float * n)()
     cnt = (C.c_int32 * n)()

@@ -14,14 +14,14 @@ void set_last_error(const char* what, hipError_t e)
 }
 
 // ---- event-pair timing around kernel launches -------------------------------------------------
-static bool g_profile_on = false;
+static unsigned g_profile_mask = 0;  // bit i: stage i is timed
 struct Rec { int stage; hipEvent_t a, b; };
 static std::vector<Rec> g_recs;
 static std::mutex g_mu;
 
 ScopedStage::ScopedStage(Stage s, hipStream_t st) : slot_(-1), st_(st)
 {
-    if (!g_profile_on) return;
+    if (!((g_profile_mask >> (int)s) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Rec r;
     r.stage = (int)s;
@@ -40,10 +40,10 @@ static const char* kStageNames[kNumStages] = {"preprocess", "tile_scan", "emit",
                                               "render_bwd", "preprocess_bwd", "cost_volume", "ptf"};
 }  // namespace fs
 
-FS_API int fs_profile_enable(int on)
+FS_API int fs_profile_enable(int stage_mask)
 {
     std::lock_guard<std::mutex> lk(fs::g_mu);
-    fs::g_profile_on = on != 0;
+    fs::g_profile_mask = (unsigned)stage_mask;
     return FS_OK;
 }
 FS_API const char* fs_profile_stage_name(int i)

@@ -752,26 +752,29 @@ constexpr int kPairQuads = 6;  // float4 per slot of two survivors
 #ifdef FS_RENDER_TRACE
 __device__ unsigned long long g_render_trace[4 * 8192];
 #endif
-__global__ __launch_bounds__(256) void render_kernel(
+__global__ __launch_bounds__(64) void render_kernel(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
     const float* __restrict__ bg, const uint32_t* __restrict__ counters,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     float* __restrict__ final_T, int32_t* __restrict__ n_contrib)
 {
-    __shared__ float4 s_pair[4][33 * kPairQuads];  // (+1 slot: the prefetch of "the next slot" may run one past)
+    __shared__ float4 s_pair[33 * kPairQuads];  // (+1 slot: the prefetch of "the next slot" may run one past)
     if (counters[1]) return;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
-    const int tile = tile_for_block(blockIdx.x, gx, gy);  // XCD-aware, balanced (fs_common.h)
+    // one single-wavefront workgroup per 8x8 quadrant; the four quadrants of a tile are consecutive workgroups of
+    // the same XCD (workgroup id -> XCD id % 8), tiles in the XCD-aware, balanced order of fs_common.h
+    const int wave = (blockIdx.x >> 3) & 3;
+    const int tile = tile_for_block((int)(blockIdx.x >> 5) * 8 + (int)(blockIdx.x & 7), gx, gy);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lane = threadIdx.x;
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const f32x2 pfx = splat2((float)px), pfy = splat2((float)py);
     const uint32_t qbit = 1u << wave;
-    float4* const cp = s_pair[wave];
+    float4* const cp = s_pair;
 
     const uint32_t a = offsets[tile];
     const int n = (int)(offsets[tile + 1] - a);
@@ -1009,7 +1012,7 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     FS_CHECK_LAUNCH("tile_sort");
     {
         ScopedStage prof_(kStRender, st);
-        hipLaunchKernelGGL(render_kernel, dim3(nblk), dim3(256), 0, st, d.H, d.W, T,
+        hipLaunchKernelGGL(render_kernel, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T,
                            offsets, point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T,
                            n_contrib);
     }

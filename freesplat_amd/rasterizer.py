@@ -32,7 +32,7 @@ from . import _lib
 TILE_CULL = os.environ.get("FREESPLAT_TILE_CULL", "1") != "0"
 # Views of one render_views call are spread round-robin over this many HIP streams so that the short
 # latency-bound launches of one view (tile scan, kernel tails) overlap the VALU-bound blend of another.
-NUM_STREAMS = max(1, int(os.environ.get("FREESPLAT_RASTER_STREAMS", "1")))  # 2: +4.6 % views/s at C3, but per-kernel timings then overlap
+NUM_STREAMS = max(1, int(os.environ.get("FREESPLAT_RASTER_STREAMS", "2")))  # views of one call round-robin over this many streams
 
 
 class GaussianRasterizationSettings(NamedTuple):

@@ -43,11 +43,11 @@ const char* fs_version(void);
 /* Last HIP error string observed by a failing call on this thread (never NULL). */
 const char* fs_last_error(void);
 
-/* Optional per-kernel timing: while enabled, every kernel launch of this library is bracketed by a
- * hipEvent pair recorded on the launch stream (stream-ordered, no sync).  fs_profile_collect()
- * synchronises the recorded events, sums milliseconds / launch counts per stage into the first n
- * slots (stage i is named fs_profile_stage_name(i), NULL past the last stage) and resets. */
-int fs_profile_enable(int on);
+/* Optional per-kernel timing: while bit i of stage_mask is set, every launch of stage i of this library is
+ * bracketed by a hipEvent pair recorded on the launch stream (stream-ordered, no sync; -1 = every stage, 0 = off).
+ * fs_profile_collect() synchronises the recorded events, sums milliseconds / launch counts per stage into the
+ * first n slots (stage i is named fs_profile_stage_name(i), NULL past the last stage) and resets. */
+int fs_profile_enable(int stage_mask);
 int fs_profile_collect(int n, float* ms_total, int32_t* launches);
 const char* fs_profile_stage_name(int i);
 
