@@ -241,11 +241,44 @@ class _RenderViews(torch.autograd.Function):
         means, cov6, shs = ctx.saved_tensors
         if g_color is None and g_depth is None:
             return (None,) * 14
-        out = None
-        for i, rs in enumerate(ctx.states):
-            gc = None if g_color is None else g_color[i]
-            gd = None if g_depth is None else g_depth[i]
-            out = R.rasterize_backward(rs, means, cov6, shs, None, gc, gd, out=out, accumulate=i > 0)
+        v = len(ctx.states)
+        n_streams = min(R.NUM_STREAMS, v)
+        if g_color is not None:
+            g_color = g_color.contiguous()
+        if g_depth is not None:
+            g_depth = g_depth.contiguous()
+        view_grads = lambda i: (None if g_color is None else g_color[i], None if g_depth is None else g_depth[i])
+        if n_streams > 1:
+            # as in the forward: views alternate over the streams; every stream sums its views into its own set of
+            # gradient tensors (the per-Gaussian accumulation is ordered inside a stream), the sets are added at the end
+            st = R._state(means.device)
+            main = torch.cuda.current_stream()
+            while len(st.side_streams) < n_streams:
+                st.side_streams.append(torch.cuda.Stream(device=means.device))
+            ready = torch.cuda.Event()
+            ready.record(main)
+            outs = [None] * n_streams
+            for i, rs in enumerate(ctx.states):
+                s = st.side_streams[i % n_streams]
+                if i < n_streams:
+                    s.wait_event(ready)
+                with torch.cuda.stream(s):
+                    outs[i % n_streams] = R.rasterize_backward(rs, means, cov6, shs, None, *view_grads(i),
+                                                               out=outs[i % n_streams], accumulate=i >= n_streams)
+            for s in st.side_streams[:n_streams]:
+                main.wait_stream(s)
+            out = outs[0]
+            for t in out.values():
+                if t is not None:
+                    t.record_stream(main)       # allocated under a side stream, handed to autograd on `main`
+            for o in outs[1:]:
+                for k in ("means3D", "cov3D", "shs", "opacities"):
+                    out[k] += o[k]
+                    o[k].record_stream(main)
+        else:
+            out = None
+            for i, rs in enumerate(ctx.states):
+                out = R.rasterize_backward(rs, means, cov6, shs, None, *view_grads(i), out=out, accumulate=i > 0)
         g_shs = out["shs"] if shs.dtype == torch.float32 else out["shs"].to(shs.dtype)
         return (out["means3D"], out["cov3D"], g_shs, out["opacities"]) + (None,) * 10
 
