@@ -59,6 +59,41 @@ __device__ __forceinline__ float fs_exp(float x)
     return ldexpf(p, (int)n);
 }
 
+// LDS operations of one wavefront execute in order: between phases of a wavefront-private LDS exchange only the
+// compiler must be kept from reordering them.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- packed fp32 (v_pk_{add,mul,fma}_f32): two Gaussians per lane-instruction in the blend loops ----
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+
+// fs_exp() of two arguments in [-80, 0], bit-identical to the scalar form: rint(m) = (m + 1.5*2^23) - 1.5*2^23
+// for |m| < 2^22, and the low bits of the biased sum are the integer for the exponent (ldexpf == integer add on
+// the exponent field while the result stays normal).  Arguments outside the range give garbage, never a trap.
+__device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
+{
+    const f32x2 magic = splat2(12582912.0f);
+    const f32x2 t = x * splat2(1.44269504088896341f) + magic;
+    const f32x2 n = t - magic;
+    f32x2 r = fma2(n, splat2(-0.693145751953125f), x);
+    r = fma2(n, splat2(-1.42860676533018e-6f), r);
+    f32x2 q = fma2(r, splat2(1.0f / 720.0f), splat2(1.0f / 120.0f));
+    q = fma2(r, q, splat2(1.0f / 24.0f));
+    q = fma2(r, q, splat2(1.0f / 6.0f));
+    q = fma2(r, q, splat2(0.5f));
+    q = fma2(r, q, splat2(1.0f));
+    q = fma2(r, q, splat2(1.0f));
+    const i32x2 e = __builtin_bit_cast(i32x2, q) + (__builtin_bit_cast(i32x2, t) << 23);
+    return __builtin_bit_cast(f32x2, e);
+}
+
 // ---- camera transforms: torch hands the matrices over transposed => column-major here -------
 __device__ __forceinline__ float3 xform43(const float* __restrict__ m, float3 p)
 {

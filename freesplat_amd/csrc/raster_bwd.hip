@@ -30,173 +30,240 @@ __device__ __forceinline__ float xchg(float v)
     else return __int_as_float(__builtin_amdgcn_ds_swizzle(i, (M << 10) | 0x1F));                          // bit-mode xor M
 }
 
-// Sum 10 per-lane values over the 64 lanes of a wavefront with a HALVING butterfly: at every level a
-// lane keeps one half of its values and hands the other half to its partner, so 10 values cost
-// 5+3+2+1+1+1 = 13 exchanges instead of 10 x 6.  Afterwards the 16 lanes with (lane & 3) == 0 each
-// hold the complete sum of ONE value (or of a zero pad); wave_value_index() says which.
+// Sum 10 per-lane values over the 64 lanes of a wavefront in 28 instructions.  Two HALVING levels on the gfx950
+// row-swap instructions: v_permlane32_swap(X, Y) leaves X+Y = (value X summed over lanes l, l+32) in the lower half
+// and (value Y ...) in the upper half -- one swap + one add per surviving value -- and v_permlane16_swap does the
+// same between the two 16-lane rows of each half.  10 values -> 5 per half -> 3 registers per row; the rest of the
+// reduction stays inside a row: 4 adds with a DPP row rotation folded in (row_ror 8, 4, 2, 1) per register.
+// Afterwards EVERY lane of row r holds the complete sums of that row's (up to) 3 values; wave_value_index() says
+// which value lane (r, j) owns (-1: none).
 __device__ __forceinline__ int wave_value_index(int lane)
 {
-    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
-    // level 1 keeps [0..4] | [5..9]; level 2 keeps slots [0,1,2] | [3,4,-]; level 3 [0,1] | [2,-]; level 4 [0] | [1]
-    const int s3 = b2;                      // slot within the level-3 survivors (2 slots)
-    if (b3 && s3 == 1) return -1;           // pad
-    const int s2 = b3 ? 2 : s3;             // slot within the level-2 survivors (3 slots)
-    if (b4 && s2 == 2) return -1;           // pad
-    const int s1 = b4 ? 3 + s2 : s2;        // slot within the level-1 survivors (5 slots)
-    return b5 ? 5 + s1 : s1;
+    const int j = lane & 15, row = (lane >> 4) & 1, half = lane >> 5;
+    if (j > 2 || (row == 1 && j == 2)) return -1;
+    return 5 * half + 3 * row + j;
+}
+__device__ __forceinline__ float swap_add32(float x, float y)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float x, float y)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float row_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum(float v)
+{
+    v = row_add<0x128>(v);  // row_ror:8
+    v = row_add<0x124>(v);  // row_ror:4
+    v = row_add<0x122>(v);  // row_ror:2
+    return row_add<0x121>(v);  // row_ror:1
 }
 __device__ __forceinline__ float wave_sum10(const float (&v)[10], int lane)
 {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
     float a[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) a[k] = (b5 ? v[5 + k] : v[k]) + xchg<32>(b5 ? v[k] : v[5 + k]);
-    float c[3];
-    c[0] = (b4 ? a[3] : a[0]) + xchg<16>(b4 ? a[0] : a[3]);
-    c[1] = (b4 ? a[4] : a[1]) + xchg<16>(b4 ? a[1] : a[4]);
-    c[2] = (b4 ? 0.0f : a[2]) + xchg<16>(b4 ? a[2] : 0.0f);
-    float e[2];
-    e[0] = (b3 ? c[2] : c[0]) + xchg<8>(b3 ? c[0] : c[2]);
-    e[1] = (b3 ? 0.0f : c[1]) + xchg<8>(b3 ? c[1] : 0.0f);
-    float f = (b2 ? e[1] : e[0]) + xchg<4>(b2 ? e[0] : e[1]);
-    f += xchg<2>(f);
-    f += xchg<1>(f);
-    return f;
+    for (int k = 0; k < 5; ++k) a[k] = swap_add32(v[k], v[5 + k]);  // lower half: values 0..4, upper half: 5..9
+    // row 0 of a half keeps a[0..2], row 1 a[3], a[4] (and a zero)
+    const float c0 = row_sum(swap_add16(a[0], a[3]));
+    const float c1 = row_sum(swap_add16(a[1], a[4]));
+    const float c2 = row_sum(swap_add16(a[2], 0.0f));
+    const int j = lane & 15;
+    return j == 0 ? c0 : (j == 1 ? c1 : c2);
 }
 
-__global__ __launch_bounds__(256) void render_bwd_kernel(
+// Sum 20 per-lane values -- 10 of survivor a, 10 of survivor b -- over the wavefront in 50 instructions: the first
+// halving level puts a's sums into the lower half and b's into the upper half (swap_add32), the second leaves
+// values 0..4 in the even row and 5..9 in the odd row of each half (swap_add16), the rest is in-row (row_sum).
+// Afterwards every lane of row r holds out[0..4] = values 5*(r&1) .. 5*(r&1)+4 of survivor (r >> 1).
+__device__ __forceinline__ void wave_sum_pair(const float (&va)[10], const float (&vb)[10], float (&out)[5])
+{
+    float h[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) h[k] = swap_add32(va[k], vb[k]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out[k] = row_sum(swap_add16(h[k], h[5 + k]));
+}
+
+constexpr int kBwdQuads = 7;  // float4 per slot of two survivors
+// Backward blend loop, same organisation as the forward (raster_fwd.hip:render_kernel): one single-wavefront
+// workgroup per 8x8 quadrant, no barriers; the tile list is walked BACK TO FRONT 64 entries at a time with the
+// records of the next batch in flight; the survivors of a batch are compacted (highest list position first) two per
+// LDS slot with interleaved fields, so exponent, exp, alpha and all per-Gaussian derivative terms of both run on
+// packed fp32, and only the transmittance / behind-colour recurrences stay sequential.  The 2 x 10 per-pixel
+// partials are summed over the wavefront by wave_sum_pair and leave as one global atomic instruction per pair
+// (20 lanes, one per component): nothing is staged or re-read.
+//
+// Recurrences, for a pixel with final transmittance Tf, walking j = last .. first:
+//   T_j   = T_{j+1} / (1 - a_j)                       transmittance in front of j     (T_{last+1} := Tf)
+//   R_j   = colour composited behind j;  R_{j-1} = R_j + a_j (c_j - R_j)              (R_last := 0)
+//   dL/da_j = T_j * sum_ch (c_j - R_j)_ch * dL/dC_ch  -  Tf / (1 - a_j) * (bg . dL/dC)
+// A survivor that does not touch the pixel enters with a_j = 0 and G_j = 0, which makes every update the identity
+// and every partial zero -- no per-value masking.
+__global__ __launch_bounds__(64) void render_bwd_kernel(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
     const float* __restrict__ bg, const float* __restrict__ final_T,
     const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, float* __restrict__ grad)
 {
-    __shared__ float4 s0[256], s1[256], s2[256];
-    __shared__ uint32_t s_id[256];  // (id << 4) | quadrant mask
-    __shared__ float s_acc[256 * 10];
-    __shared__ int s_maxlast;
-
+    __shared__ float4 s_pair[32 * kBwdQuads];
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
-    const int tile = tile_for_block(blockIdx.x, gx, gy);  // same XCD-aware, balanced order as the forward
+    const int wave = (blockIdx.x >> 3) & 3;  // quadrant; same workgroup order as the forward
+    const int tile = tile_for_block((int)(blockIdx.x >> 5) * 8 + (int)(blockIdx.x & 7), gx, gy);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);   // same 8x8 quadrant per wavefront
-    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);  // as the forward
+    const int lane = threadIdx.x;
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     const uint32_t qbit = 1u << wave;
-    const int my_slot = (lane & 3) == 0 ? wave_value_index(lane) : -1;  // which reduced value this lane owns
     const bool inside = px < W && py < H;
-    const float pfx = (float)px, pfy = (float)py;
-    const uint32_t a = offsets[tile], b = offsets[tile + 1];
-    const int n = (int)(b - a);
+    const f32x2 pfx = splat2((float)px), pfy = splat2((float)py);
+    const uint32_t a = offsets[tile];
+    const int n = (int)(offsets[tile + 1] - a);
     if (n == 0) return;
+    const uint32_t* const pl = point_list + a;
 
     const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
     const float Tf = inside ? final_T[pix] : 0.0f;
     const int last = inside ? n_contrib[pix] : 0;
-    const float gc0 = inside ? dL_dcolor[pix] : 0.0f;
-    const float gc1 = inside ? dL_dcolor[HW + pix] : 0.0f;
-    const float gc2 = inside ? dL_dcolor[2 * HW + pix] : 0.0f;
-    const float gd = (inside && dL_ddepth) ? dL_ddepth[pix] : 0.0f;
-    const float bgdot = bg[0] * gc0 + bg[1] * gc1 + bg[2] * gc2;
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    const f32x2 g01 = {inside ? dL_dcolor[pix] : 0.0f, inside ? dL_dcolor[HW + pix] : 0.0f};
+    const f32x2 g23 = {inside ? dL_dcolor[2 * HW + pix] : 0.0f, (inside && dL_ddepth) ? dL_ddepth[pix] : 0.0f};
+    const float Tb = Tf * (bg[0] * g01.x + bg[1] * g01.y + bg[2] * g23.x);
+    const f32x2 half_wh = {0.5f * (float)W, 0.5f * (float)H};
 
-    if (tid == 0) s_maxlast = 0;
-    __syncthreads();
-    atomicMax(&s_maxlast, last);
-    __syncthreads();
-    const int maxlast = s_maxlast;
+    int maxlast = last;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) maxlast = max(maxlast, __shfl_xor(maxlast, m, 64));
     if (maxlast == 0) return;
+    const int m_end = min(n, maxlast);  // entries at or beyond this position contributed to no pixel of the quadrant
 
     float T_ = Tf;
-    float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-    float lc0 = 0, lc1 = 0, lc2 = 0, lc3 = 0, last_alpha = 0;
+    f32x2 R01 = splat2(0.0f), R23 = splat2(0.0f);
+    const int row = lane >> 4, col = lane & 15;
+    float4* const cp = s_pair;
 
-    for (int r = (maxlast - 1) >> 8; r >= 0; --r) {
-        __syncthreads();  // previous batch fully flushed
-        const int idx = (r << 8) + tid;
-        uint32_t wq = 0;
-        if (idx < n) {
-            wq = point_list[a + idx];
-            if (wq & 15u) {
-                const float4* q = rec + 3 * (size_t)(wq >> 4);
-                s0[tid] = q[0];
-                s1[tid] = q[1];
-                s2[tid] = q[2];
+    // software pipeline over batches of 64 entries, highest batch first: list words two batches ahead, records one
+    const int top = (m_end - 1) >> 6;
+    auto word = [&](int bi) -> uint32_t {
+        const int j = (bi << 6) + lane;
+        return (bi >= 0 && j < m_end) ? pl[j] : 0u;
+    };
+    uint32_t w_cur = word(top), w_nxt = word(top - 1);
+    float4 r0 = {}, r1 = {}, r2 = {};
+    if (w_cur & qbit) {
+        const float4* q = rec + 3 * (size_t)(w_cur >> 4);
+        r0 = q[0]; r1 = q[1]; r2 = q[2];
+    }
+    for (int bi = top; bi >= 0; --bi) {
+        const bool hit = (w_cur & qbit) != 0;
+        const unsigned long long hits = __ballot(hit);
+        const float4 a0 = r0, a1 = r1, a2 = r2;
+        const uint32_t w_this = w_cur;
+        w_cur = w_nxt;
+        if (w_cur & qbit) {
+            const float4* q = rec + 3 * (size_t)(w_cur >> 4);
+            r0 = q[0]; r1 = q[1]; r2 = q[2];
+        }
+        w_nxt = word(bi - 2);
+        if (!hits) continue;
+        const int cnt = __popcll(hits);
+        if (hit) {
+            const int k = __popcll(hits & ~((2ull << lane) - 1ull));  // survivors above this lane: back to front
+            float* d = (float*)(cp + (k >> 1) * kBwdQuads) + (k & 1);
+            d[0] = a0.x; d[2] = a0.y;                    // [x_a x_b y_a y_b]
+            d[4] = a0.z; d[6] = a0.w;                    // [A_a A_b C_a C_b]   (A = -a/2, C = -c/2)
+            d[8] = a1.x; d[10] = a1.z;                   // [B_a B_b thr_a thr_b] (B = -b)
+            d[12] = a1.y; d[14] = __int_as_float((bi << 6) + lane + 1);  // [op_a op_b pos_a pos_b]
+            cp[(k >> 1) * kBwdQuads + 4 + (k & 1)] = make_float4(a2.x, a2.y, a2.z, a1.w);  // [r g b depth]
+            d[24] = __uint_as_float(w_this >> 4);        // [id_a id_b . .]
+            if (k == cnt - 1 && !(k & 1)) {
+                // odd count: the unused half of the last slot must hold finite numbers (it enters with weight 0)
+                d[1] = 0.0f; d[3] = 0.0f; d[5] = 0.0f; d[7] = 0.0f; d[9] = 0.0f; d[11] = 1.0f; d[13] = 0.0f;
+                d[15] = __int_as_float(0x7fffffff);
+                cp[(k >> 1) * kBwdQuads + 5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                d[25] = 0.0f;
             }
         }
-        s_id[tid] = wq;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) s_acc[k * 256 + tid] = 0.0f;
-        __syncthreads();
-        const int m = min(256, min(n, maxlast) - (r << 8));
-        for (int c = (m - 1) & ~63; c >= 0; c -= 64) {
-          unsigned long long hits = __ballot((c + lane < m) && (s_id[c + lane] & qbit));
-          if (!hits) continue;
-          // software pipeline: fetch the next survivor's record from LDS while this one is processed
-          int jn = c + 63 - __builtin_clzll(hits);
-          float4 n0 = s0[jn], n1 = s1[jn], n2 = s2[jn];
-          while (hits) {
-            const int j = jn;  // back to front
-            const float4 g0 = n0, g1 = n1, g2 = n2;
-            hits &= ~(1ull << (j - c));
-            if (hits) {
-                jn = c + 63 - __builtin_clzll(hits);
-                n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
+        wave_lds_sync();
+        const int nslots = (cnt + 1) >> 1;
+        for (int p = 0; p < nslots; ++p) {
+            const float4* q = cp + p * kBwdQuads;
+            const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+            const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
+            const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx,
+                                  fma2((f32x2){c1.z, c1.w} * dy, dy, ((f32x2){c2.x, c2.y} * dx) * dy));
+            bool on_a = (__float_as_int(c3.z) <= last) & (pw.x <= 0.0f) & (pw.x >= c2.z);
+            bool on_b = (__float_as_int(c3.w) <= last) & (pw.y <= 0.0f) & (pw.y >= c2.w);
+            if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) continue;  // wave-uniform
+            const f32x2 Gr = fs_exp2_nonpos(pw);
+            const f32x2 oe = (f32x2){c3.x, c3.y} * Gr;
+            const f32x2 al_raw = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+            on_a = on_a & (al_raw.x >= 1.0f / 255.0f);
+            on_b = on_b & (al_raw.y >= 1.0f / 255.0f);
+            if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) continue;
+            const float4 ka = q[4], kb = q[5];
+            const f32x2 al = {on_a ? al_raw.x : 0.0f, on_b ? al_raw.y : 0.0f};
+            const f32x2 G = {on_a ? Gr.x : 0.0f, on_b ? Gr.y : 0.0f};
+            const f32x2 om = splat2(1.0f) - al;
+            // 1 - alpha >= 0.01: one reciprocal (1 ulp) serves both divisions of the reference formula
+            const f32x2 rinv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+            float va[10], vb[10];
+            f32x2 dLa;
+            {   // survivor a (the one further back)
+                T_ = T_ * rinv.x;
+                const f32x2 d01 = (f32x2){ka.x, ka.y} - R01, d23 = (f32x2){ka.z, ka.w} - R23;
+                const f32x2 s = fma2(d23, g23, d01 * g01);
+                R01 = fma2(splat2(al.x), d01, R01);
+                R23 = fma2(splat2(al.x), d23, R23);
+                dLa.x = fmaf(s.x + s.y, T_, -(Tb * rinv.x));
+                const f32x2 w = splat2(al.x * T_);
+                const f32x2 c01 = w * g01, c23 = w * g23;
+                va[6] = c01.x; va[7] = c01.y; va[8] = c23.x; va[9] = c23.y;
             }
-            const int contributor = (r << 8) + j + 1;
-            const float dx = g0.x - pfx, dy = g0.y - pfy;
-            const float power = fmaf(g0.z * dx, dx, fmaf(g0.w * dy, dy, (g1.x * dx) * dy));
-            bool on = contributor <= last && power <= 0.0f && power >= g1.z;
-            float G = 0.0f, alpha = 0.0f;
-            if (on) {
-                G = fs_exp(power);
-                alpha = fminf(0.99f, g1.y * G);
-                on = alpha >= 1.0f / 255.0f;
+            {   // survivor b (in front of a)
+                T_ = T_ * rinv.y;
+                const f32x2 d01 = (f32x2){kb.x, kb.y} - R01, d23 = (f32x2){kb.z, kb.w} - R23;
+                const f32x2 s = fma2(d23, g23, d01 * g01);
+                R01 = fma2(splat2(al.y), d01, R01);
+                R23 = fma2(splat2(al.y), d23, R23);
+                dLa.y = fmaf(s.x + s.y, T_, -(Tb * rinv.y));
+                const f32x2 w = splat2(al.y * T_);
+                const f32x2 c01 = w * g01, c23 = w * g23;
+                vb[6] = c01.x; vb[7] = c01.y; vb[8] = c23.x; vb[9] = c23.y;
             }
-            const unsigned long long onmask = __ballot(on);
-            if (!onmask) continue;
-            float v_mx = 0, v_my = 0, v_ca = 0, v_cb = 0, v_cc = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_z = 0;
-            if (on) {
-                // 1 - alpha >= 0.01: one reciprocal (1 ulp) serves both divisions of the reference formula
-                const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
-                T_ = T_ * rinv;
-                const float w = alpha * T_;
-                float dL_dalpha = 0.0f;
-                acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0; lc0 = g2.x; dL_dalpha += (g2.x - acc0) * gc0;
-                acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1; lc1 = g2.y; dL_dalpha += (g2.y - acc1) * gc1;
-                acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2; lc2 = g2.z; dL_dalpha += (g2.z - acc2) * gc2;
-                acc3 = last_alpha * lc3 + (1.0f - last_alpha) * acc3; lc3 = g1.w; dL_dalpha += (g1.w - acc3) * gd;
-                v_r = w * gc0; v_g = w * gc1; v_b = w * gc2; v_z = w * gd;
-                dL_dalpha *= T_;
-                last_alpha = alpha;
-                dL_dalpha -= Tf * rinv * bgdot;
-                const float dL_dG = g1.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float cA = -2.0f * g0.z, cC = -2.0f * g0.w, cB = -g1.x;
-                const float dG_ddelx = -gdx * cA - gdy * cB;
-                const float dG_ddely = -gdy * cC - gdx * cB;
-                v_mx = dL_dG * dG_ddelx * ddelx_dx;
-                v_my = dL_dG * dG_ddely * ddely_dy;
-                v_ca = -0.5f * gdx * dx * dL_dG;
-                v_cb = -0.5f * gdx * dy * dL_dG;
-                v_cc = -0.5f * gdy * dy * dL_dG;
-                v_op = G * dL_dalpha;
+            // per-Gaussian derivative terms of both survivors, packed [a, b]
+            const f32x2 dL_dG = (f32x2){c3.x, c3.y} * dLa;
+            const f32x2 v_op = G * dLa;
+            const f32x2 gdx = G * dx, gdy = G * dy;
+            const f32x2 A2 = (f32x2){c1.x, c1.y} + (f32x2){c1.x, c1.y}, C2 = (f32x2){c1.z, c1.w} + (f32x2){c1.z, c1.w};
+            const f32x2 Bm = {c2.x, c2.y};
+            const f32x2 dGx = fma2(A2, gdx, Bm * gdy);   // dG/d(delta x) = -(a gdx + b gdy),  A = -a/2, B = -b
+            const f32x2 dGy = fma2(C2, gdy, Bm * gdx);
+            const f32x2 v_mx = (dL_dG * dGx) * splat2(half_wh.x);
+            const f32x2 v_my = (dL_dG * dGy) * splat2(half_wh.y);
+            const f32x2 hq = dL_dG * splat2(-0.5f);
+            const f32x2 tx2 = gdx * hq, ty2 = gdy * hq;
+            const f32x2 v_ca = tx2 * dx, v_cb = tx2 * dy, v_cc = ty2 * dy;
+            va[0] = v_mx.x; va[1] = v_my.x; va[2] = v_ca.x; va[3] = v_cb.x; va[4] = v_cc.x; va[5] = v_op.x;
+            vb[0] = v_mx.y; vb[1] = v_my.y; vb[2] = v_ca.y; vb[3] = v_cb.y; vb[4] = v_cc.y; vb[5] = v_op.y;
+            float tot[5];
+            wave_sum_pair(va, vb, tot);
+            // row r of the wavefront: components 5*(r&1) .. +4 of survivor (r >> 1); lane (r, j < 5) flushes component j
+            const float4 ids = q[6];
+            if (col < 5) {
+                const float v = col == 0 ? tot[0] : col == 1 ? tot[1] : col == 2 ? tot[2] : col == 3 ? tot[3] : tot[4];
+                const uint32_t id = __float_as_uint(row < 2 ? ids.x : ids.y);
+                if (v != 0.0f) atomicAdd(&grad[(size_t)id * kGradStride + 5 * (row & 1) + col], v);
             }
-            const float vals[10] = {v_mx, v_my, v_ca, v_cb, v_cc, v_op, v_r, v_g, v_b, v_z};
-            const float tot = wave_sum10(vals, lane);
-            if (my_slot >= 0) atomicAdd(&s_acc[my_slot * 256 + j], tot);
-          }
         }
-        __syncthreads();
-        if (tid < m && (s_id[tid] & 15u)) {
-            float* gout = grad + (size_t)(s_id[tid] >> 4) * kGradStride;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                const float v = s_acc[k * 256 + tid];
-                if (v != 0.0f) atomicAdd(&gout[k], v);
-            }
-        }
+        wave_lds_sync();  // the next batch's compaction overwrites the slots
     }
 }
 
@@ -470,7 +537,7 @@ FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, 
     const int nblk = tile_grid_blocks((d.W + kTile - 1) / kTile, (d.H + kTile - 1) / kTile);
     {
         ScopedStage prof_(kStRenderBwd, st);
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(nblk), dim3(256), 0, st, d.H, d.W, T, offsets,
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
                            point_list, g.rec, bg, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
     }
     FS_CHECK_LAUNCH("render_bwd");

@@ -713,31 +713,6 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(int gx, int gy, const ui
 // and walks only the survivors (s_ff1 over the ballot): entries that cannot touch the quadrant
 // cost 1/64 of a VALU test instead of a full per-pixel evaluation.
 // ------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
-
-// fs_exp() of two arguments in [-80, 0], bit-identical to the scalar form: rint(m) = (m + 1.5*2^23) - 1.5*2^23
-// for |m| < 2^22, and the low bits of the biased sum are the integer for the exponent (ldexpf == integer add on
-// the exponent field while the result stays normal).  Arguments outside the range give garbage, never a trap.
-__device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
-{
-    const f32x2 magic = splat2(12582912.0f);
-    const f32x2 t = x * splat2(1.44269504088896341f) + magic;
-    const f32x2 n = t - magic;
-    f32x2 r = fma2(n, splat2(-0.693145751953125f), x);
-    r = fma2(n, splat2(-1.42860676533018e-6f), r);
-    f32x2 q = fma2(r, splat2(1.0f / 720.0f), splat2(1.0f / 120.0f));
-    q = fma2(r, q, splat2(1.0f / 24.0f));
-    q = fma2(r, q, splat2(1.0f / 6.0f));
-    q = fma2(r, q, splat2(0.5f));
-    q = fma2(r, q, splat2(1.0f));
-    q = fma2(r, q, splat2(1.0f));
-    const i32x2 e = __builtin_bit_cast(i32x2, q) + (__builtin_bit_cast(i32x2, t) << 23);
-    return __builtin_bit_cast(f32x2, e);
-}
-
 // Blend loop.  Each wavefront owns one 8x8 quadrant of the tile and is fully independent of the
 // other three (no workgroup barrier anywhere):
 //   * it walks the tile's sorted list 64 entries at a time, reading the 32-bit list words itself (two batches
@@ -825,9 +800,7 @@ __global__ __launch_bounds__(64) void render_kernel(
                 if (!(s & 1)) { cp[(s + 1) * kPairQuads + 4] = z; cp[(s + 1) * kPairQuads + 5] = z; }  // unused second slot of the step
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();
         // Two slots (four survivors) per step: the two packed exponent/exp chains are independent, so the
         // scheduler interleaves them (no dependent-issue bubbles); the blend itself stays strictly in list order.
         const int nslots = (cnt + 1) >> 1;
@@ -872,8 +845,7 @@ __global__ __launch_bounds__(64) void render_kernel(
         }
 #undef FS_BLEND_ONE
         // (the next batch's compaction overwrites the slots: DS operations of one wavefront execute in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
