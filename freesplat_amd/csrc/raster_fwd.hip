@@ -991,3 +991,66 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     FS_CHECK_LAUNCH("render");
     return FS_OK;
 }
+
+// ---- all views of one call in ONE host call (decoder path) ---------------------------------------------------
+namespace fs {
+constexpr int kMaxStreams = 8;
+struct ForkJoin {  // cached events: fork `main` into the side streams, join them back
+    hipEvent_t ready = nullptr, done[kMaxStreams] = {};
+    bool ok = false;
+    ForkJoin()
+    {
+        ok = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < kMaxStreams && ok; ++i) ok = hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+    }
+};
+}  // namespace fs
+
+FS_API int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
+                                   const float* shs, const float* colors_precomp, const float* opacities,
+                                   const float* bg, const float* viewmatrix, const float* projmatrix,
+                                   const float* campos, const float* tanfov, const float* scale, void* geom,
+                                   void* binning, void* image, void* scratch, const size_t strides[4], int64_t cap,
+                                   float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                                   uint32_t* counters, int32_t n_streams, void* const* streams, void* main_stream)
+{
+    if (!dims || v < 0 || !strides || n_streams < 0 || n_streams > fs::kMaxStreams || (n_streams > 0 && !streams))
+        return FS_ERR_INVALID_ARG;
+    if (v == 0) return FS_OK;
+    if (!bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image || !scratch || !out_color ||
+        !out_depth || !out_alpha || !counters)
+        return FS_ERR_INVALID_ARG;
+    static thread_local fs::ForkJoin fj;
+    const int ns = n_streams <= 1 ? 0 : (n_streams < v ? n_streams : v);
+    hipStream_t main = (hipStream_t)main_stream;
+    if (ns > 0) {
+        if (!fj.ok) { set_last_error("event create", hipGetLastError()); return FS_ERR_LAUNCH; }
+        if (hipEventRecord(fj.ready, main) != hipSuccess) { set_last_error("event record", hipGetLastError()); return FS_ERR_LAUNCH; }
+        for (int s = 0; s < ns; ++s)
+            if (hipStreamWaitEvent((hipStream_t)streams[s], fj.ready, 0) != hipSuccess) {
+                set_last_error("stream wait", hipGetLastError());
+                return FS_ERR_LAUNCH;
+            }
+    }
+    const size_t P = (size_t)dims->H * dims->W;
+    int rc = FS_OK;
+    for (int i = 0; i < v && rc == FS_OK; ++i) {
+        const int s = ns > 0 ? i % ns : 0;
+        void* st = ns > 0 ? streams[s] : main_stream;
+        rc = fs_raster_forward(dims, means3D, cov3D, shs, colors_precomp, opacities, bg + 3 * (size_t)i,
+                               viewmatrix + 16 * (size_t)i, projmatrix + 16 * (size_t)i, campos + 3 * (size_t)i,
+                               tanfov ? tanfov + 2 * (size_t)i : nullptr, scale ? scale + i : nullptr,
+                               (char*)geom + strides[0] * i, (char*)binning + strides[1] * i,
+                               (char*)image + strides[2] * i, (char*)scratch + strides[3] * s, cap,
+                               out_color + 3 * P * i, out_depth + P * i, out_alpha + P * i,
+                               radii ? radii + (size_t)dims->N * i : nullptr, counters + 2 * (size_t)i, st);
+    }
+    for (int s = 0; s < ns; ++s) {  // join even after a failed launch: never leave `main` unordered
+        if (hipEventRecord(fj.done[s], (hipStream_t)streams[s]) != hipSuccess ||
+            hipStreamWaitEvent(main, fj.done[s], 0) != hipSuccess) {
+            set_last_error("stream join", hipGetLastError());
+            return FS_ERR_LAUNCH;
+        }
+    }
+    return rc;
+}

@@ -18,6 +18,8 @@ from dataclasses import dataclass
 from math import isqrt
 from typing import Optional
 
+import ctypes as C
+
 import torch
 from torch import Tensor, nn
 
@@ -193,7 +195,7 @@ class _RenderViews(torch.autograd.Function):
         alpha = torch.empty(v, h, w, dtype=torch.float32, device=dev)
         s0 = GaussianRasterizationSettings(h, w, 0.0, 0.0, None, 1.0, None, None, degree, None, False, False)
 
-        def launch(i, cap_i):
+        def launch(i, cap_i):   # single-view re-render (capacity overflow)
             dims = R.make_dims(N, shs.shape[2], s0, sh_fp16=shs.dtype == torch.float16, native_layout=True)
             rs, _, _, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i], fulls[i],
                                             campos[i], cap_i, tanfov=tanfov[i],
@@ -201,24 +203,38 @@ class _RenderViews(torch.autograd.Function):
                                             out=(color[i], depth[i], alpha[i]))
             return rs
 
+        # all v views in ONE library call (fs_raster_forward_views): per-view host work is a few pointer offsets
+        # instead of seven allocations and a 23-argument ctypes call, the views alternate over the side streams
+        # inside the library and are joined back into the current stream before the call returns
+        dims = R.make_dims(N, shs.shape[2], s0, sh_fp16=shs.dtype == torch.float16, native_layout=True)
         n_streams = min(R.NUM_STREAMS, v)
-        if n_streams > 1:
-            main = torch.cuda.current_stream()
-            while len(st.side_streams) < n_streams:
-                st.side_streams.append(torch.cuda.Stream(device=dev))
-            ready = torch.cuda.Event()
-            ready.record(main)
-            states = []
-            for i in range(v):
-                s = st.side_streams[i % n_streams]
-                if i < n_streams:
-                    s.wait_event(ready)     # inputs and output buffers were produced on `main`
-                with torch.cuda.stream(s):
-                    states.append(launch(i, cap))
-            for s in st.side_streams[:n_streams]:
-                main.wait_stream(s)
-        else:
-            states = [launch(i, cap) for i in range(v)]
+        while len(st.side_streams) < n_streams:
+            st.side_streams.append(torch.cuda.Stream(device=dev))
+        sz = R._buffer_sizes(N, h, w, cap)
+        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+        geom, binning, image = u8(v * sz[0]), u8(v * sz[1]), u8(v * sz[2])
+        scratch = u8(max(n_streams, 1) * sz[3])
+        radii = torch.empty(v, N, dtype=torch.int32, device=dev)
+        counters = torch.empty(v, 2, dtype=torch.int32, device=dev)
+        strides = (C.c_size_t * 4)(*sz)
+        handles = (C.c_void_p * max(n_streams, 1))(*[s.cuda_stream for s in st.side_streams[:n_streams]])
+        p = R._lib.ptr
+        if v > 0:
+            R._lib.check(R._lib.lib().fs_raster_forward_views(
+                C.byref(dims), v, p(means), p(cov6), p(shs), None, p(opac), p(bgs), p(views), p(fulls), p(campos),
+                p(tanfov), p(scale), p(geom), p(binning), p(image), p(scratch), strides, cap, p(color), p(depth),
+                p(alpha), p(radii), p(counters), n_streams if n_streams > 1 else 0, handles,
+                R._lib.current_stream()), "fs_raster_forward_views")
+        states = []
+        for i in range(v):
+            rs = R.RasterState()
+            rs.dims = dims
+            rs.geom, rs.binning, rs.image = (t[i * n:(i + 1) * n] for t, n in ((geom, sz[0]), (binning, sz[1]), (image, sz[2])))
+            rs.radii, rs.counters, rs.cap = radii[i], counters[i], cap
+            rs.bg, rs.view, rs.proj, rs.campos = bgs[i], views[i], fulls[i], campos[i]
+            rs.tanfov, rs.scale = tanfov[i], None if scale is None else scale[i]
+            rs.num_rendered = -1
+            states.append(rs)
         if deferred:
             _pending_checks.append(states)
         else:

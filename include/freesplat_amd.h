@@ -116,6 +116,22 @@ int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const fl
                       int64_t inst_capacity, float* out_color, float* out_depth, float* out_alpha,
                       int32_t* radii, uint32_t* counters, void* stream);
 
+/* v views of ONE Gaussian set in one host call (the decoder's path: decoder_splatting_cuda.py:55-75 renders
+ * v views per scene).  Per-view arrays are packed: bg [v,3], viewmatrix / projmatrix [v,16], campos [v,3],
+ * tanfov [v,2] | NULL, scale [v] | NULL (fs_frame_views fills all of them), out_color [v,3,H,W], out_depth /
+ * out_alpha [v,H,W], radii [v,N], counters [v,2].  geom / binning / image hold v buffers strides[0..2] bytes apart
+ * (>= the sizes of fs_raster_buffer_sizes), scratch one buffer of strides[3] bytes per stream.
+ * n_streams > 1: view i runs on streams[i % n_streams]; the call orders them after the work already queued on
+ * main_stream and orders main_stream after all of them (fork / join with events, no host sync), so to the caller
+ * the call is stream-ordered on main_stream like every other entry point.  n_streams <= 1: everything on main_stream. */
+int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
+                            const float* shs, const float* colors_precomp, const float* opacities,
+                            const float* bg, const float* viewmatrix, const float* projmatrix,
+                            const float* campos, const float* tanfov, const float* scale, void* geom,
+                            void* binning, void* image, void* scratch, const size_t strides[4], int64_t cap,
+                            float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                            uint32_t* counters, int32_t n_streams, void* const* streams, void* main_stream);
+
 /*
  * Backward.  dL_dcolor[3,H,W] (required), dL_ddepth[H,W] (may be NULL).  geom/binning/image
  * are the buffers filled by the matching forward.  `grad_scratch` >= N*12*4 bytes.
