@@ -59,6 +59,20 @@ __device__ __forceinline__ float fs_exp(float x)
     return ldexpf(p, (int)n);
 }
 
+// ---- phase timestamps inside kernels (debug builds: make EXTRA=-DFS_PHASE_TRACE; profiles/phase_trace.py) ----
+// FS_PT(kernel, k): thread 0 of the first 4096 workgroups stamps wall_clock64() (100 MHz) into slot k (< 8).
+#ifdef FS_PHASE_TRACE
+constexpr int kPtKernels = 4, kPtBlocks = 4096, kPtSlots = 8;
+static __device__ unsigned long long g_phase_trace[kPtKernels * kPtBlocks * kPtSlots];  // one per translation unit
+#define FS_PT(kern, k)                                                                                  \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < fs::kPtBlocks)                                             \
+            fs::g_phase_trace[((kern) * fs::kPtBlocks + blockIdx.x) * fs::kPtSlots + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define FS_PT(kern, k) do {} while (0)
+#endif
+
 // LDS operations of one wavefront execute in order: between phases of a wavefront-private LDS exchange only the
 // compiler must be kept from reordering them.
 __device__ __forceinline__ void wave_lds_sync()

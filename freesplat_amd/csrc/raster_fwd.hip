@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float tanfovy = tanfov_dev ? tanfov_dev[1] : d.tanfovy;
     const float wscale = scale_dev ? scale_dev[0] : 1.0f;  // scale-invariant rescale (1/near)
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    FS_PT(0, 0);
     const int base = blockIdx.x * 256;
     const int cnt = min(256, d.N - base);
     const int per_sh = d.M * 3;
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     stage_rows(l_cov, cov3D, base, cnt, per_cov);
     stage_rows(l_mean, means3D, base, cnt, 3);
     __syncthreads();
+    FS_PT(0, 1);  // inputs staged
     const int t = threadIdx.x;
     const bool live = t < cnt;
     const int i = base + t;
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             }
         }
     }
+    FS_PT(0, 2);  // projected
     if (live) {
         g.rec[3 * (size_t)i + 0] = r0;
         g.rec[3 * (size_t)i + 1] = r1;
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 
     // ---- per-tile instance counts (the staging LDS is dead from here on) ----
     __syncthreads();
+    FS_PT(0, 3);  // records written
     int* s_box = (int*)lds;
     uint32_t* s_cnt = (uint32_t*)lds + 16;
     const bool valid = rad > 0;
@@ -339,7 +343,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     unsigned long long qm = 0;
     if (valid && small) qm = pack_quad_masks(qf, r0, rect);
     if (live) g.qmask[i] = qm;
+    FS_PT(0, 4);  // quadrant masks
     const BinBox bb = block_bin_box(s_box, valid, rect);
+    FS_PT(0, 5);  // workgroup box
     if (bb.w * bb.h == 0) return;
     if (bb.lds) {
         for (int k = t; k < bb.w * bb.h; k += 256) s_cnt[k] = 0;
@@ -356,10 +362,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             }
         }
         __syncthreads();
+        FS_PT(0, 6);  // counted
         for (int k = t; k < bb.w * bb.h; k += 256) {
             const uint32_t c = s_cnt[k];
             if (c) atomicAdd(&tile_counts[(bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w], c);
         }
+        FS_PT(0, 7);  // flushed
     } else if (valid) {
         int k = 0;
         for (int y = rect.y; y < rect.w; ++y) {
@@ -421,6 +429,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
     __shared__ int s_box[8];
     __shared__ uint32_t s_cnt[kBinLds];   // per-tile count, then per-tile running rank
     __shared__ uint32_t s_base[kBinLds];  // first slot of this workgroup inside the tile's range
+    FS_PT(1, 0);
     const int t = threadIdx.x;
     const int i = blockIdx.x * 256 + t;
     const bool live = i < N;
@@ -441,10 +450,12 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
     QuadForm qf = {};
     if (valid && !small) qf = quad_form(r0, r1);
     const BinBox bb = block_bin_box(s_box, valid, rc);
+    FS_PT(1, 1);  // loaded + workgroup box
     if (bb.w * bb.h == 0) return;
     if (bb.lds) {
         for (int k = t; k < bb.w * bb.h; k += 256) s_cnt[k] = 0;
         __syncthreads();
+        FS_PT(1, 2);  // zeroed
         if (valid) {
             int k = 0;
             for (int y = rc.y; y < rc.w; ++y) {
@@ -457,6 +468,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
             }
         }
         __syncthreads();
+        FS_PT(1, 3);  // counted
         for (int k = t; k < bb.w * bb.h; k += 256) {
             const uint32_t c = s_cnt[k];
             const int tile = (bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w;
@@ -464,6 +476,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
             s_cnt[k] = 0;
         }
         __syncthreads();
+        FS_PT(1, 4);  // slots reserved
         if (valid) {
             int k = 0;
             for (int y = rc.y; y < rc.w; ++y) {
@@ -479,6 +492,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
                 }
             }
         }
+        FS_PT(1, 5);  // keys written
     } else if (valid) {
         int k = 0;
         for (int y = rc.y; y < rc.w; ++y) {
@@ -655,6 +669,7 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
     constexpr int E = 2 * EA, NA = 256 * EA, NB = 256 * EB;
     const int t = threadIdx.x;
     unsigned long long ka[EA], kb[EB];
+    FS_PT(2, 0);
 #pragma unroll
     for (int e = 0; e < EA; ++e) ka[e] = keys[t * EA + e];  // n > NA
 #pragma unroll
@@ -662,8 +677,11 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
         const uint32_t i = (uint32_t)(NA + t * EB + e);
         kb[e] = i < n ? keys[i] : ~0ull;
     }
+    FS_PT(2, 1);  // (loads issued)
     Stages<EA, NA>::run(ka, t, lds);
+    FS_PT(2, 2);  // first run sorted
     Stages<EB, NB>::run(kb, t, lds);
+    FS_PT(2, 3);  // second run sorted
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < EA; ++e) lds[t * EA + e] = ka[e];
@@ -676,13 +694,16 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
         const int i = t * E + e;
         k[e] = i < NA + NB ? lds[i] : ~0ull;
     }
+    FS_PT(2, 4);  // re-laid out
     thread_exchange<E, 255, true>(k, t, lds);  // flip step of the last stage: i <-> i ^ (512*EA - 1)
     Clean<E, 256 * E / 4>::run(k, t, lds);
+    FS_PT(2, 5);  // merged
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)t * E + e;
         if (i < n) out[i] = (uint32_t)k[e];
     }
+    FS_PT(2, 6);  // stored
 }
 
 __global__ __launch_bounds__(256) void tile_sort_kernel(int gx, int gy, const uint32_t* __restrict__ offsets,
@@ -1071,3 +1092,14 @@ FS_API int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const 
     }
     return rc;
 }
+
+#ifdef FS_PHASE_TRACE
+// debug builds only: copy out (and clear) the phase timestamps of this translation unit's kernels
+FS_API int fs_debug_phase_trace(unsigned long long* dst)
+{
+    static unsigned long long z[fs::kPtKernels * fs::kPtBlocks * fs::kPtSlots];
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(fs::g_phase_trace), sizeof(z)) != hipSuccess) return FS_ERR_LAUNCH;
+    return hipMemcpyToSymbol(HIP_SYMBOL(fs::g_phase_trace), z, sizeof(z)) == hipSuccess ? FS_OK : FS_ERR_LAUNCH;
+}
+#endif
+
