@@ -220,11 +220,14 @@ def committed_traffic(kernel: str):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
     if not files:
         return None, None
-    try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
-        return (float(k["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)) if k else (None, None)
-    except Exception:
-        return None, None
+    for f in reversed(files):   # newest summary that has this kernel (forward and backward are separate files)
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+        except Exception:
+            continue
+        if k:
+            return float(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload):
