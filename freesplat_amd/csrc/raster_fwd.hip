@@ -56,8 +56,16 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__
     const int total = cnt * per;
     if ((((uintptr_t)s) & 15) == 0) {
         const int nv = total >> 2;
-        for (int k = threadIdx.x; k < nv; k += blockDim.x)
-            ((float4*)lds)[k] = ((const float4*)s)[k];
+        // four 16-byte requests in flight per thread (a plain load -> LDS store loop keeps one: the wait for it was the
+        // longest phase of the kernel, profiles/phase_trace.py)
+        int k = threadIdx.x;
+        for (; k + 768 < nv; k += 1024) {
+            const float4 v0 = ((const float4*)s)[k], v1 = ((const float4*)s)[k + 256];
+            const float4 v2 = ((const float4*)s)[k + 512], v3 = ((const float4*)s)[k + 768];
+            ((float4*)lds)[k] = v0; ((float4*)lds)[k + 256] = v1;
+            ((float4*)lds)[k + 512] = v2; ((float4*)lds)[k + 768] = v3;
+        }
+        for (; k < nv; k += 256) ((float4*)lds)[k] = ((const float4*)s)[k];
         for (int k = (nv << 2) + threadIdx.x; k < total; k += blockDim.x) lds[k] = s[k];
     } else {
         for (int k = threadIdx.x; k < total; k += blockDim.x) lds[k] = s[k];
