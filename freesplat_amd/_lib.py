@@ -68,6 +68,8 @@ SIGNATURES = {
     "fs_ptf_gru_forward": (C.c_int, [C.c_int32] + [_VP] * 4),
     "fs_raster_forward_views": (C.c_int, [C.POINTER(RasterDims), C.c_int32] + [_VP] * 15 + [C.POINTER(C.c_size_t), C.c_int64]
                                 + [_VP] * 5 + [C.c_int32, C.POINTER(C.c_void_p), _VP]),
+    "fs_raster_backward_views": (C.c_int, [C.POINTER(RasterDims), C.c_int32] + [_VP] * 13 + [C.POINTER(C.c_size_t)] + [_VP] * 9
+                                 + [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _VP]),
     "fs_frame_views": (C.c_int, [C.c_int32] + [_VP] * 4 + [C.c_int32] + [_VP] * 6),
     "fs_depth_tail_forward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 7),
     "fs_depth_tail_backward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 13),

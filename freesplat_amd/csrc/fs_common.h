@@ -35,7 +35,7 @@ enum Stage {
     kStCostVolume, kStPtf, kNumStages
 };
 struct ScopedStage {
-    ScopedStage(Stage s, hipStream_t st);
+    ScopedStage(Stage s, hipStream_t st, int units = 1);  // units: views covered by the launch (reported as launches)
     ~ScopedStage();
     int slot_;
     hipStream_t st_;

@@ -15,16 +15,17 @@ void set_last_error(const char* what, hipError_t e)
 
 // ---- event-pair timing around kernel launches -------------------------------------------------
 static unsigned g_profile_mask = 0;  // bit i: stage i is timed
-struct Rec { int stage; hipEvent_t a, b; };
+struct Rec { int stage, units; hipEvent_t a, b; };
 static std::vector<Rec> g_recs;
 static std::mutex g_mu;
 
-ScopedStage::ScopedStage(Stage s, hipStream_t st) : slot_(-1), st_(st)
+ScopedStage::ScopedStage(Stage s, hipStream_t st, int units) : slot_(-1), st_(st)
 {
     if (!((g_profile_mask >> (int)s) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Rec r;
     r.stage = (int)s;
+    r.units = units;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
@@ -59,7 +60,7 @@ FS_API int fs_profile_collect(int n, float* ms_total, int32_t* launches)
     for (auto& r : fs::g_recs) {
         float ms = 0.0f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            if (r.stage < n) { ms_total[r.stage] += ms; launches[r.stage] += 1; }
+            if (r.stage < n) { ms_total[r.stage] += ms; launches[r.stage] += r.units; }
         } else {
             rc = FS_ERR_LAUNCH;
         }

@@ -3,12 +3,11 @@
 // Replaces the autograd backward of the CUDA extension FreeSplat uses
 // (src/model/decoder/cuda_splatting.py:114-127; semantics: SURVEY.md Appendix A.5).
 //
-//   render_bwd      1 workgroup / tile, back-to-front over the same sorted list.  Per-pixel
-//                   partials are summed across the 64 lanes of each wavefront in registers
-//                   (cross-lane butterflies), then across the 4 wavefronts with LDS float
-//                   atomics into a per-batch accumulator, and only then flushed to HBM:
-//                   one global atomic per (tile, Gaussian, component) instead of one per
-//                   (pixel, Gaussian, component).
+//   render_bwd      1 single-wavefront workgroup per 8x8 quadrant, back to front over the same sorted list,
+//                   survivors compacted in pairs (packed fp32); the per-pixel partials of a pair are summed over
+//                   the wavefront in registers (row-swap halving + in-row DPP adds) and leave as ONE global
+//                   atomic instruction per pair -- one atomic per (quadrant, Gaussian, component) instead of one
+//                   per (pixel, Gaussian, component).
 //   preprocess_bwd  1 thread / Gaussian: conic -> cov2D -> Sigma & view position, mean2D ->
 //                   mean through the perspective divide, RGB -> SH & view direction.
 //                   SH gradients leave through LDS so the [N, M, 3] rows are written coalesced.
@@ -19,30 +18,10 @@ namespace fs {
 constexpr int kGradStride = 12;  // floats per Gaussian in the accumulation scratch
 // layout: 0,1 mean2D | 2,3,4 conic (x, y(half), z) | 5 opacity | 6,7,8 rgb | 9 view z | 10,11 pad
 
-// ---- cross-lane exchange with lane ^ M without touching LDS memory where the ISA allows ----
-template <int M>
-__device__ __forceinline__ float xchg(float v)
-{
-    const int i = __float_as_int(v);
-    if constexpr (M == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-    else if constexpr (M == 32) return __shfl_xor(v, 32, 64);
-    else return __int_as_float(__builtin_amdgcn_ds_swizzle(i, (M << 10) | 0x1F));                          // bit-mode xor M
-}
-
-// Sum 10 per-lane values over the 64 lanes of a wavefront in 28 instructions.  Two HALVING levels on the gfx950
-// row-swap instructions: v_permlane32_swap(X, Y) leaves X+Y = (value X summed over lanes l, l+32) in the lower half
-// and (value Y ...) in the upper half -- one swap + one add per surviving value -- and v_permlane16_swap does the
-// same between the two 16-lane rows of each half.  10 values -> 5 per half -> 3 registers per row; the rest of the
-// reduction stays inside a row: 4 adds with a DPP row rotation folded in (row_ror 8, 4, 2, 1) per register.
-// Afterwards EVERY lane of row r holds the complete sums of that row's (up to) 3 values; wave_value_index() says
-// which value lane (r, j) owns (-1: none).
-__device__ __forceinline__ int wave_value_index(int lane)
-{
-    const int j = lane & 15, row = (lane >> 4) & 1, half = lane >> 5;
-    if (j > 2 || (row == 1 && j == 2)) return -1;
-    return 5 * half + 3 * row + j;
-}
+// Wavefront sums on the gfx950 row-swap instructions: v_permlane32_swap(X, Y) leaves X+Y = (value X summed over lanes
+// l, l+32) in the lower half and (value Y ...) in the upper half -- one swap + one add per surviving value, a HALVING
+// level -- and v_permlane16_swap does the same between the two 16-lane rows of each half.  What is left is summed
+// inside a row with 4 adds that have a DPP row rotation folded in (row_ror 8, 4, 2, 1).
 __device__ __forceinline__ float swap_add32(float x, float y)
 {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -65,19 +44,6 @@ __device__ __forceinline__ float row_sum(float v)
     v = row_add<0x122>(v);  // row_ror:2
     return row_add<0x121>(v);  // row_ror:1
 }
-__device__ __forceinline__ float wave_sum10(const float (&v)[10], int lane)
-{
-    float a[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) a[k] = swap_add32(v[k], v[5 + k]);  // lower half: values 0..4, upper half: 5..9
-    // row 0 of a half keeps a[0..2], row 1 a[3], a[4] (and a zero)
-    const float c0 = row_sum(swap_add16(a[0], a[3]));
-    const float c1 = row_sum(swap_add16(a[1], a[4]));
-    const float c2 = row_sum(swap_add16(a[2], 0.0f));
-    const int j = lane & 15;
-    return j == 0 ? c0 : (j == 1 ? c1 : c2);
-}
-
 // Sum 20 per-lane values -- 10 of survivor a, 10 of survivor b -- over the wavefront in 50 instructions: the first
 // halving level puts a's sums into the lower half and b's into the upper half (swap_add32), the second leaves
 // values 0..4 in the even row and 5..9 in the odd row of each half (swap_add16), the rest is in-row (row_sum).
@@ -278,7 +244,7 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float 
 #pragma unroll
     for (int k = 0; k < NB; ++k)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gsh[3 * k + c] = b[k] * gr[c];
+        for (int c = 0; c < 3; ++c) gsh[3 * k + c] += b[k] * gr[c];
     float dbx[16], dby[16], dbz[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) dbx[k] = dby[k] = dbz[k] = 0.0f;
@@ -310,11 +276,16 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float 
     }
 }
 
+// V views of one Gaussian set per launch: the inputs are loaded once and the gradients of all views are summed in
+// registers before the single write (per view only the 48-byte record, the tile rect and the 48-byte screen-space
+// gradient row are read).  view / proj [V,16], campos [V,3], tanfov [V,2] | NULL, scale [V] | NULL; geom and grad
+// hold V buffers geom_stride / grad_stride bytes apart.  `accumulate` adds to what the outputs already hold.
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
-    fs_raster_dims d, const float* __restrict__ means3D, const float* __restrict__ cov3D,
-    const float* __restrict__ shs, const float* __restrict__ view, const float* __restrict__ proj,
-    const float* __restrict__ campos, const float* __restrict__ tanfov_dev,
-    const float* __restrict__ scale_dev, GeomView g, const float* __restrict__ grad,
+    fs_raster_dims d, int V, const float* __restrict__ means3D, const float* __restrict__ cov3D,
+    const float* __restrict__ shs, const float* __restrict__ view_all, const float* __restrict__ proj_all,
+    const float* __restrict__ campos_all, const float* __restrict__ tanfov_dev,
+    const float* __restrict__ scale_dev, const char* __restrict__ geom_base, size_t geom_stride,
+    const char* __restrict__ grad_base, size_t grad_stride,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac,
     int accumulate)
@@ -328,28 +299,53 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const bool have_sh = shs != nullptr;
     const bool sh_cm = (d.flags & FS_RASTER_SH_CHANNEL_MAJOR) != 0, cov_full = (d.flags & FS_RASTER_COV_FULL) != 0;
     constexpr int kTriu[6] = {0, 1, 2, 4, 5, 8};
-    const float tanfovx = tanfov_dev ? tanfov_dev[0] : d.tanfovx;
-    const float tanfovy = tanfov_dev ? tanfov_dev[1] : d.tanfovy;
-    const float wscale = scale_dev ? scale_dev[0] : 1.0f;
 
     if (t < cnt) {
-        float gm[3] = {0, 0, 0}, gcov[6] = {0, 0, 0, 0, 0, 0}, gop = 0.0f;
-        float gm2x = 0.0f, gm2y = 0.0f;
+        // sums over the views
+        float am[3] = {0, 0, 0}, acov[6] = {0, 0, 0, 0, 0, 0}, aop = 0.0f, am2x = 0.0f, am2y = 0.0f;
         float gsh[48];
-        float gcol[3] = {0, 0, 0};
+        float acol[3] = {0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 48; ++k) gsh[k] = 0.0f;
+        // inputs, once
+        const float3 p0 = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+        float c0[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c0[k] = cov_full ? cov3D[9 * (size_t)i + kTriu[k]] : cov3D[6 * (size_t)i + k];
+        float shbuf[48];
+        if (have_sh) {
+            if (d.flags & FS_RASTER_SH_FP16) {
+                const _Float16* hsrc = (const _Float16*)shs + (size_t)i * per_sh;
+#pragma unroll
+                for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? (float)hsrc[sh_cm ? (k % 3) * d.M + k / 3 : k] : 0.0f;
+            } else {
+                const float* fsrc = shs + (size_t)i * per_sh;
+#pragma unroll
+                for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? fsrc[sh_cm ? (k % 3) * d.M + k / 3 : k] : 0.0f;
+            }
+        }
+      for (int vi = 0; vi < V; ++vi) {
+        const float* view = view_all + 16 * vi;
+        const float* proj = proj_all + 16 * vi;
+        const float* campos = campos_all + 3 * vi;
+        const float tanfovx = tanfov_dev ? tanfov_dev[2 * vi] : d.tanfovx;
+        const float tanfovy = tanfov_dev ? tanfov_dev[2 * vi + 1] : d.tanfovy;
+        const float wscale = scale_dev ? scale_dev[vi] : 1.0f;
+        const GeomView g = geom_view((void*)(geom_base + geom_stride * vi), d.N > 0 ? d.N : 1);
+        const float* grad = (const float*)(grad_base + grad_stride * vi);
+        float gm[3] = {0, 0, 0}, gcov[6] = {0, 0, 0, 0, 0, 0};
         const ushort4 rc = g.rect[i];
         if (rc.z > rc.x && rc.w > rc.y) {
             const float* ga = grad + (size_t)i * kGradStride;
-            float3 p = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+            float3 p = p0;
             if (scale_dev) { p.x = p.x * wscale; p.y = p.y * wscale; p.z = p.z * wscale; }
-            gop = ga[5];
-            gm2x = ga[0]; gm2y = ga[1];
+            aop += ga[5];
+            const float gm2x = ga[0], gm2y = ga[1];
+            am2x += gm2x; am2y += gm2y;
             const float fx = (float)d.W / (2.0f * tanfovx), fy = (float)d.H / (2.0f * tanfovy);
             float c3[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) c3[k] = cov_full ? cov3D[9 * (size_t)i + kTriu[k]] : cov3D[6 * (size_t)i + k];
+            for (int k = 0; k < 6; ++k) c3[k] = c0[k];
             if (scale_dev) {
                 const float s2 = wscale * wscale;
 #pragma unroll
@@ -409,7 +405,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 gm[2] += (proj[8] * mw - proj[11] * mul1) * gm2x + (proj[9] * mw - proj[11] * mul2) * gm2y;
             }
             if (!have_sh) {
-                gcol[0] = ga[6]; gcol[1] = ga[7]; gcol[2] = ga[8];
+                acol[0] += ga[6]; acol[1] += ga[7]; acol[2] += ga[8];
             } else {
                 const uint8_t cb = g.clamp[i];
                 float gr[3];
@@ -418,17 +414,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 const float dox = p.x - campos[0], doy = p.y - campos[1], doz = p.z - campos[2];
                 const float len = sqrtf(dox * dox + doy * doy + doz * doz);
                 const float x = dox / len, y = doy / len, z = doz / len;
-                float shbuf[48];
                 const float* sh = shbuf;
-                if (d.flags & FS_RASTER_SH_FP16) {
-                    const _Float16* hsrc = (const _Float16*)shs + (size_t)i * per_sh;
-#pragma unroll
-                    for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? (float)hsrc[sh_cm ? (k % 3) * d.M + k / 3 : k] : 0.0f;
-                } else {
-                    const float* fsrc = shs + (size_t)i * per_sh;
-#pragma unroll
-                    for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? fsrc[sh_cm ? (k % 3) * d.M + k / 3 : k] : 0.0f;
-                }
                 float gdv[3];
                 switch (d.sh_degree) {
                     case 0: sh_backward<0>(sh, x, y, z, gr, gsh, gdv); break;
@@ -443,40 +429,41 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 gm[2] += (-dox * doz * gdv[0] - doy * doz * gdv[1] + (s2 - doz * doz) * gdv[2]) * inv32;
             }
         }
-        if (scale_dev) {
+        {   // (the 1/near rescale of this view: d mean' / d mean = s, d cov' / d cov = s^2)
             const float s2 = wscale * wscale;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gm[k] = gm[k] * wscale;
+            for (int k = 0; k < 3; ++k) am[k] += scale_dev ? gm[k] * wscale : gm[k];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) gcov[k] = gcov[k] * s2;
+            for (int k = 0; k < 6; ++k) acov[k] += scale_dev ? gcov[k] * s2 : gcov[k];
         }
+      }  // views
         if (accumulate) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gm[k] += dL_dmeans3D[3 * (size_t)i + k];
-            gm2x += dL_dmeans2D[3 * (size_t)i];
-            gm2y += dL_dmeans2D[3 * (size_t)i + 1];
+            for (int k = 0; k < 3; ++k) am[k] += dL_dmeans3D[3 * (size_t)i + k];
+            am2x += dL_dmeans2D[3 * (size_t)i];
+            am2y += dL_dmeans2D[3 * (size_t)i + 1];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) gcov[k] += cov_full ? dL_dcov3D[9 * (size_t)i + kTriu[k]] : dL_dcov3D[6 * (size_t)i + k];
-            gop += dL_dopac[i];
+            for (int k = 0; k < 6; ++k) acov[k] += cov_full ? dL_dcov3D[9 * (size_t)i + kTriu[k]] : dL_dcov3D[6 * (size_t)i + k];
+            aop += dL_dopac[i];
             if (!have_sh) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) gcol[k] += dL_dcolors[3 * (size_t)i + k];
+                for (int k = 0; k < 3; ++k) acol[k] += dL_dcolors[3 * (size_t)i + k];
             }
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * (size_t)i + k] = gm[k];
-        dL_dmeans2D[3 * (size_t)i] = gm2x;
-        dL_dmeans2D[3 * (size_t)i + 1] = gm2y;
+        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * (size_t)i + k] = am[k];
+        dL_dmeans2D[3 * (size_t)i] = am2x;
+        dL_dmeans2D[3 * (size_t)i + 1] = am2y;
         dL_dmeans2D[3 * (size_t)i + 2] = 0.0f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            if (cov_full) dL_dcov3D[9 * (size_t)i + kTriu[k]] = gcov[k];
-            else dL_dcov3D[6 * (size_t)i + k] = gcov[k];
+            if (cov_full) dL_dcov3D[9 * (size_t)i + kTriu[k]] = acov[k];
+            else dL_dcov3D[6 * (size_t)i + k] = acov[k];
         }
         if (cov_full) {  // the reference reads the upper triangle only (cuda_splatting.py:126): no gradient below it
             dL_dcov3D[9 * (size_t)i + 3] = 0.0f; dL_dcov3D[9 * (size_t)i + 6] = 0.0f; dL_dcov3D[9 * (size_t)i + 7] = 0.0f;
         }
-        dL_dopac[i] = gop;
+        dL_dopac[i] = aop;
         if (have_sh) {
             // gsh[] beyond the active degree is still zero; static indices keep it in registers
 #pragma unroll
@@ -484,7 +471,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 if (k < per_sh) lds[t * per_sh + (sh_cm ? (k % 3) * d.M + k / 3 : k)] = gsh[k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dL_dcolors[3 * (size_t)i + k] = gcol[k];
+            for (int k = 0; k < 3; ++k) dL_dcolors[3 * (size_t)i + k] = acol[k];
         }
     }
     if (have_sh) {
@@ -501,6 +488,54 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 }  // namespace fs
 
 using namespace fs;
+
+namespace {
+
+// blend backward of ONE view into its screen-space gradient rows (grad [N, 12], zeroed here)
+int launch_render_bwd(const fs_raster_dims& d, const float* bg, const void* geom, const void* binning, const void* image,
+                      const float* dL_dcolor, const float* dL_ddepth, float* grad, hipStream_t st)
+{
+    const int T = num_tiles(d.H, d.W);
+    const size_t P = (size_t)d.H * d.W;
+    const GeomView g = geom_view(const_cast<void*>(geom), d.N);
+    const uint32_t* offsets = (const uint32_t*)binning;
+    const uint32_t* point_list = (const uint32_t*)((const char*)binning + binning_offsets_bytes(d.H, d.W));
+    const float* final_T = (const float*)image;
+    const int32_t* n_contrib = (const int32_t*)((const char*)image + align_up(P * 4, 256));
+    if (hipMemsetAsync(grad, 0, (size_t)d.N * kGradStride * 4, st) != hipSuccess) {
+        set_last_error("memset grad scratch", hipGetLastError());
+        return FS_ERR_LAUNCH;
+    }
+    const int nblk = tile_grid_blocks((d.W + kTile - 1) / kTile, (d.H + kTile - 1) / kTile);
+    {
+        ScopedStage prof_(kStRenderBwd, st);
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
+                           point_list, g.rec, bg, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
+    }
+    FS_CHECK_LAUNCH("render_bwd");
+    return FS_OK;
+}
+
+// screen space -> Gaussian parameters for V views at once (gradients summed over the views)
+int launch_preprocess_bwd(const fs_raster_dims& d, int V, const float* means3D, const float* cov3D, const float* shs,
+                          const float* view, const float* proj, const float* campos, const float* tanfov,
+                          const float* scale, const void* geom, size_t geom_stride, const void* grad, size_t grad_stride,
+                          float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs, float* dL_dcolors,
+                          float* dL_dopacities, int accumulate, hipStream_t st)
+{
+    const size_t lds = shs ? (size_t)256 * d.M * 3 * sizeof(float) : 0;
+    {
+        ScopedStage prof_(kStPreprocessBwd, st, V);
+        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, V, means3D, cov3D, shs,
+                           view, proj, campos, tanfov, scale, (const char*)geom, geom_stride, (const char*)grad,
+                           grad_stride, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs, dL_dcolors, dL_dopacities,
+                           accumulate);
+    }
+    FS_CHECK_LAUNCH("preprocess_bwd");
+    return FS_OK;
+}
+
+}  // namespace
 
 FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
                               const float* shs, const float* colors_precomp, const float* bg,
@@ -522,33 +557,79 @@ FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, 
     if (d.N <= 0) return FS_OK;
     if (shs && d.M * 3 > 48) return FS_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream_;
-    const int T = num_tiles(d.H, d.W);
-    const size_t P = (size_t)d.H * d.W;
-    GeomView g = geom_view(const_cast<void*>(geom), d.N);
-    const uint32_t* offsets = (const uint32_t*)binning;
-    const uint32_t* point_list = (const uint32_t*)((const char*)binning + binning_offsets_bytes(d.H, d.W));
-    const float* final_T = (const float*)image;
-    const int32_t* n_contrib = (const int32_t*)((const char*)image + align_up(P * 4, 256));
-    float* grad = (float*)grad_scratch;
-    if (hipMemsetAsync(grad, 0, (size_t)d.N * kGradStride * 4, st) != hipSuccess) {
-        set_last_error("memset grad scratch", hipGetLastError());
-        return FS_ERR_LAUNCH;
-    }
-    const int nblk = tile_grid_blocks((d.W + kTile - 1) / kTile, (d.H + kTile - 1) / kTile);
+    int rc = launch_render_bwd(d, bg, geom, binning, image, dL_dcolor, dL_ddepth, (float*)grad_scratch, st);
+    if (rc != FS_OK) return rc;
+    return launch_preprocess_bwd(d, 1, means3D, cov3D, shs, viewmatrix, projmatrix, campos, tanfov_dev, scale_dev, geom, 0,
+                                 grad_scratch, 0, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs, dL_dcolors,
+                                 dL_dopacities, accumulate, st);
+}
+
+namespace {
+constexpr int kMaxStreamsBwd = 8;
+struct ForkJoinBwd {
+    hipEvent_t ready = nullptr, done[kMaxStreamsBwd] = {};
+    bool ok = false;
+    ForkJoinBwd()
     {
-        ScopedStage prof_(kStRenderBwd, st);
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
-                           point_list, g.rec, bg, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
+        ok = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < kMaxStreamsBwd && ok; ++i)
+            ok = hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
     }
-    FS_CHECK_LAUNCH("render_bwd");
-    const size_t lds = shs ? (size_t)256 * d.M * 3 * sizeof(float) : 0;
-    {
-        ScopedStage prof_(kStPreprocessBwd, st);
-        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, means3D,
-                           cov3D, shs, viewmatrix, projmatrix, campos, tanfov_dev, scale_dev, g, grad, dL_dmeans3D,
-                           dL_dmeans2D,
-                           dL_dcov3D, dL_dshs, dL_dcolors, dL_dopacities, accumulate);
+};
+}  // namespace
+
+FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
+                                    const float* shs, const float* colors_precomp, const float* bg,
+                                    const float* viewmatrix, const float* projmatrix, const float* campos,
+                                    const float* tanfov, const float* scale, const void* geom, const void* binning,
+                                    const void* image, const size_t strides[3], const float* dL_dcolor,
+                                    const float* dL_ddepth, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
+                                    float* dL_dcov3D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
+                                    int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream)
+{
+    if (!dims || v < 0 || !strides || n_streams < 0 || n_streams > kMaxStreamsBwd || (n_streams > 0 && !streams))
+        return FS_ERR_INVALID_ARG;
+    if (v == 0) return FS_OK;
+    if (!means3D || !cov3D || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
+        !dL_dcolor || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D || !dL_dcov3D || !dL_dopacities)
+        return FS_ERR_INVALID_ARG;
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return FS_ERR_INVALID_ARG;
+    if (shs ? !dL_dshs : !dL_dcolors) return FS_ERR_INVALID_ARG;
+    const fs_raster_dims d = *dims;
+    if (d.N <= 0) return FS_OK;
+    if (shs && d.M * 3 > 48) return FS_ERR_UNSUPPORTED;
+    static thread_local ForkJoinBwd fj;
+    const int ns = n_streams <= 1 ? 0 : (n_streams < v ? n_streams : v);
+    hipStream_t main = (hipStream_t)main_stream;
+    if (ns > 0) {
+        if (!fj.ok || hipEventRecord(fj.ready, main) != hipSuccess) {
+            set_last_error("event record", hipGetLastError());
+            return FS_ERR_LAUNCH;
+        }
+        for (int s = 0; s < ns; ++s)
+            if (hipStreamWaitEvent((hipStream_t)streams[s], fj.ready, 0) != hipSuccess) {
+                set_last_error("stream wait", hipGetLastError());
+                return FS_ERR_LAUNCH;
+            }
     }
-    FS_CHECK_LAUNCH("preprocess_bwd");
-    return FS_OK;
+    const size_t P = (size_t)d.H * d.W, grad_stride = align_up((size_t)d.N * kGradStride * 4, 256);
+    int rc = FS_OK;
+    for (int i = 0; i < v && rc == FS_OK; ++i) {  // the blend backward of every view, alternating over the streams
+        hipStream_t st = ns > 0 ? (hipStream_t)streams[i % ns] : main;
+        rc = launch_render_bwd(d, bg + 3 * (size_t)i, (const char*)geom + strides[0] * i,
+                               (const char*)binning + strides[1] * i, (const char*)image + strides[2] * i,
+                               dL_dcolor + 3 * P * i, dL_ddepth ? dL_ddepth + P * i : nullptr,
+                               (float*)((char*)grad_scratch + grad_stride * i), st);
+    }
+    for (int s = 0; s < ns; ++s)
+        if (hipEventRecord(fj.done[s], (hipStream_t)streams[s]) != hipSuccess ||
+            hipStreamWaitEvent(main, fj.done[s], 0) != hipSuccess) {
+            set_last_error("stream join", hipGetLastError());
+            return FS_ERR_LAUNCH;
+        }
+    if (rc != FS_OK) return rc;
+    // one pass over the Gaussians for all views
+    return launch_preprocess_bwd(d, v, means3D, cov3D, shs, viewmatrix, projmatrix, campos, tanfov, scale, geom,
+                                 strides[0], grad_scratch, grad_stride, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs,
+                                 dL_dcolors, dL_dopacities, accumulate, main);
 }

@@ -235,6 +235,9 @@ class _RenderViews(torch.autograd.Function):
             rs.tanfov, rs.scale = tanfov[i], None if scale is None else scale[i]
             rs.num_rendered = -1
             states.append(rs)
+        # everything the one-call backward needs while the views still live in the strided buffers of this call
+        batch = dict(dims=dims, sz=sz, geom=geom, binning=binning, image=image, bgs=bgs, views=views, fulls=fulls,
+                     campos=campos, tanfov=tanfov, scale=scale)
         if deferred:
             _pending_checks.append(states)
         else:
@@ -244,10 +247,12 @@ class _RenderViews(torch.autograd.Function):
                 n_inst &= 0xFFFFFFFF
                 if overflow:
                     states[i] = launch(i, n_inst + 1024)
+                    batch = None        # that view now lives in its own buffers: backward goes view by view
                 states[i].num_rendered = n_inst
                 worst = max(worst, n_inst)
             st.last_instances = worst
         ctx.states = states
+        ctx.batch = batch
         ctx.save_for_backward(means, cov6, shs)
         ctx.set_materialize_grads(False)
         return color, depth
@@ -263,35 +268,31 @@ class _RenderViews(torch.autograd.Function):
             g_color = g_color.contiguous()
         if g_depth is not None:
             g_depth = g_depth.contiguous()
-        view_grads = lambda i: (None if g_color is None else g_color[i], None if g_depth is None else g_depth[i])
-        if n_streams > 1:
-            # as in the forward: views alternate over the streams; every stream sums its views into its own set of
-            # gradient tensors (the per-Gaussian accumulation is ordered inside a stream), the sets are added at the end
-            st = R._state(means.device)
-            main = torch.cuda.current_stream()
+        dev = means.device
+        N = means.shape[0]
+        if ctx.batch is not None and N > 0:
+            # one library call: the blend backward of the views alternates over the side streams, then ONE pass
+            # over the Gaussians sums the parameter gradients of all views (fs_raster_backward_views)
+            b = ctx.batch
+            st = R._state(dev)
             while len(st.side_streams) < n_streams:
-                st.side_streams.append(torch.cuda.Stream(device=means.device))
-            ready = torch.cuda.Event()
-            ready.record(main)
-            outs = [None] * n_streams
-            for i, rs in enumerate(ctx.states):
-                s = st.side_streams[i % n_streams]
-                if i < n_streams:
-                    s.wait_event(ready)
-                with torch.cuda.stream(s):
-                    outs[i % n_streams] = R.rasterize_backward(rs, means, cov6, shs, None, *view_grads(i),
-                                                               out=outs[i % n_streams], accumulate=i >= n_streams)
-            for s in st.side_streams[:n_streams]:
-                main.wait_stream(s)
-            out = outs[0]
-            for t in out.values():
-                if t is not None:
-                    t.record_stream(main)       # allocated under a side stream, handed to autograd on `main`
-            for o in outs[1:]:
-                for k in ("means3D", "cov3D", "shs", "opacities"):
-                    out[k] += o[k]
-                    o[k].record_stream(main)
+                st.side_streams.append(torch.cuda.Stream(device=dev))
+            if g_color is None:
+                g_color = torch.zeros(v, 3, b["dims"].H, b["dims"].W, dtype=torch.float32, device=dev)
+            f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+            out = dict(means3D=f32(N, 3), means2D=f32(N, 3), cov3D=f32(*cov6.shape), shs=f32(*shs.shape), opacities=f32(N))
+            scratch = torch.empty(v * ((N * 48 + 255) // 256 * 256), dtype=torch.uint8, device=dev)
+            strides = (C.c_size_t * 3)(*b["sz"][:3])
+            handles = (C.c_void_p * max(n_streams, 1))(*[s.cuda_stream for s in st.side_streams[:n_streams]])
+            p = R._lib.ptr
+            R._lib.check(R._lib.lib().fs_raster_backward_views(
+                C.byref(b["dims"]), v, p(means), p(cov6), p(shs), None, p(b["bgs"]), p(b["views"]), p(b["fulls"]),
+                p(b["campos"]), p(b["tanfov"]), p(b["scale"]), p(b["geom"]), p(b["binning"]), p(b["image"]), strides,
+                p(g_color), p(g_depth), p(scratch), p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]), p(out["shs"]),
+                None, p(out["opacities"]), 0, n_streams if n_streams > 1 else 0, handles, R._lib.current_stream()),
+                "fs_raster_backward_views")
         else:
+            view_grads = lambda i: (None if g_color is None else g_color[i], None if g_depth is None else g_depth[i])
             out = None
             for i, rs in enumerate(ctx.states):
                 out = R.rasterize_backward(rs, means, cov6, shs, None, *view_grads(i), out=out, accumulate=i > 0)

@@ -309,6 +309,21 @@ int fs_depth_tail_backward(int32_t B, int32_t D, int32_t h2, int32_t w2, const f
                            const float* g_map, const float* g_weights, float* scratch_gE,
                            float* scratch_gprob, float* g_logits, void* stream);
 
+/* Backward of v views of ONE Gaussian set in one host call (counterpart of fs_raster_forward_views; same packed
+ * per-view arrays and buffer strides[0..2] = geom / binning / image).  dL_dcolor [v,3,H,W], dL_ddepth [v,H,W] | NULL.
+ * grad_scratch: v buffers of align_up(N*48, 256) bytes.  The blend backward of the views alternates over the
+ * streams; after the join ONE pass over the Gaussians turns the screen-space gradients of all views into the
+ * parameter gradients (inputs read once, sums in registers, outputs written once; `accumulate` adds to their
+ * current contents).  Stream-ordered on main_stream like fs_raster_forward_views. */
+int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
+                             const float* shs, const float* colors_precomp, const float* bg,
+                             const float* viewmatrix, const float* projmatrix, const float* campos,
+                             const float* tanfov, const float* scale, const void* geom, const void* binning,
+                             const void* image, const size_t strides[3], const float* dL_dcolor,
+                             const float* dL_ddepth, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
+                             float* dL_dcov3D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
+                             int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream);
+
 /* Debug/test accessors into the opaque buffers (device pointers, no copies). */
 const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t H, int32_t W);  /* [T+1] offsets */
 const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] (id << 4) | 8x8-quadrant mask */
