@@ -9,7 +9,7 @@
 // The reference materialises the softmax ([B,D,h/2,w/2]) and its x2-upsampled copy ([B,D,h,w], 200 MB at
 // the native 2 x 128 x 384 x 512) just to take a max; here the logits are read once for the expectation
 // (online softmax) and the upsampled probabilities are formed on the fly from the 4 neighbours' logits
-// and softmax statistics.  HBM-bound: algorithmic bytes = 4 * B*D*h2*w2 (logits) + O(B*h*w).
+// and softmax statistics (per tile of fine pixels, through LDS).  HBM-bound: algorithmic bytes = 4 * B*D*h2*w2 (logits) + O(B*h*w).
 #include "fs_common.h"
 
 namespace fs {
@@ -57,7 +57,11 @@ __device__ __forceinline__ Bilin bilin_x2(int y, int x, int h2, int w2)
     return o;
 }
 
-// one thread per fine pixel
+// One workgroup per 32 x 8 tile of fine pixels.  The tile's coarse footprint (<= 18 x 6 pixels) has its
+// probabilities exp(l - m) / s formed ONCE per plane in LDS, 16 planes at a time, and every fine pixel then takes its
+// bilinear combination from LDS: 0.4 exponentials per fine pixel and plane instead of 4, and the logits are read
+// once per tile footprint instead of four times per fine pixel.
+constexpr int kUpW = 32, kUpH = 8, kUpPlanes = 16, kUpPatch = 18 * 6;
 __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h2, int w2,
                                                              const float* __restrict__ logits,
                                                              const float* __restrict__ stats,
@@ -65,29 +69,55 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
                                                              float* __restrict__ depth_map,
                                                              float* __restrict__ depth_w, int32_t* __restrict__ argmax)
 {
+    __shared__ float s_p[kUpPlanes][kUpPatch];
+    __shared__ float s_m[kUpPatch], s_rs[kUpPatch];
     const int H = 2 * h2, W = 2 * w2, hw = h2 * w2;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)B * H * W) return;
-    const int b = (int)(e / ((long long)H * W)), r = (int)(e % ((long long)H * W));
-    const Bilin q = bilin_x2(r / W, r % W, h2, w2);
-    const float* c = coarse + (size_t)b * hw;
-    const float fine = q.w00 * c[q.i00] + q.w01 * c[q.i01] + q.w10 * c[q.i10] + q.w11 * c[q.i11];
-    depth_map[e] = log_planes ? expf(fine) : 1.0f / fine;
+    const int b = blockIdx.z, t = threadIdx.x;
+    const int X0 = blockIdx.x * kUpW, Y0 = blockIdx.y * kUpH;
+    const int x = X0 + (t & 31), y = Y0 + (t >> 5);
+    const bool in = x < W && y < H;
+    // coarse footprint of the tile (same source-coordinate arithmetic as bilin_x2)
+    const float ry = h2 > 1 ? (float)(h2 - 1) / (float)(2 * h2 - 1) : 0.0f, rx = w2 > 1 ? (float)(w2 - 1) / (float)(2 * w2 - 1) : 0.0f;
+    const int cy0 = min((int)((float)Y0 * ry), h2 - 1), cx0 = min((int)((float)X0 * rx), w2 - 1);
+    const int cy1 = min(min((int)((float)min(Y0 + kUpH - 1, H - 1) * ry), h2 - 1) + 1, h2 - 1);
+    const int cx1 = min(min((int)((float)min(X0 + kUpW - 1, W - 1) * rx), w2 - 1) + 1, w2 - 1);
+    const int pw = cx1 - cx0 + 1, ph = cy1 - cy0 + 1, np = pw * ph;  // <= 18 x 6
     const float* m = stats + (size_t)b * 2 * hw;
     const float* s = m + hw;
-    const float m00 = m[q.i00], m01 = m[q.i01], m10 = m[q.i10], m11 = m[q.i11];
-    const float k00 = q.w00 / s[q.i00], k01 = q.w01 / s[q.i01], k10 = q.w10 / s[q.i10], k11 = q.w11 / s[q.i11];
+    for (int k = t; k < np; k += 256) {
+        const int ci = (cy0 + k / pw) * w2 + cx0 + k % pw;
+        s_m[k] = m[ci];
+        s_rs[k] = 1.0f / s[ci];
+    }
+    const Bilin q = bilin_x2(in ? y : 0, in ? x : 0, h2, w2);
+    // patch-local indices of the four taps
+    const int l00 = (q.i00 / w2 - cy0) * pw + (q.i00 % w2 - cx0), l01 = (q.i01 / w2 - cy0) * pw + (q.i01 % w2 - cx0);
+    const int l10 = (q.i10 / w2 - cy0) * pw + (q.i10 % w2 - cx0), l11 = (q.i11 / w2 - cy0) * pw + (q.i11 % w2 - cx0);
     const float* l = logits + (size_t)b * D * hw;
     float best = -1.0f;
     int bi = 0;
-    for (int d = 0; d < D; ++d) {
-        const float* ld = l + (size_t)d * hw;
-        const float v = k00 * expf(ld[q.i00] - m00) + k01 * expf(ld[q.i01] - m01) + k10 * expf(ld[q.i10] - m10) +
-                        k11 * expf(ld[q.i11] - m11);
-        if (v > best) { best = v; bi = d; }
+    for (int d0 = 0; d0 < D; d0 += kUpPlanes) {
+        __syncthreads();  // (also orders the s_m / s_rs fill before their first use)
+        const int nd = min(kUpPlanes, D - d0);
+        for (int k = t; k < nd * np; k += 256) {
+            const int dd = k / np, c = k % np;
+            const int ci = (cy0 + c / pw) * w2 + cx0 + c % pw;
+            s_p[dd][c] = expf(l[(size_t)(d0 + dd) * hw + ci] - s_m[c]) * s_rs[c];
+        }
+        __syncthreads();
+        for (int dd = 0; dd < nd; ++dd) {
+            const float v = q.w00 * s_p[dd][l00] + q.w01 * s_p[dd][l01] + q.w10 * s_p[dd][l10] + q.w11 * s_p[dd][l11];
+            if (v > best) { best = v; bi = d0 + dd; }
+        }
     }
-    depth_w[e] = best;
-    argmax[e] = bi;
+    if (in) {
+        const float* c = coarse + (size_t)b * hw;
+        const float fine = q.w00 * c[q.i00] + q.w01 * c[q.i01] + q.w10 * c[q.i10] + q.w11 * c[q.i11];
+        const size_t e = ((size_t)b * H + y) * W + x;
+        depth_map[e] = log_planes ? expf(fine) : 1.0f / fine;
+        depth_w[e] = best;
+        argmax[e] = bi;
+    }
 }
 
 // ---- backward ----
@@ -169,8 +199,8 @@ FS_API int fs_depth_tail_forward(int32_t B, int32_t D, int32_t h2, int32_t w2, c
     hipLaunchKernelGGL(depth_expect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, D, h2 * w2, logits,
                        candidates, log_planes, stats, coarse, depth);
     if (depth_map)
-        hipLaunchKernelGGL(depth_upsample_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, st, B, D, h2, w2,
-                           logits, stats, coarse, log_planes, depth_map, depth_weights, argmax);
+        hipLaunchKernelGGL(depth_upsample_kernel, dim3((2 * w2 + kUpW - 1) / kUpW, (2 * h2 + kUpH - 1) / kUpH, B), dim3(256),
+                           0, st, B, D, h2, w2, logits, stats, coarse, log_planes, depth_map, depth_weights, argmax);
     FS_CHECK_LAUNCH("depth_tail_forward");
     return FS_OK;
 }
