@@ -104,7 +104,9 @@ def check(status: int, what: str) -> None:
 
 
 def ptr(t):
-    """Device pointer of a torch tensor (or None)."""
+    """Device pointer of a torch tensor (or None).  The tensor must stay referenced until the library call that
+    receives the pointer has returned (queued its launches): never write ptr(t.contiguous()) for more than one
+    argument of a call -- a temporary freed between two conversions hands its block to the next one."""
     return None if t is None else C.c_void_p(t.data_ptr())
 
 

@@ -110,9 +110,11 @@ def frame_views(extrinsics, intrinsics, near, far, scale_invariant: bool = True)
     out = [torch.empty(v, n, dtype=torch.float32, device=dev) for n in (16, 16, 3, 2)] + [torch.empty(v, dtype=torch.float32, device=dev)]
     view, full, campos, tanfov, scale = out
     p = R._lib.ptr
-    R._lib.check(R._lib.lib().fs_frame_views(v, p(f(extrinsics)), p(f(intrinsics)), p(f(near)), p(f(far)),
-                                             1 if scale_invariant else 0, p(view), p(full), p(campos), p(tanfov),
-                                             p(scale), R._lib.current_stream()), "fs_frame_views")
+    # (converted copies must stay referenced until the launch is queued: a temporary freed between two conversions
+    # would hand its block to the next one)
+    e_, k_, n_, f_ = f(extrinsics), f(intrinsics), f(near), f(far)
+    R._lib.check(R._lib.lib().fs_frame_views(v, p(e_), p(k_), p(n_), p(f_), 1 if scale_invariant else 0, p(view), p(full),
+                                             p(campos), p(tanfov), p(scale), R._lib.current_stream()), "fs_frame_views")
     return campos, scale, tanfov, view.view(v, 4, 4), full.view(v, 4, 4)
 
 

@@ -50,10 +50,10 @@ class _DepthTail(torch.autograd.Function):
         sP = torch.empty(B, D, h2, w2, device=dev) if g_w is not None else None
         g_logits = torch.empty_like(logits)
         p = _lib.ptr
+        gc_, gd_, gm_, gw_ = c(g_coarse), c(g_depth), c(g_map), c(g_w)   # (kept alive until the launch is queued)
         _lib.check(_lib.lib().fs_depth_tail_backward(B, D, h2, w2, p(logits), p(cand), int(log_planes), p(stats), p(coarse),
-                                                     p(depth), p(dmap), p(am), p(c(g_coarse)), p(c(g_depth)), p(c(g_map)),
-                                                     p(c(g_w)), p(sE), p(sP), p(g_logits), _lib.current_stream()),
-                   "fs_depth_tail_backward")
+                                                     p(depth), p(dmap), p(am), p(gc_), p(gd_), p(gm_), p(gw_), p(sE), p(sP),
+                                                     p(g_logits), _lib.current_stream()), "fs_depth_tail_backward")
         return g_logits, None, None, None
 
 

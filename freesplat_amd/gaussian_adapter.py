@@ -95,10 +95,11 @@ class _Head(torch.autograd.Function):
         g_raw, g_dep, g_E = torch.empty_like(raw), torch.empty_like(depths), torch.empty_like(extrinsics)
         c = lambda t: None if t is None else t.contiguous()
         p = _lib.ptr
+        gc_, gs_, gsc_, gr_ = c(g_cov), c(g_sh), c(g_scales), c(g_rot)   # (kept alive until the launch is queued)
         _lib.check(_lib.lib().fs_gaussian_head_backward(M, p(raw), p(depths), p(extrinsics), p(mult), stride, p(sh_mask),
-                                                        C.c_float(smin), C.c_float(smax), p(c(g_cov)), p(c(g_sh)),
-                                                        p(c(g_scales)), p(c(g_rot)), p(g_raw), p(g_dep), p(g_E),
-                                                        _lib.current_stream()), "fs_gaussian_head_backward")
+                                                        C.c_float(smin), C.c_float(smax), p(gc_), p(gs_), p(gsc_), p(gr_),
+                                                        p(g_raw), p(g_dep), p(g_E), _lib.current_stream()),
+                   "fs_gaussian_head_backward")
         return g_raw, g_dep, g_E, None, None, None, None
 
 

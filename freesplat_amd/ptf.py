@@ -74,8 +74,8 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
     app = torch.empty(P, dtype=torch.int64, device=dev)
     counts = torch.empty(3, dtype=torch.int32, device=dev)
     p = _lib.ptr
-    _lib.check(L.fs_ptf_match(M, h, w, p(xyz), p(w2c.detach().float().contiguous()),
-                              p(kpix.detach().float().contiguous()), p(depth_i.detach().float().contiguous()),
+    w2c_, kpix_, depth_ = (t.detach().float().contiguous() for t in (w2c, kpix, depth_i))  # alive until the launch is queued
+    _lib.check(L.fs_ptf_match(M, h, w, p(xyz), p(w2c_), p(kpix_), p(depth_),
                               C.c_float(depth_thres), p(scratch), p(keep), p(fuse), p(fpix), p(app), p(counts),
                               _lib.current_stream()), "fs_ptf_match")
     nk, nf, na = counts.tolist()
