@@ -159,7 +159,7 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
 # ---------------------------------------------------------------------------------------------
 # Batched multi-view path: one shared Gaussian set, v views, one sync.
 # ---------------------------------------------------------------------------------------------
-_pending_checks: list = []  # (RasterState list) of render_views(..., check="deferred") calls
+_pending_checks: list = []  # (counters [v,2], states | None, device) of render_views(..., check="deferred") calls
 
 
 def check_deferred() -> None:
@@ -169,14 +169,18 @@ def check_deferred() -> None:
     pend, _pending_checks = _pending_checks, []
     if not pend:
         return
-    flat = [rs for states in pend for rs in states]
-    counters = torch.stack([rs.counters for rs in flat]).tolist()
-    bad = 0
-    for rs, (n_inst, overflow) in zip(flat, counters):
-        rs.num_rendered = n_inst & 0xFFFFFFFF
-        st = R._state(rs.geom.device)
-        st.last_instances = max(st.last_instances, rs.num_rendered)
-        bad += 1 if overflow else 0
+    counters = torch.cat([c for c, _, _ in pend]).tolist()
+    bad, k = 0, 0
+    for c, states, dev in pend:
+        st = R._state(dev)
+        for i in range(c.shape[0]):
+            n_inst, overflow = counters[k]
+            k += 1
+            n_inst &= 0xFFFFFFFF
+            if states is not None:
+                states[i].num_rendered = n_inst
+            st.last_instances = max(st.last_instances, n_inst)
+            bad += 1 if overflow else 0
     if bad:
         raise R._lib.FreeSplatHipError(f"{bad} deferred view(s) overflowed their instance capacity; "
                                        "re-render them (capacity history has been updated)")
@@ -241,7 +245,8 @@ class _RenderViews(torch.autograd.Function):
         batch = dict(dims=dims, sz=sz, geom=geom, binning=binning, image=image, bgs=bgs, views=views, fulls=fulls,
                      campos=campos, tanfov=tanfov, scale=scale)
         if deferred:
-            _pending_checks.append(states)
+            # without a backward to come only the 8-byte counter pairs stay alive until the check, not the buffers
+            _pending_checks.append((counters, states if any(ctx.needs_input_grad) else None, dev))
         else:
             counters = torch.stack([rs.counters for rs in states]).tolist()  # the single sync
             worst = 0

@@ -185,6 +185,41 @@ def test_capacity_overflow_retry(hip_device, monkeypatch):
     assert st["num_rendered"] > 100
 
 
+def test_render_views_overflow_now_and_deferred(hip_device, monkeypatch):
+    """Capacity overflow on the batched path: check="now" re-renders the overflowed views (forward and backward then
+    go view by view) and gives the same images and gradients; check="deferred" reports it at check_deferred()."""
+    from freesplat_amd import _lib, rasterizer as R
+    from freesplat_amd.decoder import check_deferred, render_views
+    H, W, v = 48, 64, 3
+    scene, cams = small_scene(N=1500, H=H, W=W, seed=21, n_views=v)
+    dev = hip_device
+    g = {k: scene[k].to(dev).requires_grad_(True) for k in ("means", "covariances", "harmonics", "opacities")}
+    cam = {k: t.to(dev) for k, t in cams.items()}
+    bg = torch.zeros(v, 3, device=dev)
+    args = (cam["extrinsics"], cam["intrinsics"], cam["near"], cam["far"], (H, W), bg, g["means"], g["covariances"],
+            g["harmonics"], g["opacities"])
+    c_ref, d_ref = render_views(*args)
+    w = torch.randn_like(c_ref)
+    (c_ref * w).sum().backward()
+    ref = {k: t.grad.clone() for k, t in g.items()}
+    for t in g.values():
+        t.grad = None
+    monkeypatch.setattr(R, "default_capacity", lambda N, st: 64)
+    c2, d2 = render_views(*args)                       # overflows, re-rendered view by view
+    assert torch.equal(c2, c_ref) and torch.equal(d2, d_ref)
+    (c2 * w).sum().backward()
+    for k in g:
+        assert (g[k].grad - ref[k]).abs().max() <= 2e-4 * (ref[k].abs().max() + 1e-20), k
+    with torch.no_grad():
+        render_views(*args, check="deferred")
+        with pytest.raises(_lib.FreeSplatHipError):
+            check_deferred()
+        monkeypatch.undo()
+        c3, _ = render_views(*args, check="deferred")  # capacity history now covers the scene
+        check_deferred()
+        assert torch.equal(c3, c_ref)
+
+
 @pytest.mark.parametrize("precomp,with_depth,H,W,N", [(False, True, 48, 64, 500), (True, False, 40, 40, 300),
                                                       (False, False, 128, 160, 8000)])
 def test_backward_matches_oracle(hip_device, precomp, with_depth, H, W, N):
