@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
 // compare-exchange is ascending, so an arbitrary length n works in place: partners >= n are
 // virtual +inf and never move.
 // ------------------------------------------------------------------------------------------
-constexpr int kSortLds = 4096;  // keys per tile kept in LDS (32 KiB); longer lists sort in HBM
+constexpr int kSortLds = 2048;  // 64-bit LDS exchange slots per workgroup (16 KiB: 10 workgroups/CU); exchanges of more keys go in halves
 
 template <typename Ptr>
 __device__ __forceinline__ void bitonic_sort_any(Ptr a, uint32_t n)
@@ -591,12 +591,16 @@ __device__ __forceinline__ void thread_exchange(unsigned long long (&k)[EPT], in
 #pragma unroll
         for (int e = 0; e < EPT; ++e) y[e] = lane_xor64<TM>(k[REV ? EPT - 1 - e : e]);
     } else {
-        __syncthreads();
+        constexpr int CH = EPT * 256 > kSortLds ? kSortLds / 256 : EPT;  // keys per thread that fit the exchange buffer
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) lds[e * 256 + t] = k[e];
-        __syncthreads();
+        for (int e0 = 0; e0 < EPT; e0 += CH) {
+            __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) y[e] = lds[(REV ? EPT - 1 - e : e) * 256 + (t ^ TM)];
+            for (int e = 0; e < CH; ++e) lds[e * 256 + t] = k[REV ? EPT - 1 - (e0 + e) : e0 + e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < CH; ++e) y[e0 + e] = lds[e * 256 + (t ^ TM)];
+        }
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -690,18 +694,30 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
     FS_PT(2, 2);  // first run sorted
     Stages<EB, NB>::run(kb, t, lds);
     FS_PT(2, 3);  // second run sorted
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < EA; ++e) lds[t * EA + e] = ka[e];
-#pragma unroll
-    for (int e = 0; e < EB; ++e) lds[NA + t * EB + e] = kb[e];
-    __syncthreads();
     unsigned long long k[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = t * E + e;
-        k[e] = i < NA + NB ? lds[i] : ~0ull;
+    for (int c0 = 0; c0 < NA + NB; c0 += kSortLds) {  // through the exchange buffer, kSortLds keys at a time
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            const int i = t * EA + e - c0;
+            if (i >= 0 && i < kSortLds) lds[i] = ka[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int i = NA + t * EB + e - c0;
+            if (i >= 0 && i < kSortLds) lds[i] = kb[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = t * E + e - c0;
+            if (i >= 0 && i < kSortLds && i + c0 < NA + NB) k[e] = lds[i];
+        }
     }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (t * E + e >= NA + NB) k[e] = ~0ull;
     FS_PT(2, 4);  // re-laid out
     thread_exchange<E, 255, true>(k, t, lds);  // flip step of the last stage: i <-> i ^ (512*EA - 1)
     Clean<E, 256 * E / 4>::run(k, t, lds);
