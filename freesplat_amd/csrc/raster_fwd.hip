@@ -435,8 +435,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
                                                    unsigned long long cap)
 {
     __shared__ int s_box[8];
-    __shared__ uint32_t s_cnt[kBinLds];   // per-tile count, then per-tile running rank
-    __shared__ uint32_t s_base[kBinLds];  // first slot of this workgroup inside the tile's range
+    __shared__ uint32_t s_cnt[kBinLds];   // per tile of the workgroup's box: instance count, then the next free slot
     FS_PT(1, 0);
     const int t = threadIdx.x;
     const int i = blockIdx.x * 256 + t;
@@ -480,8 +479,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
         for (int k = t; k < bb.w * bb.h; k += 256) {
             const uint32_t c = s_cnt[k];
             const int tile = (bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w;
-            s_base[k] = c ? offsets[tile] + atomicAdd(&cursors[tile], c) : 0u;
-            s_cnt[k] = 0;
+            s_cnt[k] = c ? offsets[tile] + atomicAdd(&cursors[tile], c) : 0u;  // first slot of this workgroup in the tile's range
         }
         __syncthreads();
         FS_PT(1, 4);  // slots reserved
@@ -493,8 +491,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
                 for (int x = rc.x; x < rc.z; ++x, ++k) {
                     const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
                     if (!cull || m) {
-                        const int kk = (y - bb.y0) * bb.w + (x - bb.x0);
-                        const unsigned long long slot = (unsigned long long)s_base[kk] + atomicAdd(&s_cnt[kk], 1u);
+                        const unsigned long long slot = atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
                         if (slot < cap) keys[slot] = key_hi | m;
                     }
                 }
