@@ -230,28 +230,37 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const bool sh_cm = (d.flags & FS_RASTER_SH_CHANNEL_MAJOR) != 0;
     const int sh_cs = sh_cm ? d.M : 1, sh_ks = sh_cm ? 1 : 3;
     const int per_cov = (d.flags & FS_RASTER_COV_FULL) ? 9 : 6;
-    float* l_sh = lds;                                   // [256 * per_sh] (+pad to 4)
-    float* l_cov = l_sh + ((256 * per_sh + 3) & ~3);     // [256 * per_cov]
-    float* l_mean = l_cov + 256 * 9;                     // [256 * 3]
+    float* l_sh = lds;                                   // [256 * per_sh]: the only rows wide enough to need staging
     if (shs) {
         if (d.flags & FS_RASTER_SH_FP16) stage_rows_half(l_sh, (const _Float16*)shs, base, cnt, per_sh);
         else stage_rows(l_sh, shs, base, cnt, per_sh);
     }
-    stage_rows(l_cov, cov3D, base, cnt, per_cov);
-    stage_rows(l_mean, means3D, base, cnt, 3);
-    __syncthreads();
-    FS_PT(0, 1);  // inputs staged
     const int t = threadIdx.x;
     const bool live = t < cnt;
     const int i = base + t;
+    // mean (12 B) and covariance (24 / 36 B) rows straight into registers: a wavefront's rows are one contiguous
+    // 0.8 - 2.3 KB range, every fetched line is fully used
+    float3 p_in = make_float3(0.0f, 0.0f, 0.0f);
+    float c_in[6] = {0, 0, 0, 0, 0, 0};
+    if (live) {
+        p_in = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+        if (per_cov == 9) {  // row-major 3x3, upper triangle
+            const float* cr = cov3D + 9 * (size_t)i;
+            c_in[0] = cr[0]; c_in[1] = cr[1]; c_in[2] = cr[2]; c_in[3] = cr[4]; c_in[4] = cr[5]; c_in[5] = cr[8];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c_in[k] = cov3D[6 * (size_t)i + k];
+        }
+    }
+    __syncthreads();
+    FS_PT(0, 1);  // inputs staged
 
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
     uint8_t cb = 0;
     int rad = 0;
 
-    float3 p = live ? make_float3(l_mean[3 * t], l_mean[3 * t + 1], l_mean[3 * t + 2])
-                    : make_float3(0.0f, 0.0f, 0.0f);
+    float3 p = p_in;
     if (scale_dev) { p.x = p.x * wscale; p.y = p.y * wscale; p.z = p.z * wscale; }
     const float3 pv = xform43(view, p);
     if (live && pv.z > 0.2f) {
@@ -260,13 +269,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         const float ndcx = ph.x * pw, ndcy = ph.y * pw;
         const float fx = (float)d.W / (2.0f * tanfovx), fy = (float)d.H / (2.0f * tanfovy);
         float c3[6];
-        if (per_cov == 9) {  // row-major 3x3, upper triangle
-            const float* cr = l_cov + 9 * t;
-            c3[0] = cr[0]; c3[1] = cr[1]; c3[2] = cr[2]; c3[3] = cr[4]; c3[4] = cr[5]; c3[5] = cr[8];
-        } else {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) c3[k] = l_cov[6 * t + k];
-        }
+        for (int k = 0; k < 6; ++k) c3[k] = c_in[k];
         if (scale_dev) {
             const float s2 = wscale * wscale;
 #pragma unroll
@@ -1010,7 +1014,7 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     }
     const int M = shs ? d.M : 0;
     if (d.N > 0) {
-        size_t lds = (size_t)(((256 * M * 3 + 3) & ~3) + 256 * 9 + 256 * 3) * sizeof(float);
+        size_t lds = (size_t)(256 * M * 3) * sizeof(float);
         if (lds < (size_t)(16 + kBinLds) * 4) lds = (size_t)(16 + kBinLds) * 4;
         {
             ScopedStage prof_(kStPreprocess, st);
