@@ -206,7 +206,7 @@ def main():
             iso = breakdown.get(key, (0.0, 0))
             out["roofline"]["isolated_launch_ms"] = iso[0] / max(iso[1], 1)
         if world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline_and_parity(scene, cams_all, H, W, color[0], args.workload))
+            out.update(cpu_baseline_and_parity(scene, cams_all, H, W, color[0], args.workload, train=train))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -230,10 +230,10 @@ def committed_traffic(kernel: str):
     return None, None
 
 
-def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload):
+def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload, train=False):
     """Times the CPU oracle (kind "port": OpenMP restatement of the reference algorithm, all host
-    cores) on a bounded sample -- whole views of the same workload until >= 10 s of CPU work or 3
-    views -- and checks the GPU image of view 0 against it (max-abs, PSNR)."""
+    cores) on a bounded sample -- whole views of the same workload (forward, or forward + backward in train mode)
+    until >= 10 s of CPU work or 3 views -- and checks the GPU image of view 0 against it (max-abs, PSNR)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util_raster import oracle_forward, view_inputs
@@ -246,6 +246,9 @@ def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload):
         vi_n = view_inputs(scene, cams_all, n % cams_all["extrinsics"].shape[0], H, W)
         t = time.perf_counter()
         st = oracle_forward(vi_n)
+        if train:
+            from oracle import raster_oracle as ro
+            ro.backward(st, np.ones((3, H, W), np.float32))
         t_tot += time.perf_counter() - t
         if n == 0:
             st0 = st
@@ -260,7 +263,8 @@ def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload):
     psnr = None if mse == 0 else float(-10 * np.log10(mse))
     return {
         "cpu_baseline": {"value": n / t_tot, "unit": "views/s", "cores": cores, "kind": "port",
-                         "sample": f"{n} forward view(s) of {workload} through oracle/raster_oracle.c (OpenMP)"},
+                         "sample": f"{n} {'forward+backward' if train else 'forward'} view(s) of {workload} through "
+                                   "oracle/raster_oracle.c (OpenMP)"},
         "parity": {"max_abs_err_vs_oracle": err, "psnr_db_vs_oracle": psnr if psnr is not None else "inf",
                    "bit_exact": bool((g == st0["color"]).all())},
     }
