@@ -73,6 +73,9 @@ static __device__ unsigned long long g_phase_trace[kPtKernels * kPtBlocks * kPtS
 #define FS_PT(kern, k) do {} while (0)
 #endif
 
+// ptf_gru.hip: the GRU of a fold step (n pairs, or at most n_max with the count in counts[1] on the device)
+int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const float* tables, float* fused, hipStream_t st);
+
 // LDS operations of one wavefront execute in order: between phases of a wavefront-private LDS exchange only the
 // compiler must be kept from reordering them.
 __device__ __forceinline__ void wave_lds_sync()

@@ -29,13 +29,17 @@ __global__ __launch_bounds__(256) void ptf_fill_kernel(uint32_t* __restrict__ zb
 }
 
 // w2c = inverse(extrinsics_i) row-major [16]; kpix = {fx, fy, cx, cy} in pixels
-__global__ __launch_bounds__(256) void ptf_project_kernel(int M, int h, int w, const float* __restrict__ xyz,
+// (every kernel below takes its element count either from the host (`M`) or, when `Mp` is non-null, from device memory:
+//  fs_ptf_fold_step chains the fold steps of all views without a host sync, sizing grids for an upper bound)
+__global__ __launch_bounds__(256) void ptf_project_kernel(int M, const int32_t* __restrict__ Mp, int h, int w,
+                                                          const float* __restrict__ xyz,
                                                           const float* __restrict__ w2c,
                                                           const float* __restrict__ kpix,
                                                           int32_t* __restrict__ pix_of,
                                                           uint32_t* __restrict__ zbits_of,
                                                           uint32_t* __restrict__ zbuf)
 {
+    if (Mp) M = *Mp;
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     const float x = xyz[3 * (size_t)m], y = xyz[3 * (size_t)m + 1], z = xyz[3 * (size_t)m + 2];
@@ -62,12 +66,14 @@ __device__ __forceinline__ bool fusion_mask(uint32_t zb, float d, float depth_th
     return fabsf(__uint_as_float(zb) - d) < fmaxf(d * 0.05f, depth_thres);
 }
 
-__global__ __launch_bounds__(256) void ptf_flags_kernel(int M, int P, const int32_t* __restrict__ pix_of,
+__global__ __launch_bounds__(256) void ptf_flags_kernel(int M, const int32_t* __restrict__ Mp, int P,
+                                                        const int32_t* __restrict__ pix_of,
                                                         const uint32_t* __restrict__ zbits_of,
                                                         const uint32_t* __restrict__ zbuf,
                                                         const float* __restrict__ depth_i, float depth_thres,
                                                         uint8_t* __restrict__ win, uint8_t* __restrict__ app)
 {
+    if (Mp) M = *Mp;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < M) {
         const int pix = pix_of[e];
@@ -97,11 +103,13 @@ __device__ __forceinline__ uint32_t load4(const uint8_t* __restrict__ f, int bas
 }
 
 // blocks [0, nbM) count `win` over M, blocks [nbM, nbM+nbP) count `app` over P
-__global__ __launch_bounds__(256) void ptf_count_kernel(int M, int P, int nbM, const uint8_t* __restrict__ win,
+__global__ __launch_bounds__(256) void ptf_count_kernel(int M, const int32_t* __restrict__ Mp, int P, int nbM,
+                                                        const uint8_t* __restrict__ win,
                                                         const uint8_t* __restrict__ app,
                                                         uint32_t* __restrict__ block_counts)
 {
     __shared__ uint32_t s_w[4];
+    if (Mp) M = *Mp;
     const bool second = (int)blockIdx.x >= nbM;
     const uint8_t* f = second ? app : win;
     const int n = second ? P : M;
@@ -116,11 +124,12 @@ __global__ __launch_bounds__(256) void ptf_count_kernel(int M, int P, int nbM, c
 }
 
 // exclusive scan of the two block-count ranges (one workgroup); counts = {n_keep, n_fuse, n_append}
-__global__ __launch_bounds__(1024) void ptf_scan_blocks_kernel(int M, int nbM, int nbP,
+__global__ __launch_bounds__(1024) void ptf_scan_blocks_kernel(int M, const int32_t* __restrict__ Mp, int nbM, int nbP,
                                                                uint32_t* __restrict__ block_counts,
                                                                int32_t* __restrict__ counts)
 {
     __shared__ uint32_t part[1024];
+    if (Mp) M = *Mp;
     for (int range = 0; range < 2; ++range) {
         uint32_t* a = block_counts + (range ? nbM : 0);
         const int n = range ? nbP : nbM;
@@ -145,13 +154,14 @@ __global__ __launch_bounds__(1024) void ptf_scan_blocks_kernel(int M, int nbM, i
         }
         if (t == 1023) {
             if (range == 0) { counts[1] = (int32_t)part[1023]; counts[0] = M - (int32_t)part[1023]; }
-            else counts[2] = (int32_t)part[1023];
+            else { counts[2] = (int32_t)part[1023]; counts[3] = counts[0] + counts[1] + counts[2]; }  // [3]: size of the next state
         }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void ptf_emit_kernel(int M, int P, int nbM, const uint8_t* __restrict__ win,
+__global__ __launch_bounds__(256) void ptf_emit_kernel(int M, const int32_t* __restrict__ Mp, int P, int nbM,
+                                                       const uint8_t* __restrict__ win,
                                                        const uint8_t* __restrict__ app,
                                                        const int32_t* __restrict__ pix_of,
                                                        const uint32_t* __restrict__ block_offsets,
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(256) void ptf_emit_kernel(int M, int P, int nbM, co
                                                        long long* __restrict__ append_pix)
 {
     __shared__ uint32_t s_w[4];
+    if (Mp) M = *Mp;
     const bool second = (int)blockIdx.x >= nbM;
     const uint8_t* f = second ? app : win;
     const int n = second ? P : M;
@@ -221,13 +232,15 @@ __device__ __forceinline__ void pos_enc2(float a, float b, float* __restrict__ o
 }
 
 // one 16-lane group per fused pair: lanes 0..15 move the two 64-float latents as float4, lane 0/1 the encodings
-__global__ __launch_bounds__(256) void ptf_gru_inputs_kernel(int n_fuse, const long long* __restrict__ fuse_idx,
+__global__ __launch_bounds__(256) void ptf_gru_inputs_kernel(int n_fuse, const int32_t* __restrict__ counts,
+                                                            const long long* __restrict__ fuse_idx,
                                                             const long long* __restrict__ fuse_pix,
                                                             const float* __restrict__ G, const float* __restrict__ R,
                                                             const float* __restrict__ O, const float* __restrict__ g_i,
                                                             const float* __restrict__ rho_i,
                                                             const float* __restrict__ om_i, float* __restrict__ cat)
 {
+    if (counts) n_fuse = counts[1];
     const int t = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
     if (t >= n_fuse) return;
     const long long m = fuse_idx[t], p = fuse_pix[t];
@@ -241,11 +254,13 @@ __global__ __launch_bounds__(256) void ptf_gru_inputs_kernel(int n_fuse, const l
 struct PtfState { float *G, *X, *R, *O, *E, *D; };
 
 __global__ __launch_bounds__(256) void ptf_write_state_kernel(
-    int n_keep, int n_fuse, int n_app, const long long* __restrict__ keep_idx, const long long* __restrict__ fuse_idx,
+    int n_keep, int n_fuse, int n_app, const int32_t* __restrict__ counts, const long long* __restrict__ keep_idx,
+    const long long* __restrict__ fuse_idx,
     const long long* __restrict__ fuse_pix, const long long* __restrict__ app_pix, PtfState s, const float* __restrict__ g_i,
     const float* __restrict__ x_i, const float* __restrict__ rho_i, const float* __restrict__ om_i,
     const float* __restrict__ d_i, const float* __restrict__ E_i, const float* __restrict__ fused, PtfState o)
 {
+    if (counts) { n_keep = counts[0]; n_fuse = counts[1]; n_app = counts[2]; }
     const int row = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
     const int n_out = n_keep + n_fuse + n_app;
     if (row >= n_out) return;
@@ -305,10 +320,11 @@ FS_API size_t fs_ptf_scratch_bytes(int32_t M, int32_t h, int32_t w)
     return ptf_scratch_layout(M > 0 ? M : 1, h * w, off);
 }
 
-FS_API int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const float* w2c,
-                        const float* kpix, const float* depth_i, float depth_thres, void* scratch,
-                        int64_t* keep_idx, int64_t* fuse_idx, int64_t* fuse_pix, int64_t* append_pix,
-                        int32_t* counts, void* stream_)
+// M: number of state rows, or (Mp != NULL) an upper bound of *Mp used for sizing grids and the scratch layout
+static int ptf_match_impl(int32_t M, const int32_t* Mp, int32_t h, int32_t w, const float* xyz, const float* w2c,
+                          const float* kpix, const float* depth_i, float depth_thres, void* scratch,
+                          int64_t* keep_idx, int64_t* fuse_idx, int64_t* fuse_pix, int64_t* append_pix,
+                          int32_t* counts, void* stream_)
 {
     if (M < 0 || h <= 0 || w <= 0 || !w2c || !kpix || !depth_i || !scratch || !append_pix || !counts)
         return FS_ERR_INVALID_ARG;
@@ -328,17 +344,26 @@ FS_API int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const
     ScopedStage prof_(kStPtf, st);
     hipLaunchKernelGGL(ptf_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, st, zbuf, P);
     if (M > 0)
-        hipLaunchKernelGGL(ptf_project_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, h, w, xyz, w2c, kpix,
+        hipLaunchKernelGGL(ptf_project_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, Mp, h, w, xyz, w2c, kpix,
                            pix_of, zbits_of, zbuf);
     const int E = M > P ? M : P;
-    hipLaunchKernelGGL(ptf_flags_kernel, dim3((E + 255) / 256), dim3(256), 0, st, M, P, pix_of, zbits_of, zbuf,
+    hipLaunchKernelGGL(ptf_flags_kernel, dim3((E + 255) / 256), dim3(256), 0, st, M, Mp, P, pix_of, zbits_of, zbuf,
                        depth_i, depth_thres, win, app);
-    hipLaunchKernelGGL(ptf_count_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, P, nbM, win, app, blocks);
-    hipLaunchKernelGGL(ptf_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, M, nbM, nbP, blocks, counts);
-    hipLaunchKernelGGL(ptf_emit_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, P, nbM, win, app, pix_of, blocks,
+    hipLaunchKernelGGL(ptf_count_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, Mp, P, nbM, win, app, blocks);
+    hipLaunchKernelGGL(ptf_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, M, Mp, nbM, nbP, blocks, counts);
+    hipLaunchKernelGGL(ptf_emit_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, Mp, P, nbM, win, app, pix_of, blocks,
                        (long long*)keep_idx, (long long*)fuse_idx, (long long*)fuse_pix, (long long*)append_pix);
     FS_CHECK_LAUNCH("ptf_match");
     return FS_OK;
+}
+
+FS_API int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const float* w2c,
+                        const float* kpix, const float* depth_i, float depth_thres, void* scratch,
+                        int64_t* keep_idx, int64_t* fuse_idx, int64_t* fuse_pix, int64_t* append_pix,
+                        int32_t* counts, void* stream_)
+{
+    return ptf_match_impl(M, nullptr, h, w, xyz, w2c, kpix, depth_i, depth_thres, scratch, keep_idx, fuse_idx, fuse_pix,
+                          append_pix, counts, stream_);
 }
 
 FS_API int fs_ptf_gru_inputs(int32_t n_fuse, const int64_t* fuse_idx, const int64_t* fuse_pix, const float* G,
@@ -350,7 +375,7 @@ FS_API int fs_ptf_gru_inputs(int32_t n_fuse, const int64_t* fuse_idx, const int6
     if (!fuse_idx || !fuse_pix || !G || !R || !O || !g_i || !rho_i || !om_i || !cat) return FS_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream_;
     ScopedStage prof_(kStPtf, st);
-    hipLaunchKernelGGL(ptf_gru_inputs_kernel, dim3((n_fuse + 15) / 16), dim3(256), 0, st, n_fuse,
+    hipLaunchKernelGGL(ptf_gru_inputs_kernel, dim3((n_fuse + 15) / 16), dim3(256), 0, st, n_fuse, (const int32_t*)nullptr,
                        (const long long*)fuse_idx, (const long long*)fuse_pix, G, R, O, g_i, rho_i, om_i, cat);
     FS_CHECK_LAUNCH("ptf_gru_inputs");
     return FS_OK;
@@ -376,8 +401,100 @@ FS_API int fs_ptf_write_state(int32_t n_keep, int32_t n_fuse, int32_t n_app, con
                const_cast<float*>(E), const_cast<float*>(D)};
     PtfState o{oG, oX, oR, oO, oE, oD};
     hipLaunchKernelGGL(ptf_write_state_kernel, dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
-                       n_app, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
+                       n_app, (const int32_t*)nullptr, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
                        (const long long*)append_pix, s, g_i, x_i, rho_i, om_i, d_i, E_i, fused, o);
     FS_CHECK_LAUNCH("ptf_write_state");
+    return FS_OK;
+}
+
+// ---- one whole fold step without host involvement -----------------------------------------------------------
+namespace {
+struct FoldLayout { size_t match, keep, fuse, fpix, app, cat, fused, total; };
+FoldLayout fold_layout(int M_max, int P)
+{
+    FoldLayout L;
+    size_t off[7];
+    const size_t nf = (size_t)(M_max < P ? M_max : P);
+    size_t o = 0;
+    L.match = o; o += align_up(ptf_scratch_layout(M_max > 0 ? M_max : 1, P, off), 256);
+    L.keep = o;  o += align_up((size_t)(M_max > 0 ? M_max : 1) * 8, 256);
+    L.fuse = o;  o += align_up((nf > 0 ? nf : 1) * 8, 256);
+    L.fpix = o;  o += align_up((nf > 0 ? nf : 1) * 8, 256);
+    L.app = o;   o += align_up((size_t)P * 8, 256);
+    L.cat = o;   o += align_up((nf > 0 ? nf : 1) * 176 * 4, 256);
+    L.fused = o; o += align_up((nf > 0 ? nf : 1) * 64 * 4, 256);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+FS_API size_t fs_ptf_fold_scratch_bytes(int32_t M_max, int32_t h, int32_t w)
+{
+    if (M_max < 0 || h <= 0 || w <= 0) return 0;
+    return fold_layout(M_max, h * w).total;
+}
+
+FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, const float* G, const float* X,
+                            const float* R, const float* O, const float* E, const float* D, const float* g_i,
+                            const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
+                            const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
+                            void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
+                            int32_t* counts, void* stream_)
+{
+    if (M_max <= 0 || h <= 0 || w <= 0 || !G || !X || !R || !O || !E || !D || !g_i || !x_i || !rho_i || !om_i || !d_i ||
+        !E_i || !w2c || !kpix || !gru_tables || !scratch || !oG || !oX || !oR || !oO || !oE || !oD || !counts)
+        return FS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    const int P = h * w;
+    const FoldLayout L = fold_layout(M_max, P);
+    char* s = (char*)scratch;
+    long long *keep = (long long*)(s + L.keep), *fuse = (long long*)(s + L.fuse), *fpix = (long long*)(s + L.fpix),
+              *app = (long long*)(s + L.app);
+    float *cat = (float*)(s + L.cat), *fused = (float*)(s + L.fused);
+    int rc = ptf_match_impl(M_max, M_dev, h, w, X, w2c, kpix, d_i, depth_thres, s + L.match, (int64_t*)keep,
+                            (int64_t*)fuse, (int64_t*)fpix, (int64_t*)app, counts, stream_);
+    if (rc != FS_OK) return rc;
+    const int nf_max = M_max < P ? M_max : P;
+    ScopedStage prof_(kStPtf, st);
+    hipLaunchKernelGGL(ptf_gru_inputs_kernel, dim3((nf_max + 15) / 16), dim3(256), 0, st, nf_max, (const int32_t*)counts,
+                       (const long long*)fuse, (const long long*)fpix, G, R, O, g_i, rho_i, om_i, cat);
+    FS_CHECK_LAUNCH("ptf_gru_inputs");
+    rc = launch_ptf_gru(nf_max, counts, cat, gru_tables, fused, st);
+    if (rc != FS_OK) return rc;
+    PtfState si{const_cast<float*>(G), const_cast<float*>(X), const_cast<float*>(R), const_cast<float*>(O),
+                const_cast<float*>(E), const_cast<float*>(D)};
+    PtfState so{oG, oX, oR, oO, oE, oD};
+    const long long n_out_max = (long long)M_max + P;
+    hipLaunchKernelGGL(ptf_write_state_kernel, dim3((unsigned)((n_out_max + 15) / 16)), dim3(256), 0, st, 0, 0, 0,
+                       (const int32_t*)counts, (const long long*)keep, (const long long*)fuse, (const long long*)fpix,
+                       (const long long*)app, si, g_i, x_i, rho_i, om_i, d_i, E_i, fused, so);
+    FS_CHECK_LAUNCH("ptf_write_state");
+    return FS_OK;
+}
+
+// All fold steps of one scene in one host call: views 1 .. V-1 are folded into the state that starts as view 0.
+// lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es / w2c [V,16], kpix [V,4]; E0 [P,16] = view 0's extrinsics repeated
+// (the initial per-Gaussian extrinsics); bufA / bufB: two sets of 6 state arrays (G, X, R, O, E, D) with V*P rows each,
+// written alternately; counts [V,4].  The final state is in set ((V - 1) & 1 ? A : B) with counts[V-1][3] rows.
+FS_API int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const float* xs, const float* rho,
+                       const float* om, const float* dep, const float* Es, const float* E0, const float* w2c,
+                       const float* kpix, float depth_thres, const float* gru_tables, void* scratch,
+                       float* const* bufA, float* const* bufB, int32_t* counts, void* stream_)
+{
+    if (V < 2 || h <= 0 || w <= 0 || !lat || !xs || !rho || !om || !dep || !Es || !E0 || !w2c || !kpix || !gru_tables ||
+        !scratch || !bufA || !bufB || !counts)
+        return FS_ERR_INVALID_ARG;
+    const size_t P = (size_t)h * w;
+    const float* cur[6] = {lat, xs, rho, om, E0, dep};
+    for (int i = 1; i < V; ++i) {
+        float* const* out = (i & 1) ? bufA : bufB;
+        const int rc = fs_ptf_fold_step((int32_t)(i * P), i == 1 ? nullptr : counts + 4 * (i - 1) + 3, h, w, cur[0], cur[1],
+                                        cur[2], cur[3], cur[4], cur[5], lat + i * P * 64, xs + i * P * 3, rho + i * P,
+                                        om + i * P, dep + i * P, Es + 16 * (size_t)i, w2c + 16 * (size_t)i,
+                                        kpix + 4 * (size_t)i, depth_thres, gru_tables, scratch, out[0], out[1], out[2],
+                                        out[3], out[4], out[5], counts + 4 * i, stream_);
+        if (rc != FS_OK) return rc;
+        for (int k = 0; k < 6; ++k) cur[k] = out[k];
+    }
     return FS_OK;
 }

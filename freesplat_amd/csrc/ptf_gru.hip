@@ -33,9 +33,11 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 #define FS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-__global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const float* __restrict__ cat,
+__global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __restrict__ counts,
+                                                      const float* __restrict__ cat,
                                                       const float* __restrict__ tab, float* __restrict__ fused)
 {
+    if (counts) n = counts[1];  // (device-resident pair count: fs_ptf_fold_step)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = blockIdx.x * 4 + wave;
     if (grp * 32 >= n) return;
@@ -157,6 +159,16 @@ __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const float* __rest
     }
 }
 
+// n pairs, or (counts != NULL) at most n_max with the actual number in counts[1] on the device
+int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const float* tables, float* fused, hipStream_t st)
+{
+    if (n_max <= 0) return FS_OK;
+    const int groups = (n_max + 31) / 32;
+    hipLaunchKernelGGL(ptf_gru_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, cat, tables, fused);
+    FS_CHECK_LAUNCH("ptf_gru_forward");
+    return FS_OK;
+}
+
 }  // namespace fs
 
 using namespace fs;
@@ -170,8 +182,5 @@ FS_API int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, 
     if (!cat || !tables || !fused) return FS_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream_;
     ScopedStage prof_(kStPtf, st);
-    const int groups = (n + 31) / 32;
-    hipLaunchKernelGGL(ptf_gru_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, tables, fused);
-    FS_CHECK_LAUNCH("ptf_gru_forward");
-    return FS_OK;
+    return launch_ptf_gru(n, nullptr, cat, tables, fused, st);
 }

@@ -72,13 +72,13 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
     fuse = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
     fpix = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
     app = torch.empty(P, dtype=torch.int64, device=dev)
-    counts = torch.empty(3, dtype=torch.int32, device=dev)
+    counts = torch.empty(4, dtype=torch.int32, device=dev)
     p = _lib.ptr
     w2c_, kpix_, depth_ = (t.detach().float().contiguous() for t in (w2c, kpix, depth_i))  # alive until the launch is queued
     _lib.check(L.fs_ptf_match(M, h, w, p(xyz), p(w2c_), p(kpix_), p(depth_),
                               C.c_float(depth_thres), p(scratch), p(keep), p(fuse), p(fpix), p(app), p(counts),
                               _lib.current_stream()), "fs_ptf_match")
-    nk, nf, na = counts.tolist()
+    nk, nf, na, _ = counts.tolist()
     return keep[:nk], fuse[:nf], fpix[:nf], app[:na]
 
 
@@ -131,9 +131,10 @@ def gru_tables(gru: "GRU") -> Tensor:
 
 def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
                           depth_thres):
-    """Inference path (no autograd): per view fs_ptf_match -> fs_ptf_gru_inputs -> fs_ptf_gru_forward (GRU
-    on the fp32 matrix cores) -> fs_ptf_write_state: HIP kernels only.  Same results and order as the
-    differentiable path below."""
+    """Inference path (no autograd): ONE library call (fs_ptf_fold) folds all views -- per view match -> GRU inputs ->
+    GRU on the fp32 matrix cores -> next state, with every data-dependent size kept on the device -- and the host
+    syncs once afterwards, for the final number of Gaussians (the reference syncs four times per view).
+    Same results and order as the differentiable path below."""
     L = _lib.lib()
     p = _lib.ptr
     h, w = image_shape
@@ -144,37 +145,30 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
     rho = f(densities[0, :, :, 0, 0])             # [V,P]
     om = f(weight_emb[0, :, :, 0, 0])
     dep = f(depths.reshape(V, -1))
-    Es = f(extrinsics[0])                         # [V,4,4]
+    Es = f(extrinsics[0]).reshape(V, 16)          # [V,16]
     dev = lat.device
     P = h * w
-    G, X, R, O, D = lat[0], xs[0], rho[0], om[0], dep[0]
-    E = Es[0].reshape(1, 16).repeat(P, 1)
-    for i in range(1, V):
-        K = intrinsics[0, i].clone()
-        K[:1, :] *= w
-        K[1:2, :] *= h
-        kpix = torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
-        w2c = torch.linalg.inv_ex(Es[i]).inverse
-        keep, fuse, fpix, app = match_view(X, w2c, kpix, dep[i], h, w, depth_thres)
-        nk, nf, na = keep.numel(), fuse.numel(), app.numel()
-        fused = None
-        if nf > 0:
-            cat = torch.empty(nf, 176, device=dev)
-            _lib.check(L.fs_ptf_gru_inputs(nf, p(fuse), p(fpix), p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]),
-                                           p(cat), _lib.current_stream()), "fs_ptf_gru_inputs")
-            fused = torch.empty(nf, 64, device=dev)
-            _lib.check(L.fs_ptf_gru_forward(nf, p(cat), p(gru_tables(gru)), p(fused), _lib.current_stream()),
-                       "fs_ptf_gru_forward")
-        n_out = nk + nf + na
-        nG, nX = torch.empty(n_out, 64, device=dev), torch.empty(n_out, 3, device=dev)
-        nR, nO, nD = (torch.empty(n_out, device=dev) for _ in range(3))
-        nE = torch.empty(n_out, 16, device=dev)
-        _lib.check(L.fs_ptf_write_state(nk, nf, na, p(keep), p(fuse), p(fpix), p(app), p(G), p(X), p(R), p(O), p(E), p(D),
-                                        p(lat[i]), p(xs[i]), p(rho[i]), p(om[i]), p(dep[i]), p(Es[i].contiguous()),
-                                        p(fused), p(nG), p(nX), p(nR), p(nO), p(nE), p(nD), _lib.current_stream()),
-                   "fs_ptf_write_state")
-        G, X, R, O, E, D = nG, nX, nR, nO, nE, nD
-    return G[None], X[None], E.view(1, -1, 4, 4), D[None]
+    if V == 1:
+        return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
+    # per-view camera constants for all views at once
+    K = f(intrinsics[0])
+    kpix = torch.stack([K[:, 0, 0] * w, K[:, 1, 1] * h, K[:, 0, 2] * w, K[:, 1, 2] * h], dim=-1).contiguous()   # [V,4]
+    w2c = torch.linalg.inv_ex(Es.view(V, 4, 4)).inverse.reshape(V, 16).contiguous()
+    tables = gru_tables(gru)
+    # the state after view 0 is view 0 itself; fs_ptf_fold folds views 1 .. V-1 into it, writing the successive states
+    # alternately into two sets of buffers -- one library call, one host sync afterwards
+    E0 = Es[0].reshape(1, 16).repeat(P, 1)
+    rows = 2 * P if V == 2 else V * P
+    bufs = [[torch.empty(rows, n, device=dev) for n in (64, 3, 1, 1, 16, 1)] for _ in range(1 if V == 2 else 2)]
+    ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in b]) for b in bufs]
+    counts = torch.empty(V, 4, dtype=torch.int32, device=dev)
+    scratch = torch.empty(L.fs_ptf_fold_scratch_bytes((V - 1) * P, h, w), dtype=torch.uint8, device=dev)
+    _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), p(E0), p(w2c), p(kpix),
+                             C.c_float(depth_thres), p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts),
+                             _lib.current_stream()), "fs_ptf_fold")
+    n = int(counts[V - 1, 3].item())               # the only host sync of the fold
+    G, X, _, _, E, D = bufs[0] if ((V - 1) & 1 or V == 2) else bufs[1]
+    return G[None, :n], X[None, :n], E[:n].view(1, n, 4, 4), D[None, :n, 0]
 
 
 def fuse_gaussians(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,

@@ -211,7 +211,7 @@ size_t fs_ptf_scratch_bytes(int32_t M, int32_t h, int32_t w);
  *   keep_idx[n_keep]  global entries that stay as they are          (global[~mask])
  *   fuse_idx[n_fuse]  global entries fused with view i, fuse_pix[n_fuse] their pixel in view i
  *   append_pix[n_app] pixels of view i that start new Gaussians     (~fusion_mask)
- * counts[3] = {n_keep, n_fuse, n_app} (device).  Index buffers must hold M (resp. h*w) int64.
+ * counts[4] = {n_keep, n_fuse, n_app, n_keep + n_fuse + n_app} (device).  Index buffers must hold M (resp. h*w) int64.
  * Bit-exact index semantics (round-half-even pixel, exact z equality, ties fuse together).
  */
 int fs_ptf_match(int32_t M, int32_t h, int32_t w, const float* xyz, const float* w2c,
@@ -236,6 +236,32 @@ int fs_ptf_write_state(int32_t n_keep, int32_t n_fuse, int32_t n_app, const int6
                        const float* D, const float* g_i, const float* x_i, const float* rho_i,
                        const float* om_i, const float* d_i, const float* E_i, const float* fused, float* oG,
                        float* oX, float* oR, float* oO, float* oE, float* oD, void* stream);
+
+/* One whole fold step of PTF (fs_ptf_match -> fs_ptf_gru_inputs -> fs_ptf_gru_forward -> fs_ptf_write_state) with
+ * every data-dependent size kept ON THE DEVICE, so that the steps of all views can be queued back to back without a
+ * host sync (the reference syncs four times per view: encoder_freesplat.py:450-453,474,484).
+ * The current state G [.,64], X [.,3], R, O, E [.,16], D has *M_dev valid rows (M_dev NULL: M_max rows); M_max is a
+ * host-side upper bound of it (i * h*w after i views) that sizes grids and the scratch.  Outputs must hold
+ * M_max + h*w rows; counts[4] = {n_keep, n_fuse, n_app, rows of the new state} -- pass &counts[3] as the next step's
+ * M_dev.  scratch: fs_ptf_fold_scratch_bytes(M_max, h, w). */
+size_t fs_ptf_fold_scratch_bytes(int32_t M_max, int32_t h, int32_t w);
+int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, const float* G, const float* X,
+                     const float* R, const float* O, const float* E, const float* D, const float* g_i,
+                     const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
+                     const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
+                     void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
+                     int32_t* counts, void* stream);
+
+/* All fold steps of one scene in one host call (no host sync, no allocation): views 1 .. V-1 are folded into the state
+ * that starts as view 0.  lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es / w2c [V,16] (camera-to-world and its
+ * inverse), kpix [V,4] = {fx, fy, cx, cy} in pixels; E0 [P,16] = view 0's extrinsics repeated per pixel.  bufA / bufB:
+ * two sets of 6 state arrays {G [.,64], X [.,3], R, O, E [.,16], D} with V*P rows each, written alternately;
+ * counts [V,4].  The final state is set A if (V - 1) is odd, else B, with counts[V-1][3] rows.
+ * scratch: fs_ptf_fold_scratch_bytes((V - 1) * P, h, w). */
+int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const float* xs, const float* rho,
+                const float* om, const float* dep, const float* Es, const float* E0, const float* w2c,
+                const float* kpix, float depth_thres, const float* gru_tables, void* scratch,
+                float* const* bufA, float* const* bufB, int32_t* counts, void* stream);
 
 /* The GRU of the fold step on the fp32 matrix cores (networks.py:188-214): cat[n,176] rows from
  * fs_ptf_gru_inputs -> fused[n,64].  `tables` = the six weight matrices and biases pre-arranged in MFMA
