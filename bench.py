@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--views", type=int, default=8, help="target views per step per GPU")
+    ap.add_argument("--views", type=int, default=16, help="target views per step per GPU (one decoder call)")
     ap.add_argument("--workload", default="c3_968x1296_1M",
                     help="c3_968x1296_1M (metric config) | c2_640x480_300k | c1_256x256_plumbing")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
