@@ -72,7 +72,8 @@ SIGNATURES = {
                                  + [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _VP]),
     "fs_ptf_fold_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
     "fs_ptf_fold_step": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 14 + [C.c_float] + [_VP] * 10),
-    "fs_ptf_fold": (C.c_int, [C.c_int32] * 3 + [_VP] * 9 + [C.c_float] + [_VP] * 2 + [C.POINTER(C.c_void_p)] * 2 + [_VP] * 2),
+    "fs_ptf_fold_bytes": (C.c_size_t, [C.c_int32] * 3),
+    "fs_ptf_fold": (C.c_int, [C.c_int32] * 3 + [_VP] * 8 + [C.c_float] + [_VP] * 2 + [C.POINTER(C.c_void_p)] * 2 + [_VP] * 2),
     "fs_frame_views": (C.c_int, [C.c_int32] + [_VP] * 4 + [C.c_int32] + [_VP] * 6),
     "fs_depth_tail_forward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 7),
     "fs_depth_tail_backward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 13),

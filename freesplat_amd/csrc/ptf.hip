@@ -472,19 +472,57 @@ FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int3
     return FS_OK;
 }
 
-// All fold steps of one scene in one host call: views 1 .. V-1 are folded into the state that starts as view 0.
-// lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es / w2c [V,16], kpix [V,4]; E0 [P,16] = view 0's extrinsics repeated
-// (the initial per-Gaussian extrinsics); bufA / bufB: two sets of 6 state arrays (G, X, R, O, E, D) with V*P rows each,
-// written alternately; counts [V,4].  The final state is in set ((V - 1) & 1 ? A : B) with counts[V-1][3] rows.
-FS_API int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const float* xs, const float* rho,
-                       const float* om, const float* dep, const float* Es, const float* E0, const float* w2c,
-                       const float* kpix, float depth_thres, const float* gru_tables, void* scratch,
-                       float* const* bufA, float* const* bufB, int32_t* counts, void* stream_)
+// Camera constants of the fold in one launch: thread i scales the normalised intrinsics of view i to pixels
+// (encoder_freesplat.py:445-448, one multiply each: same bits as torch); all threads replicate view 0's extrinsics per
+// pixel (the initial per-Gaussian extrinsics, :441).  The world-to-camera matrices are NOT formed here: a pixel's
+// round-half-even decision can hinge on their last bit, so they come from the same torch inverse the reference uses.
+__global__ __launch_bounds__(256) void ptf_cameras_kernel(int V, int P, int h, int w, const float* __restrict__ Es,
+                                                          const float* __restrict__ Kn, float* __restrict__ kpix,
+                                                          float* __restrict__ E0)
 {
-    if (V < 2 || h <= 0 || w <= 0 || !lat || !xs || !rho || !om || !dep || !Es || !E0 || !w2c || !kpix || !gru_tables ||
-        !scratch || !bufA || !bufB || !counts)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < (long long)P * 4) ((float4*)E0)[t] = ((const float4*)Es)[t & 3];
+    if (t >= V) return;
+    const float* K = Kn + 9 * t;
+    kpix[4 * t] = K[0] * (float)w; kpix[4 * t + 1] = K[4] * (float)h;
+    kpix[4 * t + 2] = K[2] * (float)w; kpix[4 * t + 3] = K[5] * (float)h;
+}
+
+namespace {
+size_t fold_camera_bytes(int V, int P) { return align_up((size_t)V * 4 * 4, 256) + align_up((size_t)P * 64, 256); }
+}
+
+FS_API size_t fs_ptf_fold_bytes(int32_t V, int32_t h, int32_t w)
+{
+    if (V < 2 || h <= 0 || w <= 0) return 0;
+    return fold_layout((V - 1) * h * w, h * w).total + fold_camera_bytes(V, h * w);
+}
+
+// All fold steps of one scene in one host call: views 1 .. V-1 are folded into the state that starts as view 0.
+// lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es [V,16] (camera-to-world), w2c [V,16] (its inverse), Kn [V,9]
+// (normalised intrinsics);
+// bufA / bufB: two sets of 6 state arrays (G, X, R, O, E, D) with V*P rows each (2*P for V == 2, bufB unused), written
+// alternately; counts [V,4].  The final state is in set A if (V - 1) is odd, else B, with counts[V-1][3] rows.
+// scratch: fs_ptf_fold_bytes(V, h, w).
+FS_API int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const float* xs, const float* rho,
+                       const float* om, const float* dep, const float* Es, const float* w2c, const float* Kn,
+                       float depth_thres, const float* gru_tables, void* scratch, float* const* bufA, float* const* bufB,
+                       int32_t* counts, void* stream_)
+{
+    if (V < 2 || h <= 0 || w <= 0 || !lat || !xs || !rho || !om || !dep || !Es || !w2c || !Kn || !gru_tables || !scratch ||
+        !bufA || !bufB || !counts)
         return FS_ERR_INVALID_ARG;
     const size_t P = (size_t)h * w;
+    hipStream_t st = (hipStream_t)stream_;
+    char* cam = (char*)scratch + fold_layout((int)((V - 1) * P), (int)P).total;
+    float* kpix = (float*)cam;
+    float* E0 = (float*)(cam + align_up((size_t)V * 4 * 4, 256));
+    {
+        const long long nt = (long long)P * 4 > V ? (long long)P * 4 : V;
+        hipLaunchKernelGGL(ptf_cameras_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, V, (int)P, h, w, Es,
+                           Kn, kpix, E0);
+        FS_CHECK_LAUNCH("ptf_cameras");
+    }
     const float* cur[6] = {lat, xs, rho, om, E0, dep};
     for (int i = 1; i < V; ++i) {
         float* const* out = (i & 1) ? bufA : bufB;

@@ -150,22 +150,18 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
     P = h * w
     if V == 1:
         return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
-    # per-view camera constants for all views at once
-    K = f(intrinsics[0])
-    kpix = torch.stack([K[:, 0, 0] * w, K[:, 1, 1] * h, K[:, 0, 2] * w, K[:, 1, 2] * h], dim=-1).contiguous()   # [V,4]
-    w2c = torch.linalg.inv_ex(Es.view(V, 4, 4)).inverse.reshape(V, 16).contiguous()
     tables = gru_tables(gru)
     # the state after view 0 is view 0 itself; fs_ptf_fold folds views 1 .. V-1 into it, writing the successive states
-    # alternately into two sets of buffers -- one library call, one host sync afterwards
-    E0 = Es[0].reshape(1, 16).repeat(P, 1)
+    # alternately into two sets of buffers -- one library call (camera constants included), one host sync afterwards
+    Kn = f(intrinsics[0]).reshape(V, 9)
+    w2c = torch.linalg.inv_ex(Es.view(V, 4, 4)).inverse.reshape(V, 16).contiguous()   # (the reference's own inverse)
     rows = 2 * P if V == 2 else V * P
     bufs = [[torch.empty(rows, n, device=dev) for n in (64, 3, 1, 1, 16, 1)] for _ in range(1 if V == 2 else 2)]
     ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in b]) for b in bufs]
     counts = torch.empty(V, 4, dtype=torch.int32, device=dev)
-    scratch = torch.empty(L.fs_ptf_fold_scratch_bytes((V - 1) * P, h, w), dtype=torch.uint8, device=dev)
-    _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), p(E0), p(w2c), p(kpix),
-                             C.c_float(depth_thres), p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts),
-                             _lib.current_stream()), "fs_ptf_fold")
+    scratch = torch.empty(L.fs_ptf_fold_bytes(V, h, w), dtype=torch.uint8, device=dev)
+    _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), p(w2c), p(Kn), C.c_float(depth_thres),
+                             p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts), _lib.current_stream()), "fs_ptf_fold")
     n = int(counts[V - 1, 3].item())               # the only host sync of the fold
     G, X, _, _, E, D = bufs[0] if ((V - 1) & 1 or V == 2) else bufs[1]
     return G[None, :n], X[None, :n], E[:n].view(1, n, 4, 4), D[None, :n, 0]

@@ -253,15 +253,16 @@ int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, 
                      int32_t* counts, void* stream);
 
 /* All fold steps of one scene in one host call (no host sync, no allocation): views 1 .. V-1 are folded into the state
- * that starts as view 0.  lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es / w2c [V,16] (camera-to-world and its
- * inverse), kpix [V,4] = {fx, fy, cx, cy} in pixels; E0 [P,16] = view 0's extrinsics repeated per pixel.  bufA / bufB:
- * two sets of 6 state arrays {G [.,64], X [.,3], R, O, E [.,16], D} with V*P rows each, written alternately;
- * counts [V,4].  The final state is set A if (V - 1) is odd, else B, with counts[V-1][3] rows.
- * scratch: fs_ptf_fold_scratch_bytes((V - 1) * P, h, w). */
+ * that starts as view 0.  lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es [V,16] (camera-to-world), w2c [V,16]
+ * (its inverse, from the caller: a pixel's rounding can hinge on its last bit, so it must be the reference's own
+ * torch inverse), Kn [V,9] (normalised intrinsics; scaled to pixels on the device, encoder_freesplat.py:445-448).  bufA / bufB: two sets of 6 state arrays {G [.,64], X [.,3], R, O, E [.,16], D} with V*P rows
+ * each (2*P for V == 2, where bufB is unused), written alternately; counts [V,4].  The final state is set A if
+ * (V - 1) is odd, else B, with counts[V-1][3] rows.  scratch: fs_ptf_fold_bytes(V, h, w). */
+size_t fs_ptf_fold_bytes(int32_t V, int32_t h, int32_t w);
 int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const float* xs, const float* rho,
-                const float* om, const float* dep, const float* Es, const float* E0, const float* w2c,
-                const float* kpix, float depth_thres, const float* gru_tables, void* scratch,
-                float* const* bufA, float* const* bufB, int32_t* counts, void* stream);
+                const float* om, const float* dep, const float* Es, const float* w2c, const float* Kn,
+                float depth_thres, const float* gru_tables, void* scratch, float* const* bufA, float* const* bufB,
+                int32_t* counts, void* stream);
 
 /* The GRU of the fold step on the fp32 matrix cores (networks.py:188-214): cat[n,176] rows from
  * fs_ptf_gru_inputs -> fused[n,64].  `tables` = the six weight matrices and biases pre-arranged in MFMA
