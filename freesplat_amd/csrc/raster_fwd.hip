@@ -402,30 +402,39 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ counters,
                                                          unsigned long long cap)
 {
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
+    __shared__ uint32_t s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (T + 1023) / 1024;
     const int lo = min(T, t * per), hi = min(T, lo + per);
     uint32_t s = 0;
     for (int k = lo; k < hi; ++k) s += counts[k];
-    part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = (t >= off) ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    // inclusive scan of the 1024 partial sums: shuffles inside a wavefront, the 16 wavefront totals through LDS
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
     }
-    uint32_t run = part[t] - s;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t v = s_wave[k];
+        before += k < wave ? v : 0u;
+        total += v;
+    }
+    inc += before;
+    uint32_t run = inc - s;
     for (int k = lo; k < hi; ++k) {
         offsets[k] = run;
         cursors[k] = 0;
         run += counts[k];
     }
     if (t == 1023) {
-        offsets[T] = part[1023];
-        counters[0] = part[1023];
-        counters[1] = ((unsigned long long)part[1023] > cap) ? 1u : 0u;
+        offsets[T] = total;
+        counters[0] = total;
+        counters[1] = ((unsigned long long)total > cap) ? 1u : 0u;
     }
 }
 
