@@ -403,11 +403,16 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
                                                          unsigned long long cap)
 {
     __shared__ uint32_t s_wave[16];
+    __shared__ unsigned long long s_wide[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (T + 1023) / 1024;
     const int lo = min(T, t * per), hi = min(T, lo + per);
     uint32_t s = 0;
-    for (int k = lo; k < hi; ++k) s += counts[k];
+    unsigned long long wide = 0;  // the instance total in 64 bits: offsets are 32-bit, a wrapped total must not pass as small
+    for (int k = lo; k < hi; ++k) { s += counts[k]; wide += counts[k]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wide += __shfl_xor(wide, d, 64);
+    if (lane == 0) s_wide[wave] = wide;
     // inclusive scan of the 1024 partial sums: shuffles inside a wavefront, the 16 wavefront totals through LDS
     uint32_t inc = s;
 #pragma unroll
@@ -432,9 +437,12 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
         run += counts[k];
     }
     if (t == 1023) {
+        unsigned long long total64 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) total64 += s_wide[k];
         offsets[T] = total;
-        counters[0] = total;
-        counters[1] = ((unsigned long long)total > cap) ? 1u : 0u;
+        counters[0] = total64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total64;  // saturates: "more than 2^32 - 1"
+        counters[1] = (total64 > cap) ? 1u : 0u;
     }
 }
 
@@ -1004,6 +1012,7 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
     if (gx > 65535 || gy > 65535) return FS_ERR_UNSUPPORTED;
     if (d.N > (1 << 28)) return FS_ERR_UNSUPPORTED;  // list entries are (id << 4 | quadrant mask)
+    if (cap > 0xFFFFFFFFll) return FS_ERR_UNSUPPORTED;  // tile ranges are 32-bit
     hipStream_t st = (hipStream_t)stream_;
     const int T = gx * gy;
     const size_t P = (size_t)d.H * d.W;
