@@ -217,3 +217,41 @@ def test_backward_matches_autograd_of_dense(sh_degree, precomp, with_depth):
         close(got["colors_precomp"], cp.grad, "colors")
     else:
         close(got["shs"], s.grad, "shs")
+
+
+def test_backward_matches_finite_differences_of_dense():
+    """the hand-derived backward of the C oracle against central finite differences of the
+    float64 dense restatement (the discrete pieces -- tile rects, radii, depth order -- held fixed), on a scene small
+    enough to perturb parameter by parameter."""
+    H, W = 24, 32
+    scene, cams = small_scene(N=12, H=H, W=W, seed=77, sh_degree=1)
+    scene["opacities"] = scene["opacities"].clamp(0.1, 0.8)
+    vi = view_inputs(scene, cams, 0, H, W, bg=(0.2, 0.1, 0.3))
+    st = oracle_forward(vi)
+    rng = np.random.default_rng(3)
+    g_color = rng.normal(size=(3, H, W)).astype(np.float32)
+    got = ro.backward(st, g_color)
+    order = torch.from_numpy(np.lexsort((np.arange(st["N"]), st["depths"].view(np.uint32))).astype(np.int64))
+    gc = torch.from_numpy(g_color).double()
+
+    def loss(m, c, o, s):
+        color, _, _ = render_dense(H, W, vi["tanfovx"], vi["tanfovy"], vi["bg"], vi["viewmatrix"], vi["projmatrix"],
+                                   vi["sh_degree"], vi["campos"], m, c, o, shs=s, rect=torch.from_numpy(st["rect"]),
+                                   radii=torch.from_numpy(st["radii"]), order=order)
+        return float((color * gc).sum())
+
+    base = [vi[k].double().clone() for k in ("means3D", "cov3D", "opacities", "shs")]
+    names = ("means3D", "cov3D", "opacities", "shs")
+    for which, name in enumerate(names):
+        flat = base[which].reshape(-1)
+        ana = np.asarray(got[name], np.float64).reshape(-1)
+        idx = rng.choice(flat.numel(), size=min(12, flat.numel()), replace=False)
+        fd = np.zeros(len(idx))
+        for j, i in enumerate(idx):
+            h = 1e-5 * max(1.0, abs(float(flat[i])))
+            args_p, args_m = [t.clone() for t in base], [t.clone() for t in base]
+            args_p[which].reshape(-1)[i] += h
+            args_m[which].reshape(-1)[i] -= h
+            fd[j] = (loss(*args_p) - loss(*args_m)) / (2 * h)
+        scale = np.abs(ana).max() + 1e-12
+        assert np.abs(fd - ana[idx]).max() / scale < 2e-3, (name, fd, ana[idx])
