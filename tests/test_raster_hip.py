@@ -324,6 +324,48 @@ def test_frame_views_matches_reference_framing(hip_device):
     assert (s1 == 1).all()
 
 
+def test_splatter_script_scenario(hip_device):
+    """The scenario of the reference's own smoke script (src/scripts/test_splatter.py): ONE unit Gaussian at the
+    origin, opacity 1, only the degree-2 coefficients of the red channel set (= 10), cameras spinning around it at
+    radius 10 with fx = fy = 0.5, near 0.1 / far 20 -- restricted to the degrees the rasterizer supports (the script
+    asks for 25 coefficients; the extension evaluates at most degree 3).  Product (render_cuda, the script's call) vs
+    the oracle, plus the structure the script's comments describe (green / blue carry no harmonics)."""
+    from freesplat_amd import synthetic
+    from freesplat_amd.decoder import _frame, render_cuda
+    from oracle import raster_oracle as ro
+    H = W = 128
+    frames = 6
+    ang = np.linspace(0.0, 2 * np.pi, frames, endpoint=False)
+    c2w = np.stack([synthetic._look_at_c2w(np.array([10 * np.sin(a), 0.0, -10 * np.cos(a)]), np.zeros(3)) for a in ang])
+    E = torch.from_numpy(c2w.astype(np.float32))
+    K = torch.tensor([[0.5, 0, 0.5], [0, 0.5, 0.5], [0, 0, 1.0]]).expand(frames, 3, 3).contiguous()
+    near, far = torch.full((frames,), 0.1), torch.full((frames,), 20.0)
+    q = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(4)))[0]
+    cov = (q @ torch.eye(3) @ q.T)[None]                      # rotation @ diag(1) @ rotation^T
+    means, opac = torch.zeros(1, 3), torch.ones(1)
+    sh = torch.zeros(1, 3, 9)
+    sh[:, 0, 4:9] = 10.0
+    dev = hip_device
+    rep = lambda x: x[None].expand(frames, *x.shape).to(dev)
+    with torch.no_grad():
+        color, depth = render_cuda(E.to(dev), K.to(dev), near.to(dev), far.to(dev), (H, W), torch.zeros(frames, 3, device=dev),
+                                   rep(means), rep(cov), rep(sh), rep(opac))
+    color = color.cpu().numpy()
+    extr, scale, tx, ty, view, full = _frame(E, K, near, far, True)
+    r, c = torch.triu_indices(3, 3)
+    for i in range(frames):
+        s = scale[i]
+        st = ro.forward(H, W, float(tx[i]), float(ty[i]), np.zeros(3, np.float32), view[i].numpy(), full[i].numpy(), 2,
+                        extr[i, :3, 3].numpy(), (means * s).numpy(), (cov * s * s)[:, r, c].numpy(), opac.numpy(),
+                        shs=sh.transpose(-1, -2).contiguous().numpy())
+        assert np.abs(color[i] - st["color"]).max() <= ATOL_PIXEL
+        a = st["alpha"]
+        assert a.max() > 0.9 and a[0, 0] == 0.0                               # an opaque blob in the middle
+        np.testing.assert_allclose(color[i, 1], 0.5 * a, atol=1e-5)           # green, blue: DC 0 -> 0.5, no harmonics
+        np.testing.assert_allclose(color[i, 2], 0.5 * a, atol=1e-5)
+    assert color[0, 0].max() > 1.0 and color[2, 0].max() == 0.0   # red follows the degree-2 lobes as the camera turns
+
+
 def test_cpu_tensor_raises(hip_device):
     from freesplat_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     scene, cams = small_scene(N=10, H=16, W=16, seed=1)
