@@ -1010,7 +1010,7 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     if (shs && (d.sh_degree < 0 || d.sh_degree > 3 || (d.sh_degree + 1) * (d.sh_degree + 1) > d.M))
         return FS_ERR_UNSUPPORTED;
     const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
-    if (gx > 65535 || gy > 65535) return FS_ERR_UNSUPPORTED;
+    if (gx > 32767 || gy > 32767) return FS_ERR_UNSUPPORTED;  // tile coordinates travel as 15-bit fields (ushort4 rects, packed shuffles)
     if (d.N > (1 << 28)) return FS_ERR_UNSUPPORTED;  // list entries are (id << 4 | quadrant mask)
     if (cap > 0xFFFFFFFFll) return FS_ERR_UNSUPPORTED;  // tile ranges are 32-bit
     hipStream_t st = (hipStream_t)stream_;
