@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
         s_m[k] = m[ci];
         s_rs[k] = 1.0f / s[ci];
     }
-    const Bilin q = bilin_x2(in ? y : 0, in ? x : 0, h2, w2);
+    // (threads past the image edge take the taps of the nearest inside pixel of THIS tile: their patch-local
+    // indices must stay inside the LDS patch; their results are never stored)
+    const Bilin q = bilin_x2(min(y, H - 1), min(x, W - 1), h2, w2);
     // patch-local indices of the four taps
     const int l00 = (q.i00 / w2 - cy0) * pw + (q.i00 % w2 - cx0), l01 = (q.i01 / w2 - cy0) * pw + (q.i01 % w2 - cx0);
     const int l10 = (q.i10 / w2 - cy0) * pw + (q.i10 % w2 - cx0), l11 = (q.i11 / w2 - cy0) * pw + (q.i11 % w2 - cx0);

@@ -75,11 +75,12 @@ constexpr int kBwdQuads = 7;  // float4 per slot of two survivors
 __global__ __launch_bounds__(64) void render_bwd_kernel(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-    const float* __restrict__ bg, const float* __restrict__ final_T,
+    const float* __restrict__ bg, const uint32_t* __restrict__ counters, const float* __restrict__ final_T,
     const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, float* __restrict__ grad)
 {
     __shared__ float4 s_pair[32 * kBwdQuads];
+    if (counters && counters[1]) return;  // the forward overflowed its capacity: no image, no lists -> zero gradients
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     const int wave = (blockIdx.x >> 3) & 3;  // quadrant; same workgroup order as the forward
     const int tile = tile_for_block((int)(blockIdx.x >> 5) * 8 + (int)(blockIdx.x & 7), gx, gy);
@@ -493,7 +494,7 @@ namespace {
 
 // blend backward of ONE view into its screen-space gradient rows (grad [N, 12], zeroed here)
 int launch_render_bwd(const fs_raster_dims& d, const float* bg, const void* geom, const void* binning, const void* image,
-                      const float* dL_dcolor, const float* dL_ddepth, float* grad, hipStream_t st)
+                      const uint32_t* counters, const float* dL_dcolor, const float* dL_ddepth, float* grad, hipStream_t st)
 {
     const int T = num_tiles(d.H, d.W);
     const size_t P = (size_t)d.H * d.W;
@@ -510,7 +511,7 @@ int launch_render_bwd(const fs_raster_dims& d, const float* bg, const void* geom
     {
         ScopedStage prof_(kStRenderBwd, st);
         hipLaunchKernelGGL(render_bwd_kernel, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
-                           point_list, g.rec, bg, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
+                           point_list, g.rec, bg, counters, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
     }
     FS_CHECK_LAUNCH("render_bwd");
     return FS_OK;
@@ -541,23 +542,25 @@ FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, 
                               const float* shs, const float* colors_precomp, const float* bg,
                               const float* viewmatrix, const float* projmatrix, const float* campos,
                               const float* tanfov_dev, const float* scale_dev,
-                              const void* geom, const void* binning, const void* image,
+                              const void* geom, const void* binning, const void* image, const uint32_t* counters,
                               const float* dL_dcolor, const float* dL_ddepth, void* grad_scratch,
                               float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D,
                               float* dL_dshs, float* dL_dcolors, float* dL_dopacities, int accumulate,
                               void* stream_)
 {
-    if (!dims || !means3D || !cov3D || !bg || !viewmatrix || !projmatrix || !campos || !geom ||
+    if (!dims) return FS_ERR_INVALID_ARG;
+    const fs_raster_dims d = *dims;
+    if (d.N < 0) return FS_ERR_INVALID_ARG;
+    if (d.N == 0) return FS_OK;  // an empty Gaussian set has empty gradients; its arrays may be NULL (as in the forward)
+    if (!means3D || !cov3D || !bg || !viewmatrix || !projmatrix || !campos || !geom ||
         !binning || !image || !dL_dcolor || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D ||
         !dL_dcov3D || !dL_dopacities)
         return FS_ERR_INVALID_ARG;
     if ((shs == nullptr) == (colors_precomp == nullptr)) return FS_ERR_INVALID_ARG;
     if (shs ? !dL_dshs : !dL_dcolors) return FS_ERR_INVALID_ARG;
-    const fs_raster_dims d = *dims;
-    if (d.N <= 0) return FS_OK;
     if (shs && d.M * 3 > 48) return FS_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream_;
-    int rc = launch_render_bwd(d, bg, geom, binning, image, dL_dcolor, dL_ddepth, (float*)grad_scratch, st);
+    int rc = launch_render_bwd(d, bg, geom, binning, image, counters, dL_dcolor, dL_ddepth, (float*)grad_scratch, st);
     if (rc != FS_OK) return rc;
     return launch_preprocess_bwd(d, 1, means3D, cov3D, shs, viewmatrix, projmatrix, campos, tanfov_dev, scale_dev, geom, 0,
                                  grad_scratch, 0, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs, dL_dcolors,
@@ -582,7 +585,7 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
                                     const float* shs, const float* colors_precomp, const float* bg,
                                     const float* viewmatrix, const float* projmatrix, const float* campos,
                                     const float* tanfov, const float* scale, const void* geom, const void* binning,
-                                    const void* image, const size_t strides[3], const float* dL_dcolor,
+                                    const void* image, const uint32_t* counters, const size_t strides[3], const float* dL_dcolor,
                                     const float* dL_ddepth, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
                                     float* dL_dcov3D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
                                     int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream)
@@ -590,15 +593,21 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
     if (!dims || v < 0 || !strides || n_streams < 0 || n_streams > kMaxStreamsBwd || (n_streams > 0 && !streams))
         return FS_ERR_INVALID_ARG;
     if (v == 0) return FS_OK;
+    const fs_raster_dims d = *dims;
+    if (d.N < 0) return FS_ERR_INVALID_ARG;
+    if (d.N == 0) return FS_OK;
     if (!means3D || !cov3D || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
         !dL_dcolor || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D || !dL_dcov3D || !dL_dopacities)
         return FS_ERR_INVALID_ARG;
     if ((shs == nullptr) == (colors_precomp == nullptr)) return FS_ERR_INVALID_ARG;
     if (shs ? !dL_dshs : !dL_dcolors) return FS_ERR_INVALID_ARG;
-    const fs_raster_dims d = *dims;
-    if (d.N <= 0) return FS_OK;
     if (shs && d.M * 3 > 48) return FS_ERR_UNSUPPORTED;
-    static thread_local ForkJoinBwd fj;
+    // events belong to the device that was current when they were created: one cached set per (thread, device)
+    static thread_local ForkJoinBwd* fj_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) { set_last_error("hipGetDevice", hipGetLastError()); return FS_ERR_LAUNCH; }
+    if (!fj_dev[dev_]) fj_dev[dev_] = new ForkJoinBwd();
+    ForkJoinBwd& fj = *fj_dev[dev_];
     const int ns = n_streams <= 1 ? 0 : (n_streams < v ? n_streams : v);
     hipStream_t main = (hipStream_t)main_stream;
     if (ns > 0) {
@@ -618,7 +627,7 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
         hipStream_t st = ns > 0 ? (hipStream_t)streams[i % ns] : main;
         rc = launch_render_bwd(d, bg + 3 * (size_t)i, (const char*)geom + strides[0] * i,
                                (const char*)binning + strides[1] * i, (const char*)image + strides[2] * i,
-                               dL_dcolor + 3 * P * i, dL_ddepth ? dL_ddepth + P * i : nullptr,
+                               counters ? counters + 2 * (size_t)i : nullptr, dL_dcolor + 3 * P * i, dL_ddepth ? dL_ddepth + P * i : nullptr,
                                (float*)((char*)grad_scratch + grad_stride * i), st);
     }
     for (int s = 0; s < ns; ++s)

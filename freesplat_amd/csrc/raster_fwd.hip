@@ -1101,7 +1101,12 @@ FS_API int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const 
     if (!bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image || !scratch || !out_color ||
         !out_depth || !out_alpha || !counters)
         return FS_ERR_INVALID_ARG;
-    static thread_local fs::ForkJoin fj;
+    // events belong to the device that was current when they were created: one cached set per (thread, device)
+    static thread_local fs::ForkJoin* fj_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) { set_last_error("hipGetDevice", hipGetLastError()); return FS_ERR_LAUNCH; }
+    if (!fj_dev[dev_]) fj_dev[dev_] = new fs::ForkJoin();
+    fs::ForkJoin& fj = *fj_dev[dev_];
     const int ns = n_streams <= 1 ? 0 : (n_streams < v ? n_streams : v);
     hipStream_t main = (hipStream_t)main_stream;
     if (ns > 0) {

@@ -242,7 +242,7 @@ class _RenderViews(torch.autograd.Function):
             rs.num_rendered = -1
             states.append(rs)
         # everything the one-call backward needs while the views still live in the strided buffers of this call
-        batch = dict(dims=dims, sz=sz, geom=geom, binning=binning, image=image, bgs=bgs, views=views, fulls=fulls,
+        batch = dict(dims=dims, sz=sz, geom=geom, binning=binning, image=image, counters=counters, bgs=bgs, views=views, fulls=fulls,
                      campos=campos, tanfov=tanfov, scale=scale)
         if deferred:
             # without a backward to come only the 8-byte counter pairs stay alive until the check, not the buffers
@@ -277,7 +277,10 @@ class _RenderViews(torch.autograd.Function):
             g_depth = g_depth.contiguous()
         dev = means.device
         N = means.shape[0]
-        if ctx.batch is not None and N > 0:
+        if N == 0 or v == 0:   # nothing rendered: empty / zero gradients (torch hands out NULL pointers for empty tensors)
+            return (torch.zeros_like(means), torch.zeros_like(cov6), torch.zeros_like(shs),
+                    torch.zeros(N, dtype=torch.float32, device=dev)) + (None,) * 10
+        if ctx.batch is not None:
             # one library call: the blend backward of the views alternates over the side streams, then ONE pass
             # over the Gaussians sums the parameter gradients of all views (fs_raster_backward_views)
             b = ctx.batch
@@ -294,7 +297,8 @@ class _RenderViews(torch.autograd.Function):
             p = R._lib.ptr
             R._lib.check(R._lib.lib().fs_raster_backward_views(
                 C.byref(b["dims"]), v, p(means), p(cov6), p(shs), None, p(b["bgs"]), p(b["views"]), p(b["fulls"]),
-                p(b["campos"]), p(b["tanfov"]), p(b["scale"]), p(b["geom"]), p(b["binning"]), p(b["image"]), strides,
+                p(b["campos"]), p(b["tanfov"]), p(b["scale"]), p(b["geom"]), p(b["binning"]), p(b["image"]), p(b["counters"]),
+                strides,
                 p(g_color), p(g_depth), p(scratch), p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]), p(out["shs"]),
                 None, p(out["opacities"]), 0, n_streams if n_streams > 1 else 0, handles, R._lib.current_stream()),
                 "fs_raster_backward_views")
@@ -312,7 +316,9 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  covariances: Tensor, sh_coefficients: Tensor, opacities: Tensor,
                  scale_invariant: bool = True, check: str = "now"):
     """v views [v,...] of ONE Gaussian set (means [G,3], covariances [G,3,3], sh [G,3,d_sh],
-    opacities [G]).  Same numbers as render_cuda on v repeated copies, but the per-view 1/near
+    opacities [G]).  Same result as render_cuda on v repeated copies to within fp32 rounding of the camera
+    matrices (fs_frame_views forms them in double and rounds once; render_cuda, like the reference, chains fp32
+    torch ops -- tests/test_raster_hip.py compares the two with a tolerance); the per-view 1/near
     rescale and tan(fov) stay on the device (fs_raster_forward's scale_dev / tanfov_dev), nothing is
     repeated, the images are written straight into the [v,...] outputs, and the only host sync is
     the instance-capacity check: check="now" (default) does it at the end of the call and re-renders

@@ -200,7 +200,7 @@ def rasterize_backward(rs: RasterState, means3D, cov3D, shs, colors, g_color, g_
     p = _lib.ptr
     _lib.check(_lib.lib().fs_raster_backward(
         C.byref(d), p(means3D), p(cov3D), p(shs), p(colors), p(rs.bg), p(rs.view), p(rs.proj),
-        p(rs.campos), p(rs.tanfov), p(rs.scale), p(rs.geom), p(rs.binning), p(rs.image), p(g_color),
+        p(rs.campos), p(rs.tanfov), p(rs.scale), p(rs.geom), p(rs.binning), p(rs.image), p(rs.counters), p(g_color),
         p(g_depth), p(scratch),
         p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]), p(out["shs"]), p(out["colors"]),
         p(out["opacities"]), 1 if accumulate else 0, _lib.current_stream()), "fs_raster_backward")

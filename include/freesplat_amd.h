@@ -134,7 +134,10 @@ int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const float* 
 
 /*
  * Backward.  dL_dcolor[3,H,W] (required), dL_ddepth[H,W] (may be NULL).  geom/binning/image
- * are the buffers filled by the matching forward.  `grad_scratch` >= N*12*4 bytes.
+ * are the buffers filled by the matching forward, `counters` the forward's counter pair (may be NULL): when its
+ * overflow flag is set the forward produced no image and no valid lists, and the backward of that view yields
+ * ZERO gradients instead of walking unbacked tile ranges (a caller that defers the capacity check -- decoder
+ * check="deferred" -- may reach backward before it has seen the flag).  `grad_scratch` >= N*12*4 bytes.
  * Outputs (device; overwritten when accumulate == 0, added to when accumulate != 0 -- the
  * multi-view decoder sums the per-view gradients of one shared Gaussian set this way):
  * dL_dmeans3D[N,3], dL_dmeans2D[N,3] (screen-space grad
@@ -145,7 +148,7 @@ int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const f
                        const float* shs, const float* colors_precomp, const float* bg,
                        const float* viewmatrix, const float* projmatrix, const float* campos,
                        const float* tanfov_dev, const float* scale_dev,
-                       const void* geom, const void* binning, const void* image,
+                       const void* geom, const void* binning, const void* image, const uint32_t* counters,
                        const float* dL_dcolor, const float* dL_ddepth, void* grad_scratch,
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs,
                        float* dL_dcolors, float* dL_dopacities, int accumulate, void* stream);
@@ -337,7 +340,8 @@ int fs_depth_tail_backward(int32_t B, int32_t D, int32_t h2, int32_t w2, const f
                            float* scratch_gprob, float* g_logits, void* stream);
 
 /* Backward of v views of ONE Gaussian set in one host call (counterpart of fs_raster_forward_views; same packed
- * per-view arrays and buffer strides[0..2] = geom / binning / image).  dL_dcolor [v,3,H,W], dL_ddepth [v,H,W] | NULL.
+ * per-view arrays and buffer strides[0..2] = geom / binning / image; counters [v,2] | NULL as in fs_raster_backward).
+ * dL_dcolor [v,3,H,W], dL_ddepth [v,H,W] | NULL.
  * grad_scratch: v buffers of align_up(N*48, 256) bytes.  The blend backward of the views alternates over the
  * streams; after the join ONE pass over the Gaussians turns the screen-space gradients of all views into the
  * parameter gradients (inputs read once, sums in registers, outputs written once; `accumulate` adds to their
@@ -346,7 +350,7 @@ int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float*
                              const float* shs, const float* colors_precomp, const float* bg,
                              const float* viewmatrix, const float* projmatrix, const float* campos,
                              const float* tanfov, const float* scale, const void* geom, const void* binning,
-                             const void* image, const size_t strides[3], const float* dL_dcolor,
+                             const void* image, const uint32_t* counters, const size_t strides[3], const float* dL_dcolor,
                              const float* dL_ddepth, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
                              float* dL_dcov3D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
                              int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream);

@@ -59,6 +59,14 @@ static inline float fso_exp(float x)
 }
 FSO_API float fso_exp_public(float x) { return fso_exp(x); }
 
+/* Blend-loop exponential: 0 = the arithmetic contract above (what the HIP kernels implement, the default),
+ * 1 = libm expf().  Mode 1 exists ONLY to quantify how much of the image depends on the private contract
+ * (tests/test_raster_hip.py::test_exp_contract_sensitivity, bench.py `parity.exp_contract`): it stands in for
+ * "some other correctly-behaving exp", e.g. the CUDA extension's __expf. */
+static int g_exp_mode = 0;
+FSO_API void fso_set_exp_mode(int mode) { g_exp_mode = mode; }
+static inline float fso_blend_exp(float x) { return g_exp_mode ? expf(x) : fso_exp(x); }
+
 static const float SH_C0 = 0.28209479177387814f;
 static const float SH_C1 = 0.4886025119029199f;
 static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
@@ -299,7 +307,7 @@ FSO_API void fso_render(const fso_params* P, const unsigned* ranges, const unsig
                     const float hA = -0.5f * co[0], hC = -0.5f * co[2], nB = -co[1];
                     const float power = fmaf(hA * dx, dx, fmaf(hC * dy, dy, (nB * dx) * dy));
                     if (power > 0.0f) continue;
-                    const float alpha = fminf(0.99f, co[3] * fso_exp(power));
+                    const float alpha = fminf(0.99f, co[3] * fso_blend_exp(power));
                     if (alpha < 1.0f / 255.0f) continue;
                     const float test_T = T * (1.0f - alpha);
                     if (test_T < 0.0001f) break;
@@ -325,10 +333,15 @@ FSO_API void fso_render(const fso_params* P, const unsigned* ranges, const unsig
 
 /*
  * Backward of the blend.  dL_dcolor [3,H,W], dL_ddepth [H,W] or NULL.
- * Accumulates (sequentially, deterministic): dL_dmean2D[2N], dL_dconic[3N] (x, y(half), z),
- * dL_dopacity[N], dL_drgb[3N], dL_dz[N].  Buffers must be zeroed by the caller.
- * Accumulation in double to serve as the accuracy reference for the float-atomic HIP path.
+ * Accumulates into dL_dmean2D[2N], dL_dconic[3N] (x, y(half), z), dL_dopacity[N], dL_drgb[3N], dL_dz[N]
+ * (buffers zeroed by the caller), in double, to serve as the accuracy reference for the float-atomic
+ * HIP path.
+ *
+ * Parallel AND deterministic: tiles run on OpenMP threads, each summing the per-pixel terms of its own list
+ * entries (fixed pixel order) into a private [entries x 10] block of doubles; the per-Gaussian totals are then
+ * formed by one sequential pass over the instance list (tile order).  No atomics, no thread-count dependence.
  */
+#define FSO_NPART 10
 FSO_API void fso_render_backward(const fso_params* P, const unsigned* ranges,
                                  const unsigned* point_list, const float* means2D,
                                  const float* conic_opacity, const float* rgb, const float* depths,
@@ -341,6 +354,9 @@ FSO_API void fso_render_backward(const fso_params* P, const unsigned* ranges,
     const int gx = (W + FSO_TILE - 1) / FSO_TILE, gy = (H + FSO_TILE - 1) / FSO_TILE;
     const size_t HW = (size_t)H * W;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const size_t I = ranges[2 * (gx * gy - 1) + 1];
+    double* part = (double*)calloc((I > 0 ? I : 1) * FSO_NPART, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 4)
     for (int tile = 0; tile < gx * gy; ++tile) {
         const int tx = tile % gx, ty = tile / gx;
         const unsigned a = ranges[2 * tile], b = ranges[2 * tile + 1];
@@ -358,13 +374,14 @@ FSO_API void fso_render_backward(const fso_params* P, const unsigned* ranges,
                 const float bgdot = P->bg[0] * g0 + P->bg[1] * g1 + P->bg[2] * g2;
                 float acc[4] = {0, 0, 0, 0}, lastc[4] = {0, 0, 0, 0}, last_alpha = 0.0f;
                 for (int k = last; k >= 1; --k) {
-                    const unsigned g = point_list[a + (unsigned)k - 1];
+                    const size_t slot = (size_t)a + (unsigned)k - 1;
+                    const unsigned g = point_list[slot];
                     const float dx = means2D[2 * g] - pfx, dy = means2D[2 * g + 1] - pfy;
                     const float* co = conic_opacity + 4 * g;
                     const float hA = -0.5f * co[0], hC = -0.5f * co[2], nB = -co[1];
                     const float power = fmaf(hA * dx, dx, fmaf(hC * dy, dy, (nB * dx) * dy));
                     if (power > 0.0f) continue;
-                    const float G = fso_exp(power);
+                    const float G = fso_blend_exp(power);
                     const float alpha = fminf(0.99f, co[3] * G);
                     if (alpha < 1.0f / 255.0f) continue;
                     T = T / (1.0f - alpha);
@@ -377,10 +394,11 @@ FSO_API void fso_render_backward(const fso_params* P, const unsigned* ranges,
                         lastc[ch] = c[ch];
                         dL_dalpha += (c[ch] - acc[ch]) * gg[ch];
                     }
-                    dL_drgb[3 * g] += (double)(w * g0);
-                    dL_drgb[3 * g + 1] += (double)(w * g1);
-                    dL_drgb[3 * g + 2] += (double)(w * g2);
-                    dL_dz[g] += (double)(w * gd);
+                    double* q = part + slot * FSO_NPART;
+                    q[6] += (double)(w * g0);
+                    q[7] += (double)(w * g1);
+                    q[8] += (double)(w * g2);
+                    q[9] += (double)(w * gd);
                     dL_dalpha *= T;
                     last_alpha = alpha;
                     dL_dalpha += (-Tf / (1.0f - alpha)) * bgdot;
@@ -388,15 +406,25 @@ FSO_API void fso_render_backward(const fso_params* P, const unsigned* ranges,
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddelx = -gdx * co[0] - gdy * co[1];
                     const float dG_ddely = -gdy * co[2] - gdx * co[1];
-                    dL_dmean2D[2 * g] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-                    dL_dmean2D[2 * g + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
-                    dL_dconic[3 * g] += (double)(-0.5f * gdx * dx * dL_dG);
-                    dL_dconic[3 * g + 1] += (double)(-0.5f * gdx * dy * dL_dG);
-                    dL_dconic[3 * g + 2] += (double)(-0.5f * gdy * dy * dL_dG);
-                    dL_dopacity[g] += (double)(G * dL_dalpha);
+                    q[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                    q[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                    q[2] += (double)(-0.5f * gdx * dx * dL_dG);
+                    q[3] += (double)(-0.5f * gdx * dy * dL_dG);
+                    q[4] += (double)(-0.5f * gdy * dy * dL_dG);
+                    q[5] += (double)(G * dL_dalpha);
                 }
             }
     }
+    for (size_t s = 0; s < I; ++s) {   /* fixed order: tile-major, then list position */
+        const unsigned g = point_list[s];
+        const double* q = part + s * FSO_NPART;
+        dL_dmean2D[2 * g] += q[0]; dL_dmean2D[2 * g + 1] += q[1];
+        dL_dconic[3 * g] += q[2]; dL_dconic[3 * g + 1] += q[3]; dL_dconic[3 * g + 2] += q[4];
+        dL_dopacity[g] += q[5];
+        dL_drgb[3 * g] += q[6]; dL_drgb[3 * g + 1] += q[7]; dL_drgb[3 * g + 2] += q[8];
+        dL_dz[g] += q[9];
+    }
+    free(part);
 }
 
 /*

@@ -42,7 +42,15 @@ def lib():
         _LIB.fso_preprocess.restype = C.c_long
         _LIB.fso_exp_public.restype = C.c_float
         _LIB.fso_exp_public.argtypes = [C.c_float]
+        _LIB.fso_set_exp_mode.argtypes = [C.c_int]
+        _LIB.fso_set_exp_mode.restype = None
     return _LIB
+
+
+def set_exp_mode(libm: bool) -> None:
+    """Blend-loop exp: False = the arithmetic contract shared with the HIP kernels (default); True = libm expf
+    (sensitivity studies only -- see raster_oracle.c:fso_set_exp_mode)."""
+    lib().fso_set_exp_mode(1 if libm else 0)
 
 
 def _p(a):

@@ -55,18 +55,25 @@ def test_config4_5_long_sequence_fold(hip_device, V, h, w):
 
 
 def test_config5_fp16_sh_storage(hip_device):
-    """fp16 SH = storage only: the image equals the fp32 path fed the fp16-rounded coefficients bit for bit,
-    and the gradients agree."""
-    from util_raster import hip_forward, small_scene, view_inputs
+    """fp16 SH = storage only (BASELINE config 5): against the ORACLE fed the fp16-rounded coefficients the image is
+    bit-exact and the gradients are within the backward's bar; and the fp32 HIP path on those coefficients gives
+    the same image bit for bit."""
+    from oracle import raster_oracle as ro
+    from util_raster import hip_forward, oracle_forward, small_scene, view_inputs
     H, W = 64, 80
     scene, cams = small_scene(N=1500, H=H, W=W, seed=12)
     vi = view_inputs(scene, cams, 0, H, W, bg=(0.1, 0.2, 0.3))
     vi32 = dict(vi); vi32["shs"] = vi["shs"].half().float()
     vi16 = dict(vi); vi16["shs"] = vi["shs"].half()
+    assert not torch.equal(vi32["shs"], vi["shs"])                     # the rounding is not a no-op on this scene
+    st = oracle_forward(vi32)
     (c32, _, d32, _), l32 = hip_forward(vi32, hip_device, requires_grad=True)
     (c16, _, d16, _), l16 = hip_forward(vi16, hip_device, requires_grad=True)
+    np.testing.assert_array_equal(c16.detach().cpu().numpy(), st["color"])
+    np.testing.assert_array_equal(d16.detach().cpu().numpy(), st["depth"])
     assert torch.equal(c32, c16) and torch.equal(d32, d16)
     w = torch.randn_like(c32)
+    ref = ro.backward(st, w.cpu().numpy())
     (c32 * w).sum().backward()
     (c16 * w).sum().backward()
     assert l16["shs"].grad.dtype == torch.float16
@@ -75,3 +82,8 @@ def test_config5_fp16_sh_storage(hip_device):
         assert (l32[k].grad - l16[k].grad).abs().max().item() <= 2e-4 * s, k
     s = l32["shs"].grad.abs().max().item()
     assert (l32["shs"].grad - l16["shs"].grad.float()).abs().max().item() <= 2e-3 * s   # fp16 rounding of the grad
+    for k in ("means3D", "cov3D", "opacities"):
+        r = ref[k]
+        assert np.abs(l16[k].grad.cpu().numpy().reshape(r.shape) - r).max() <= 2e-4 * np.abs(r).max(), k
+    r = ref["shs"]
+    assert np.abs(l16["shs"].grad.float().cpu().numpy() - r).max() <= 2e-3 * np.abs(r).max()
