@@ -1,17 +1,25 @@
 #!/usr/bin/env python
-"""bench.py -- rendered views/sec of the MI355X rasterizer on BASELINE.json's metric config.
+"""bench.py -- rendered views/sec of the MI355X rasterizer on BASELINE.json's metric config, plus (N=1) the
+other rows of the hot path under the same clock.
 
   python bench.py [--gpus N --steps K --warmup W]            (N=1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W    (N>1, one rank per GPU)
 
-A "step" renders `--views` target views (default 8) of the synthetic 1.0 M-Gaussian scene at
+A "step" renders `--views` target views (default 16) of the synthetic 1.0 M-Gaussian scene at
 968x1296 on every rank (weak scaling, view-sharded: rank r renders its own block of the N*views
 target cameras) and, for N>1, all-gathers the rendered colour+depth images over RCCL on a side
 stream, overlapped with the next step.  Inputs are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line with `roofline` (render kernel, HIP-event timed inside the timed
-region through the library's fs_profile_* hooks) and `cpu_baseline` (the CPU oracle, OpenMP, on
-ONE view of the same workload, rank 0, N=1 only).
+
+Rank 0 prints ONE JSON line.  Top level = the headline metric (forward rendering, config 3's size) with
+`roofline` (render kernel, HIP-event timed inside the timed region through the library's fs_profile_* hooks),
+`cpu_baseline` (the CPU oracle, OpenMP, on whole views of the same workload) and `parity`.  At N=1 the same line
+carries sub-objects measured in the same run, each with its own roofline / cpu_baseline / parity:
+  "train"        fwd+bwd training step at config 3 (roofline: render_bwd kernel)
+  "c2"           config 2 (640x480, 300 k Gaussians, forward)
+  "cost_volume"  plane-sweep cost volume: native 96x128 K=1 and config-3 scale 242x324 K=2 (roofline: fp32 MFMA)
+  "ptf"          Pixel-wise Triplet Fusion folds: 2 and 10 views at 384x512 (roofline: HBM)
+(`--sections raster` restricts the run to the top-level metric.)
 """
 from __future__ import annotations
 
@@ -38,56 +46,75 @@ def parse():
     ap.add_argument("--workload", default="c3_968x1296_1M",
                     help="c3_968x1296_1M (metric config) | c2_640x480_300k | c1_256x256_plumbing")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
-                    help="fwd: forward rendering (the metric); train: fwd + bwd (+ grad all-reduce)")
+                    help="top-level measurement. fwd: forward rendering (the metric); train: fwd + bwd (+ grad exchange)")
+    ap.add_argument("--sections", default="all",
+                    help="N=1 only: comma list of extra sub-objects (train,c2,cost_volume,ptf), 'all', or 'raster' for none")
+    ap.add_argument("--grad-exchange", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
+                    help="N>1 train mode: how the per-Gaussian gradients of the view shards are summed")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 through torch.distributed.run (see module docstring)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
-    # FS_DIST_BACKEND=gloo + FS_SHARE_GPU=1 exercise the N>1 control flow on a single-GPU box (tests only)
-    backend = os.environ.get("FS_DIST_BACKEND", "nccl")
-    if os.environ.get("FS_SHARE_GPU") == "1":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+class Ctx:
+    """Process-wide state of one bench run (device, ranks)."""
 
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit("launch N>1 through torch.distributed.run (see module docstring)")
+            args.gpus = self.world
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+        # FS_DIST_BACKEND=gloo + FS_SHARE_GPU=1 exercise the N>1 control flow on a single-GPU box (tests only)
+        backend = os.environ.get("FS_DIST_BACKEND", "nccl")
+        if os.environ.get("FS_SHARE_GPU") == "1":
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warmup: int, cpu_baseline: bool) -> dict | None:
+    """One rasterizer measurement (forward, or forward+backward): returns the JSON object on rank 0."""
+    args = cx.args
+    world, rank, dev = cx.world, cx.rank, cx.dev
     from freesplat_amd import _lib, synthetic
     from freesplat_amd.decoder import check_deferred, render_views
-    from freesplat_amd.view_sharding import AsyncViewGather, allreduce_gaussian_grads, shard_range
+    from freesplat_amd.view_sharding import AsyncViewGather, GradExchange, shard_range
 
-    H, W, N = synthetic.WORKLOADS[args.workload]
+    H, W, N = synthetic.WORKLOADS[workload]
     scene = synthetic.make_scene(N)
-    n_total_views = args.views * world
+    n_total_views = views * world
     cams_all = synthetic.target_cameras(n_total_views)
     mine = shard_range(n_total_views, rank, world)
     sl = slice(mine.start, mine.stop)
     cams = {k: v[sl].to(dev) for k, v in cams_all.items()}
     g = {k: scene[k].to(dev) for k in ("means", "covariances", "harmonics", "opacities")}
     bg = torch.zeros(len(mine), 3, device=dev)
-    train = args.mode == "train"
+    train = mode == "train"
     if train:
         for t in g.values():
             t.requires_grad_(True)
         target = torch.rand(len(mine), 3, H, W, device=dev)
     gather = AsyncViewGather(n_total_views, device=dev) if (world > 1 and not args.no_gather and not train) else None
+    exchange = GradExchange(args.grad_exchange) if (world > 1 and train) else None
 
     def step():
         if train:
@@ -97,8 +124,8 @@ def main():
                                         (H, W), bg, g["means"], g["covariances"], g["harmonics"], g["opacities"])
             loss = ((color - target) ** 2).mean()
             loss.backward()
-            if world > 1:
-                allreduce_gaussian_grads([t.grad for t in g.values()])
+            if exchange is not None:
+                exchange([t.grad for t in g.values()])
             return color, depth
         with torch.no_grad():
             # capacity check deferred to the end of the timed region (check_deferred below): the GPU
@@ -111,14 +138,8 @@ def main():
                 gather.launch(torch.cat([color, depth], dim=1))
         return color, depth
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for attempt in range(2):
-        for _ in range(max(args.warmup, 1) if attempt else args.warmup):
+        for _ in range(max(warmup, 1) if attempt else warmup):
             color, depth = step()
         if gather is not None:
             gather.wait()
@@ -130,7 +151,7 @@ def main():
             # updated by the check, warm up again with it (the timed region below still fails loudly on overflow)
             if attempt:
                 raise
-    barrier()
+    cx.barrier()
     profile = not args.no_profile
     dominant = "render_bwd" if train else "render"
     if profile:
@@ -140,12 +161,12 @@ def main():
         _lib.profile_collect()
         _lib.profile_enable(True, stages=[dominant])
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         color, depth = step()
     if gather is not None:
         gather.wait()
     check_deferred()  # raises if any view of the timed region overflowed its instance capacity
-    barrier()
+    cx.barrier()
     dt = time.perf_counter() - t0
     stages, breakdown = {}, {}
     if profile:
@@ -168,48 +189,49 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        from freesplat_amd.rasterizer import NUM_STREAMS as R_NUM_STREAMS, _state
-        n_inst = _state(dev).last_instances
-        views = n_total_views * args.steps
-        # algorithmic bytes per rendered view: N*(12+24+4+12*d_sh) + P*(12+4)
-        alg_fwd = N * 148 + H * W * 16
-        alg_bwd = 2 * N * 148 + H * W * 20
-        out = {
-            "metric": f"rendered views/sec @ {H}x{W}, {N / 1e6:.1f}M Gaussians" + (" (fwd+bwd)" if train else ""),
-            "value": views / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "mode": args.mode, "image_hw": [H, W], "gaussians": N,
-                       "sh_degree": 2, "views_per_step_per_gpu": args.views, "raster_streams": R_NUM_STREAMS,
-                       "instances_per_view": int(n_inst),
-                       "parallelism": f"view-sharded x{world}" + (" + all_reduce(gaussian grads)" if (train and world > 1) else
-                                                                  " + all_gather(color,depth)" if gather else "")},
-        }
-        if stages:
-            key = "render_bwd" if train else "render"
-            ms, cnt = stages.get(key, (0.0, 0))
-            per = ms / max(cnt, 1) * 1e-3
-            alg = alg_bwd if train else alg_fwd
-            ach = alg / per / 1e9 if per > 0 else 0.0
-            traffic, traffic_src = committed_traffic("fs::" + key + "_kernel") if args.workload.startswith("c3") else (None, None)
-            out["roofline"] = {"bound": "hbm", "kernel": key + "_kernel", "achieved": ach, "peak": 8000.0,
-                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
-                               "traffic_source": traffic_src,
-                               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": per * 1e3,
-                               "launches": cnt}
-            out["kernel_ms_per_view"] = {k: v[0] / max(v[1], 1) for k, v in breakdown.items() if v[1]}
-            out["kernel_ms_per_view_note"] = ("2 extra untimed single-stream steps with every stage event-timed (isolated "
-                                              "durations); roofline.avg_launch_ms is from the timed region, where the "
-                                              "launches of adjacent views overlap on config.raster_streams streams")
-            iso = breakdown.get(key, (0.0, 0))
-            out["roofline"]["isolated_launch_ms"] = iso[0] / max(iso[1], 1)
-        if world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline_and_parity(scene, cams_all, H, W, color[0], args.workload, train=train))
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    from freesplat_amd.rasterizer import NUM_STREAMS as R_NUM_STREAMS, _state
+    n_inst = _state(dev).last_instances
+    n_views_done = n_total_views * steps
+    # algorithmic bytes per rendered view: N*(12+24+4+12*d_sh) + P*(12+4)
+    alg_fwd = N * 148 + H * W * 16
+    alg_bwd = 2 * N * 148 + H * W * 20
+    out = {
+        "metric": f"rendered views/sec @ {H}x{W}, {N / 1e6:.1f}M Gaussians" + (" (fwd+bwd)" if train else ""),
+        "value": n_views_done / dt, "unit": "views/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "mode": mode, "image_hw": [H, W], "gaussians": N,
+                   "sh_degree": 2, "views_per_step_per_gpu": views, "raster_streams": R_NUM_STREAMS,
+                   "instances_per_view": int(n_inst),
+                   "parallelism": f"view-sharded x{world}" + (f" + {args.grad_exchange}(gaussian grads)" if exchange else
+                                                              " + all_gather(color,depth)" if gather else "")},
+    }
+    if stages:
+        ms, cnt = stages.get(dominant, (0.0, 0))
+        per = ms / max(cnt, 1) * 1e-3
+        alg = alg_bwd if train else alg_fwd
+        ach = alg / per / 1e9 if per > 0 else 0.0
+        traffic, traffic_src = committed_traffic("fs::" + dominant + "_kernel") if workload.startswith("c3") else (None, None)
+        out["roofline"] = {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": ach, "peak": 8000.0,
+                           "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                           "traffic_source": traffic_src,
+                           "algorithmic_bytes_per_launch": alg, "avg_launch_ms": per * 1e3,
+                           "launches": cnt}
+        out["kernel_ms_per_view"] = {k: v[0] / max(v[1], 1) for k, v in breakdown.items() if v[1]}
+        out["kernel_ms_per_view_note"] = ("2 extra untimed single-stream steps with every stage event-timed (isolated "
+                                          "durations); roofline.avg_launch_ms is from the timed region, where the "
+                                          "launches of adjacent views overlap on config.raster_streams streams")
+        iso = breakdown.get(dominant, (0.0, 0))
+        out["roofline"]["isolated_launch_ms"] = iso[0] / max(iso[1], 1)
+        ksum = sum(out["kernel_ms_per_view"].values())
+        if ksum > 0:   # the whole pipeline of one view against the same algorithmic bytes
+            out["roofline"]["pipeline_frac_isolated"] = (alg_fwd + (alg_bwd if train else 0)) / (ksum * 1e-3) / 8e12
+    if world == 1 and cpu_baseline:
+        out.update(cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=train))
+    return out
 
 
 def committed_traffic(kernel: str):
@@ -230,44 +252,97 @@ def committed_traffic(kernel: str):
     return None, None
 
 
-def cpu_baseline_and_parity(scene, cams_all, H, W, gpu_color0, workload, train=False):
+def cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=False):
     """Times the CPU oracle (kind "port": OpenMP restatement of the reference algorithm, all host
     cores) on a bounded sample -- whole views of the same workload (forward, or forward + backward in train mode)
-    until >= 10 s of CPU work or 3 views -- and checks the GPU image of view 0 against it (max-abs, PSNR)."""
+    until >= 10 s of CPU work or 3 views -- and checks the GPU result of view 0 against it: image max-abs / PSNR /
+    bit-exactness, in train mode every gradient, and (forward) the sensitivity of the image to the private exp()
+    contract the oracle and the kernels share (oracle re-run with libm expf)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from util_raster import oracle_forward, view_inputs
+    from oracle import raster_oracle as ro
+    from util_raster import hip_forward, oracle_forward, view_inputs
     cores = os.cpu_count() or 1
     os.environ["OMP_NUM_THREADS"] = str(cores)
+    rng = np.random.default_rng(0)
+    g_color = rng.normal(size=(3, H, W)).astype(np.float32)
     vi = view_inputs(scene, cams_all, 0, H, W)
     oracle_forward(vi) if H * W <= 640 * 480 else None  # warm small workloads only
-    n, t_tot, st0 = 0, 0.0, None
+    n, t_tot, st0, ref0 = 0, 0.0, None, None
     while n < 3 and t_tot < 10.0:
         vi_n = view_inputs(scene, cams_all, n % cams_all["extrinsics"].shape[0], H, W)
         t = time.perf_counter()
         st = oracle_forward(vi_n)
-        if train:
-            from oracle import raster_oracle as ro
-            ro.backward(st, np.ones((3, H, W), np.float32))
+        ref = ro.backward(st, g_color) if train else None
         t_tot += time.perf_counter() - t
         if n == 0:
-            st0 = st
+            st0, ref0 = st, ref
         n += 1
     # parity of the kernels: the SAME (CPU-framed) inputs through the product rasterizer
-    import torch
-    from util_raster import hip_forward
-    (gc, _, _, _), _ = hip_forward(view_inputs(scene, cams_all, 0, H, W), torch.device("cuda", torch.cuda.current_device()))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    (gc, _, _, _), leaves = hip_forward(vi, dev, requires_grad=train)
     g = gc.detach().cpu().numpy()
     err = float(np.abs(g - st0["color"]).max())
     mse = float(((g.clip(0, 1) - st0["color"].clip(0, 1)) ** 2).mean())
     psnr = None if mse == 0 else float(-10 * np.log10(mse))
+    parity = {"max_abs_err_vs_oracle": err, "psnr_db_vs_oracle": psnr if psnr is not None else "inf",
+              "bit_exact": bool((g == st0["color"]).all())}
+    if train:
+        (gc * torch.from_numpy(g_color).to(dev)).sum().backward()
+        rel = {}
+        for k in ("means3D", "cov3D", "shs", "opacities"):
+            a = leaves[k].grad.cpu().numpy().reshape(ref0[k].shape)
+            rel[k] = float(np.abs(a - ref0[k]).max() / (np.abs(ref0[k]).max() + 1e-20))
+        parity["grad_err_over_max_abs"] = rel
+        parity["grad_tolerance"] = 2e-4
+    else:
+        try:
+            ro.set_exp_mode(True)
+            st_libm = oracle_forward(vi)
+        finally:
+            ro.set_exp_mode(False)
+        d = np.abs(g - st_libm["color"]).max(axis=0)
+        mse2 = float(((g.clip(0, 1) - st_libm["color"].clip(0, 1)) ** 2).mean())
+        parity["exp_contract"] = {"what": "HIP image (contract exp) vs the oracle with libm expf in the blend loop",
+                                  "max_abs": float(d.max()), "pixels_above_1e-4": int((d > 1e-4).sum()), "pixels": H * W,
+                                  "psnr_db": "inf" if mse2 == 0 else float(-10 * np.log10(mse2))}
     return {
         "cpu_baseline": {"value": n / t_tot, "unit": "views/s", "cores": cores, "kind": "port",
                          "sample": f"{n} {'forward+backward' if train else 'forward'} view(s) of {workload} through "
                                    "oracle/raster_oracle.c (OpenMP)"},
-        "parity": {"max_abs_err_vs_oracle": err, "psnr_db_vs_oracle": psnr if psnr is not None else "inf",
-                   "bit_exact": bool((g == st0["color"]).all())},
+        "parity": parity,
     }
+
+
+def main():
+    args = parse()
+    cx = Ctx(args)
+    cpu = not args.no_cpu_baseline
+    out = bench_raster(cx, args.workload, args.mode, args.views, args.steps, args.warmup, cpu)
+    sections = []
+    if cx.world == 1 and args.sections != "raster":
+        sections = ["train", "c2", "cost_volume", "ptf"] if args.sections == "all" else args.sections.split(",")
+    if "train" in sections and args.mode != "train":
+        out["train"] = bench_raster(cx, args.workload, "train", min(args.views, 8), max(3, args.steps // 2), 2, cpu)
+    if "c2" in sections and not args.workload.startswith("c2"):
+        out["c2"] = bench_raster(cx, "c2_640x480_300k", "fwd", args.views, args.steps, args.warmup, cpu)
+    if "cost_volume" in sections or "ptf" in sections:
+        import bench_encoder as be
+        if "cost_volume" in sections:
+            out["cost_volume"] = {
+                "native_96x128_K1": be.bench_cost_volume(cx.dev, args.steps, args.warmup, cpu=cpu),
+                "c3scale_242x324_K2": be.bench_cost_volume(cx.dev, max(3, args.steps // 4), 1, V=3, K=2, h4=242, w4=324,
+                                                           cpu=cpu, cpu_views=1),
+            }
+        if "ptf" in sections:
+            out["ptf"] = {
+                "fold_2_views": be.bench_ptf(cx.dev, args.steps, args.warmup, cpu=cpu),
+                "fold_10_views": be.bench_ptf(cx.dev, max(2, args.steps // 4), 1, V=10, cpu=False),
+            }
+    if cx.rank == 0:
+        print(json.dumps(out), flush=True)
+    if cx.world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -29,7 +29,8 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48):
+def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, cpu=True, cpu_views=None):
+    """`cpu_views`: how many of the V current views the CPU baseline sweeps (bounded sample; default all)."""
     import inputs
     from freesplat_amd import _lib
     from freesplat_amd.cost_volume import AVGFeatureVolumeManager
@@ -50,29 +51,35 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48):
         dt = timed(lambda: mg(**args), steps, warmup)
         _lib.profile_enable(False)
         ms, cnt = _lib.profile_collect()["cost_volume"]
-    torch.set_num_threads(os.cpu_count() or 1)
-    t0 = time.perf_counter()
-    ref = cvo.cost_volume(kw["cur_feats"], kw["src_feats"], kw["src_extrinsics"], kw["src_Ks"], kw["cur_invK"],
-                          kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
-    t_cpu = time.perf_counter() - t0
-    torch.set_num_threads(8)
-    e = (out - ref).abs()
-    err = float(e.max())
-    n_out = int((e > 1e-4).sum())
     flops = V * h4 * w4 * D * (480 * K + 5248)
     kern = ms / max(cnt, 1) * 1e-3
-    return {"metric": f"cost-volume views/sec @ {h4}x{w4} match res, D={D}, K={K}", "value": V / dt, "unit": "views/s",
+    extra = {}
+    if cpu:
+        nv = V if cpu_views is None else min(V, cpu_views)
+        torch.set_num_threads(os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        ref = cvo.cost_volume(kw["cur_feats"][:nv], kw["src_feats"][:nv], kw["src_extrinsics"][:nv], kw["src_Ks"][:nv],
+                              kw["cur_invK"][:nv], kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
+        t_cpu = time.perf_counter() - t0
+        torch.set_num_threads(8)
+        e = (out[:nv] - ref).abs()
+        extra = {"cpu_baseline": {"value": nv / t_cpu, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                                  "sample": f"{nv} of {V} current view(s) through oracle/cost_volume_oracle.py (torch CPU, "
+                                            "vectorised over D; pinned by the reference's golden volumes)"},
+                 "parity": {"max_abs_err_vs_oracle": float(e.max()), "median_abs_err": float(e.median()),
+                            "cells_above_1e-4": int((e > 1e-4).sum()), "cells": e.numel(),
+                            "note": "cells above 1e-4 are validity flips of bilinear taps on the image border "
+                                    "(tests/test_cost_volume_hip.py bounds them)"}}
+    return dict({"metric": f"cost-volume views/sec @ {h4}x{w4} match res, D={D}, K={K}", "value": V / dt, "unit": "views/s",
             "ms_per_call": dt * 1e3, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cv_native", "views": V, "sources": K, "channels": C},
             "roofline": {"bound": "mfma", "kernel": "cost_volume (relayout + sweep)", "achieved": flops / kern / 1e12,
                          "peak": 157.3, "unit": "TFLOP/s", "frac": flops / kern / 1e12 / 157.3,
-                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern * 1e3, "traffic": None},
-            "cpu_baseline": {"value": V / t_cpu, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-                             "sample": "1 call of oracle/cost_volume_oracle.py (torch CPU, vectorised over D)"},
-            "parity": {"max_abs_err_vs_oracle": err, "cells_above_1e-4": n_out, "cells": e.numel()}}
+                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern * 1e3, "launches": cnt,
+                         "traffic": None}}, **extra)
 
 
-def bench_ptf(dev, steps, warmup, V=2, h=384, w=512):
+def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_ptf_hip import _scene
     from freesplat_amd import _lib
@@ -91,21 +98,39 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512):
         dt = timed(lambda: m.fuse_gaussians(*a), steps, warmup)
         _lib.profile_enable(False)
         ms, cnt = _lib.profile_collect()["ptf"]
-    torch.set_num_threads(os.cpu_count() or 1)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w))
-        t_cpu = time.perf_counter() - t0
-    torch.set_num_threads(8)
-    err = max(float((x - y).abs().max()) for x, y in zip(out, ref))
+    from freesplat_amd import ptf as _ptf
+    steps_counts = _ptf.LAST_FOLD_COUNTS.tolist()      # [V,4]: kept, fused, appended, state rows after the step
+    # algorithmic bytes of the fold (SURVEY.md 8(d), 344-byte state record): per step read M*12 (xyz) + P*4 (depth),
+    # gather kept + both sides of every fused pair + appended pixels, write the new state
+    P, REC = h * w, 344
+    alg, M = 0, P
+    for i in range(1, V):
+        k, f, a, m_out = steps_counts[i]
+        alg += M * 12 + P * 4 + (k + 2 * f + a) * REC + (k + f + a) * REC
+        M = m_out
+    kern_ms = ms / (steps + warmup)   # every launch of the library's ptf stage (event-bracketed), per fold call
+    extra = {}
+    if cpu:
+        torch.set_num_threads(os.cpu_count() or 1)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w))
+            t_cpu = time.perf_counter() - t0
+        torch.set_num_threads(8)
+        err = max(float((x - y).abs().max()) for x, y in zip(out, ref))
+        extra = {"cpu_baseline": {"value": 1.0 / t_cpu, "unit": "folds/s", "cores": os.cpu_count(), "kind": "port",
+                                  "sample": f"1 fold of {V} views through oracle/ptf_oracle.py (numpy match + torch CPU GRU; "
+                                            "pinned by the reference's golden folds)"},
+                 "parity": {"max_abs_err_vs_oracle": err, "same_count_and_order": bool(out[0].shape == ref[0].shape)}}
     M_in, M_out = V * h * w, out[0].shape[1]
-    return {"metric": f"PTF folds/sec, {V} views @ {h}x{w}", "value": 1.0 / dt, "unit": "folds/s", "ms_per_call": dt * 1e3,
-            "dtype": "f32 / int64 indices", "data": "synthetic",
-            "config": {"workload": "ptf_native", "views": V, "gaussians_in": M_in, "gaussians_out": M_out},
-            "match_step_ms": ms / max(cnt, 1),
-            "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "folds/s", "cores": os.cpu_count(), "kind": "port",
-                             "sample": "1 fold through oracle/ptf_oracle.py (numpy match + torch CPU GRU)"},
-            "parity": {"max_abs_err_vs_oracle": err, "same_count": bool(out[0].shape == ref[0].shape)}}
+    return dict({"metric": f"PTF folds/sec, {V} views @ {h}x{w}", "value": 1.0 / dt, "unit": "folds/s", "ms_per_call": dt * 1e3,
+                 "dtype": "f32 / int64 indices", "data": "synthetic",
+                 "config": {"workload": "ptf_native", "views": V, "gaussians_in": M_in, "gaussians_out": M_out,
+                            "fused_pairs_per_step": [c[1] for c in steps_counts[1:]]},
+                 "roofline": {"bound": "hbm", "kernel": "ptf fold (match + gru_inputs + gru + write_state, all steps)",
+                              "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": alg / (kern_ms * 1e-3) / 8e12, "algorithmic_bytes_per_fold": alg,
+                              "kernel_ms_per_fold": kern_ms, "launches": cnt // max(steps + warmup, 1), "traffic": None}}, **extra)
 
 
 def bench_depth_tail(dev, steps, warmup, V=2, D=128, h2=192, w2=256):

@@ -43,10 +43,10 @@ def patch_reference(decoder: bool = True) -> dict:
     net.DepthDecoder.forward = depth_tail.depth_decoder_forward
     done["src.model.encoder.modules.networks.DepthDecoder.forward"] = depth_tail.depth_decoder_forward
     if decoder:
-        try:
-            dec = importlib.import_module("src.model.decoder")
-            dec.DECODERS["splatting_cuda"] = lambda cfg, dataset_cfg: DecoderSplattingCUDA(dataset_cfg.background_color)
-            done['src.model.decoder.DECODERS["splatting_cuda"]'] = DecoderSplattingCUDA
-        except Exception as e:  # the decoder package drags in the dataset package; report, don't hide
-            done["src.model.decoder (not patched)"] = repr(e)
+        # same constructor (cfg, dataset_cfg) as the class it replaces, so get_decoder() is untouched.  A failure to
+        # import the reference's decoder package is an error of the caller's environment and propagates.
+        dec = importlib.import_module("src.model.decoder")
+        dec.DECODERS["splatting_cuda"] = DecoderSplattingCUDA
+        dec.DecoderSplattingCUDA = DecoderSplattingCUDA
+        done['src.model.decoder.DECODERS["splatting_cuda"]'] = DecoderSplattingCUDA
     return done

@@ -160,3 +160,36 @@ class AVGFeatureVolumeManager(nn.Module):
                                    _dev32(src_extrinsics, "src_extrinsics"), _dev32(src_Ks, "src_Ks"),
                                    _dev32(cur_invK, "cur_invK"), flat, strides, net[0].weight, net[0].bias,
                                    net[2].weight, net[2].bias, net[4].weight, net[4].bias)
+
+
+def sharded_cost_volume(manager, local_feats: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                        image_hw: tuple[int, int], num_context_views: int, group=None) -> Tensor:
+    """Plane-sweep cost volumes of the context views of ONE scene with the views sharded over a process group
+    (the `B = b*V` rows of encoder_freesplat.py:260-288 are independent, b = 1 in every shipped
+    config).  Rank r holds `local_feats` [V_r, C, h/4, w/4] -- the matching features of ITS views
+    (view_sharding.shard_range(V, r, world)) -- and the full cameras extrinsics [1,V,4,4] / intrinsics [1,V,3,3] /
+    near, far [1,V].  One all-gather of the feature maps (2.36 MB per view at the native 96x128; its backward is a
+    reduce-scatter), then every rank sweeps only its own current views: returns [V_r, D, h/4, w/4], which stays local
+    for the per-view CNN that consumes it.  `manager` = AVGFeatureVolumeManager (any callable with its forward's
+    keyword arguments).  Without an initialised process group (or world size 1) this is the unsharded call."""
+    import torch.distributed as dist
+    from .encoder_glue import prepare_cost_volume_inputs
+    from .view_sharding import gather_features_autograd, shard_range
+    if extrinsics.shape[0] != 1:
+        raise NotImplementedError("sharded_cost_volume: one scene per call (b = 1, config/main.yaml:26)")
+    V = extrinsics.shape[1]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        feats, mine = local_feats, range(V)
+    else:
+        mine = shard_range(V, dist.get_rank(group), world)
+        if local_feats.shape[0] != len(mine):
+            raise ValueError(f"rank holds {local_feats.shape[0]} feature maps, expected {len(mine)}")
+        feats = gather_features_autograd(local_feats, V, group)
+    kw = prepare_cost_volume_inputs(extrinsics, intrinsics, feats, near, far, image_hw, num_context_views)
+    rows = slice(mine.start, mine.stop)
+    local_kw = {k: (v if k in ("min_depth", "max_depth") else v[rows]) for k, v in kw.items()}
+    if len(mine) == 0:
+        D = getattr(manager, "num_depth_bins", 0)
+        return feats.new_zeros((0, D) + tuple(feats.shape[-2:])) + 0.0 * feats.sum()
+    return manager(**local_kw)

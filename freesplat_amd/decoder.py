@@ -353,16 +353,52 @@ class Gaussians:
     opacities: Tensor    # [b, g]
 
 
-class DecoderSplattingCUDA(nn.Module):
-    """Mirror of decoder_splatting_cuda.py:20-75 (registry key "splatting_cuda").  `batched=True`
-    (default) renders through `render_views`; `batched=False` reproduces the reference's
-    repeat-per-view call pattern through `render_cuda`."""
+@dataclass
+class DecoderSplattingCUDACfg:
+    """decoder_splatting_cuda.py:15-17"""
+    name: str = "splatting_cuda"
 
-    def __init__(self, background_color=(0.0, 0.0, 0.0), batched: bool = True):
+
+class DecoderSplattingCUDA(nn.Module):
+    """Mirror of decoder_splatting_cuda.py:20-75 (registry key "splatting_cuda"): same constructor
+    `(cfg, dataset_cfg)` -- only `dataset_cfg.background_color` is read, as in the reference (:28-32) -- same
+    `forward` signature and `DecoderOutput`.
+
+    Beyond the reference (keyword-only, defaults keep the reference's behaviour on one GPU):
+      batched=True   render through `render_views` (no v-fold repeat of the Gaussians, one sync per call);
+                     False reproduces the reference's repeat-per-view call pattern through `render_cuda`.
+      group          a torch.distributed process group (or True for the default group): the v target views of
+                     every scene are SHARDED over its ranks (view_sharding.shard_range), each rank renders its
+                     block, the images are all-gathered (RCCL over xGMI) so that every rank returns the full
+                     [b, v, ...] output, and in backward the per-Gaussian gradients of the shards are summed over
+                     the ranks in one flat bucket -- the multi-GPU run of src/main.py:98-103 without replicating
+                     the render work.  Gaussians and cameras must be identical on all ranks of the group."""
+
+    def __init__(self, cfg=None, dataset_cfg=None, *, background_color=None, batched: bool = True, group=None):
         super().__init__()
-        self.register_buffer("background_color", torch.tensor(background_color, dtype=torch.float32),
+        if background_color is None:
+            background_color = getattr(dataset_cfg, "background_color", None) if dataset_cfg is not None else None
+        if background_color is None:
+            if cfg is not None and not hasattr(cfg, "name") and dataset_cfg is None:
+                background_color = cfg      # DecoderSplattingCUDA((r, g, b)): round-1 form, kept for callers of it
+                cfg = None
+            else:
+                background_color = (0.0, 0.0, 0.0)
+        self.cfg = cfg if cfg is not None else DecoderSplattingCUDACfg()
+        self.dataset_cfg = dataset_cfg
+        self.register_buffer("background_color", torch.tensor(list(background_color), dtype=torch.float32),
                              persistent=False)
         self.batched = batched
+        self.group = group
+
+    def _dist_group(self):
+        if self.group is None or self.group is False:
+            return None
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("DecoderSplattingCUDA(group=...) needs an initialised torch.distributed process group")
+        g = None if self.group is True else self.group      # None = the default group
+        return (g, dist) if dist.get_world_size(g) > 1 else None
 
     def forward(self, gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                 image_shape: tuple[int, int], depth_mode=None, no_color: bool = False) -> DecoderOutput:
@@ -373,7 +409,11 @@ class DecoderSplattingCUDA(nn.Module):
                 raise RuntimeError("no_color=True with depth_mode set has no defined result in the reference")
             return DecoderOutput(None, None)
         bg = self.background_color
-        if self.batched:
+        sharded = self._dist_group()
+        if sharded is not None:
+            color, depth = self._forward_sharded(sharded[0], sharded[1], gaussians, extrinsics, intrinsics, near, far,
+                                                 image_shape)
+        elif self.batched:
             colors, depths = [], []
             for i in range(b):
                 c, d = render_views(extrinsics[i], intrinsics[i], near[i], far[i], image_shape,
@@ -392,3 +432,27 @@ class DecoderSplattingCUDA(nn.Module):
             depth = depth.reshape(b, v, *depth.shape[1:]).squeeze(2)
         depth = depth / 2  # decoder_splatting_cuda.py:62
         return DecoderOutput(color, None if depth_mode is None else depth)
+
+    def _forward_sharded(self, group, dist, gaussians, extrinsics, intrinsics, near, far, image_shape):
+        """View-sharded rendering of every scene of the batch: no collective on the render
+        path itself; one all-gather of colour+depth per scene, one flat-bucket gradient sum in backward."""
+        from .view_sharding import gather_views_autograd, replicate_gaussians, shard_range
+        b, v = extrinsics.shape[:2]
+        h, w = image_shape
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        mine = shard_range(v, rank, world)
+        sl = slice(mine.start, mine.stop)
+        bg = self.background_color
+        colors, depths = [], []
+        for i in range(b):
+            means, cov, sh, op = replicate_gaussians([gaussians.means[i], gaussians.covariances[i],
+                                                      gaussians.harmonics[i], gaussians.opacities[i]], group)
+            if len(mine):
+                c, d = render_views(extrinsics[i, sl], intrinsics[i, sl], near[i, sl], far[i, sl], image_shape,
+                                    bg[None].expand(len(mine), 3), means, cov, sh, op)
+                local = torch.cat([c, d], dim=1)                       # [v_local, 4, h, w]
+            else:   # more ranks than views: this rank contributes nothing (but must keep the graph connected)
+                local = torch.zeros(0, 4, h, w, device=extrinsics.device) + 0.0 * (means.sum() + cov.sum() + sh.sum() + op.sum())
+            full = gather_views_autograd(local, v, group)              # [v, 4, h, w] on every rank
+            colors.append(full[:, :3]); depths.append(full[:, 3])
+        return torch.stack(colors), torch.stack(depths)

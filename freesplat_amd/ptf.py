@@ -83,6 +83,7 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
 
 
 _table_cache: dict = {}
+LAST_FOLD_COUNTS = None   # device tensor [V,4] (kept, fused, appended, state rows) of the last fused fold: bench accounting
 
 
 def gru_tables(gru: "GRU") -> Tensor:
@@ -162,6 +163,8 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
     scratch = torch.empty(L.fs_ptf_fold_bytes(V, h, w), dtype=torch.uint8, device=dev)
     _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), p(w2c), p(Kn), C.c_float(depth_thres),
                              p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts), _lib.current_stream()), "fs_ptf_fold")
+    global LAST_FOLD_COUNTS
+    LAST_FOLD_COUNTS = counts
     n = int(counts[V - 1, 3].item())               # the only host sync of the fold
     G, X, _, _, E, D = bufs[0] if ((V - 1) & 1 or V == 2) else bufs[1]
     return G[None, :n], X[None, :n], E[:n].view(1, n, 4, 4), D[None, :n, 0]

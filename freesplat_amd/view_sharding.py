@@ -6,6 +6,17 @@ Gaussian set are split across ranks; the only exchanges are an all-gather of the
 The reference has no explicit distributed code (Lightning DDP over scenes only, src/main.py:98-103);
 this is the view-sharded decoder the north_star asks for.
 
+Exchanges:
+  rasterizer forward   all-gather of the rendered colour+depth images       gather_views / AsyncViewGather / gather_views_autograd
+  rasterizer backward  sum of the per-Gaussian gradients of the view shards
+                         - reduce-scatter by Gaussian rows (each rank receives the total for the rows it owns; 1/G of
+                           the bucket crosses each link, the direct pattern on the 7 point-to-point xGMI links)
+                                                                            reduce_scatter_gaussian_grads
+                         - all-reduce when every rank needs every row (replicated encoder)
+                                                                            allreduce_gaussian_grads / replicate_gaussians
+  cost volume          all-gather of the 48-channel 1/4-resolution feature maps, then view i -> rank i mod G
+                                                                            freesplat_amd.cost_volume.sharded_cost_volume
+
 xGMI is point-to-point (7 links/GPU): one all-gather of a whole step's images per rank (tens of MB)
 keeps every link busy with a few large messages rather than many per-view ones, and it runs on a
 side stream so that the next step's rasterization overlaps it.
@@ -17,6 +28,29 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 from torch import Tensor
+
+
+def _is_gloo(group=None) -> bool:
+    return dist.get_backend(group) == "gloo"
+
+
+def _stage(t: Tensor, group=None) -> Tensor:
+    """gloo (the CPU test backend; also what lets the N>1 control flow run with several ranks sharing ONE GPU, which
+    RCCL refuses) moves host memory: device tensors are staged through the host for it.  RCCL takes them as they are."""
+    return t.cpu() if (t.is_cuda and _is_gloo(group)) else t
+
+
+def _reduce_scatter_sum(flat: Tensor, chunk: int, group=None) -> Tensor:
+    """[world*chunk] -> this rank's [chunk] of the element-wise sum over ranks.  RCCL: one reduce_scatter.  gloo has
+    no reduce-scatter: all-reduce and slice (same result; test backend only)."""
+    if _is_gloo(group):
+        buf = _stage(flat, group).clone()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        r = dist.get_rank(group)
+        return buf[r * chunk: (r + 1) * chunk].to(flat.device)
+    mine = torch.empty(chunk, dtype=flat.dtype, device=flat.device)
+    dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM, group=group)
+    return mine
 
 
 def shard_range(n_items: int, rank: int, world: int) -> range:
@@ -42,8 +76,11 @@ def gather_views(local: Tensor, n_total: int, group=None) -> Tensor:
     if local.shape[0] < mx:
         pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad])
+    dev = local.device
+    local = _stage(local.contiguous(), group)
     out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    dist.all_gather_into_tensor(out, local, group=group)
+    out = out.to(dev)
     if all(c == mx for c in counts):
         return out
     return torch.cat([out[r * mx: r * mx + c] for r, c in enumerate(counts)])
@@ -84,10 +121,131 @@ def allreduce_gaussian_grads(grads: list[Optional[Tensor]], group=None) -> None:
     ts = [g for g in grads if g is not None]
     if not ts:
         return
-    flat = torch.cat([t.reshape(-1) for t in ts])
+    flat = _stage(torch.cat([t.reshape(-1) for t in ts]), group)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat = flat.to(ts[0].device)
     off = 0
     for t in ts:
         n = t.numel()
         t.copy_(flat[off: off + n].view_as(t))
         off += n
+
+
+def reduce_scatter_gaussian_grads(grads: list[Optional[Tensor]], group=None) -> list[Optional[Tensor]]:
+    """Sum the view-sharded gradients of the shared Gaussian set across ranks and leave every rank with the total
+    for the Gaussian rows it OWNS (shard_range over dim 0 of each tensor): one reduce-scatter of one flat bucket
+    laid out rank-major ([rows of rank 0 of every tensor | rows of rank 1 ...], padded to equal chunks).
+    Returns the row shards [rows_r, ...] in the order of `grads` (None stays None).  Concatenating the shards of
+    all ranks reproduces allreduce_gaussian_grads."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ts = [g for g in grads if g is not None]
+    if not ts:
+        return list(grads)
+    rows = [[shard_range(t.shape[0], r, world) for t in ts] for r in range(world)]
+    per = [[len(rr) * (t[0].numel() if t.shape[0] else 0) for rr, t in zip(rows[r], ts)] for r in range(world)]
+    chunk = max(sum(p) for p in per)
+    flat = torch.zeros(world * chunk, dtype=ts[0].dtype, device=ts[0].device)
+    for r in range(world):
+        off = r * chunk
+        for rr, t, n in zip(rows[r], ts, per[r]):
+            if n:
+                flat[off: off + n] = t[rr.start: rr.stop].reshape(-1)
+            off += n
+    mine = _reduce_scatter_sum(flat, chunk, group)
+    out, off, it = [], 0, iter(zip(rows[rank], ts, per[rank]))
+    for g in grads:
+        if g is None:
+            out.append(None)
+            continue
+        rr, t, n = next(it)
+        out.append(mine[off: off + n].view((len(rr),) + tuple(t.shape[1:])))
+        off += n
+    return out
+
+
+class GradExchange:
+    """The gradient exchange of a view-sharded training step, by name: "all_reduce" sums in place (every rank ends
+    with every row), "reduce_scatter" returns the row shards this rank owns."""
+
+    def __init__(self, kind: str = "reduce_scatter", group=None):
+        if kind not in ("reduce_scatter", "all_reduce"):
+            raise ValueError(kind)
+        self.kind, self.group = kind, group
+
+    def __call__(self, grads: list[Optional[Tensor]]):
+        if self.kind == "all_reduce":
+            allreduce_gaussian_grads(grads, self.group)
+            return grads
+        return reduce_scatter_gaussian_grads(grads, self.group)
+
+
+class _GatherViewsFn(torch.autograd.Function):
+    """All-gather of per-view tensors that autograd can cross: every rank goes on to compute the SAME loss on the
+    gathered views, so the gradient of the local shard is simply its slice of the incoming gradient (no collective
+    in backward; the sum over ranks happens once, on the Gaussian gradients -- replicate_gaussians)."""
+
+    @staticmethod
+    def forward(ctx, local, n_total, group):
+        ctx.group, ctx.n_total = group, n_total
+        return gather_views(local, n_total, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        r = shard_range(ctx.n_total, dist.get_rank(ctx.group), dist.get_world_size(ctx.group))
+        return g[r.start: r.stop].contiguous(), None, None
+
+
+def gather_views_autograd(local: Tensor, n_total: int, group=None) -> Tensor:
+    return _GatherViewsFn.apply(local, n_total, group)
+
+
+class _ReplicateFn(torch.autograd.Function):
+    """Identity on the (replicated) Gaussian tensors whose backward sums their gradients over the ranks in ONE flat
+    bucket: with the views of a scene sharded over the ranks each rank holds the partial gradient of its own views;
+    afterwards every rank holds the total, so a replicated encoder continues backward identically everywhere."""
+
+    @staticmethod
+    def forward(ctx, group, *tensors):
+        ctx.group = group
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [None if g is None else g.contiguous() for g in grads]
+        allreduce_gaussian_grads(gs, ctx.group)
+        return (None,) + tuple(gs)
+
+
+def replicate_gaussians(tensors: list[Tensor], group=None) -> list[Tensor]:
+    return list(_ReplicateFn.apply(group, *tensors))
+
+
+class _GatherFeatsFn(torch.autograd.Function):
+    """All-gather of per-view feature maps whose consumers differ per rank (cost-volume sharding: rank r uses the
+    gathered maps as SOURCES of its own current views): the gradient of a local map is the SUM over the ranks of
+    their gradients for it -- backward is a reduce-scatter."""
+
+    @staticmethod
+    def forward(ctx, local, n_total, group):
+        ctx.group, ctx.n_total, ctx.tail = group, n_total, tuple(local.shape[1:])
+        return gather_views(local, n_total, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        world, rank = dist.get_world_size(ctx.group), dist.get_rank(ctx.group)
+        counts = shard_counts(ctx.n_total, world)
+        mx = max(counts)
+        per = 1
+        for d in ctx.tail:
+            per *= d
+        flat = torch.zeros(world * mx * per, dtype=g.dtype, device=g.device)
+        lo = 0
+        for r, c in enumerate(counts):
+            flat[r * mx * per: (r * mx + c) * per] = g[lo: lo + c].reshape(-1)
+            lo += c
+        mine = _reduce_scatter_sum(flat, mx * per, ctx.group)
+        return mine[: counts[rank] * per].view((counts[rank],) + ctx.tail), None, None
+
+
+def gather_features_autograd(local: Tensor, n_total: int, group=None) -> Tensor:
+    return _GatherFeatsFn.apply(local, n_total, group)

@@ -1,0 +1,55 @@
+"""N>1 on a one-GPU box (-m gpu): two ranks launched exactly as the driver launches bench.py
+(`python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 ...`) share cuda:0 and talk over gloo
+(FS_DIST_BACKEND=gloo FS_SHARE_GPU=1; RCCL refuses two ranks on one device).  What runs is the real sharded code:
+bench.py's N>1 branch and the process-group paths of the decoder and the cost volume, on the HIP kernels."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(script_args, timeout=600):
+    env = dict(os.environ, FS_DIST_BACKEND="gloo", FS_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    return p.stdout
+
+
+def test_sharded_decoder_and_cost_volume_two_ranks(hip_device):
+    out = _torchrun([os.path.join(ROOT, "tests", "dist_worker.py")])
+    line = [l for l in out.splitlines() if l.startswith("DIST_WORKER_RESULT ")][-1]
+    for res in json.loads(line[len("DIST_WORKER_RESULT "):]):
+        assert res["decoder_color_equal"] and res["decoder_depth_equal"], res      # gathered images == single-process render
+        assert max(res["decoder_grad_err"].values()) < 2e-4, res                  # float-atomic backward: the usual bar
+        assert res["cv_rows_equal"], res
+        assert res["cv_feat_grad_err"] < 1e-4, res
+
+
+@pytest.mark.parametrize("mode", ["fwd", "train"])
+def test_bench_two_ranks_runs_the_sharded_branch(hip_device, mode):
+    """bench.py --gpus 2 end to end (small workload): NCCL-free init, view sharding, AsyncViewGather on a side stream
+    (fwd) / reduce-scatter gradient exchange (train), max-over-ranks timing, one JSON line from rank 0."""
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--views", "3",
+                     "--workload", "c1_256x256_plumbing", "--mode", mode])
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    want = "reduce_scatter(gaussian grads)" if mode == "train" else "all_gather(color,depth)"
+    assert d["config"]["parallelism"] == f"view-sharded x2 + {want}", d["config"]
+    assert d["roofline"]["launches"] == 2 * 3     # rank 0's own views of the timed region
