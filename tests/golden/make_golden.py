@@ -229,8 +229,58 @@ def gen_depth_tail():
              module_depth_weights=out["depth_weights"])
 
 
+def gen_ply():
+    """The reference's export_ply (src/model/ply_export.py:26-92) run for real on a seeded scene.  `plyfile` is not
+    installed here, so a recording stand-in for its two entry points captures what the reference hands to
+    PlyElement.describe (the structured vertex array = its attribute table and names) and the output path; the
+    fixture keeps the inputs and that table.  (The byte layout plyfile would write -- binary_little_endian, one
+    `property float <name>` per field in dtype order -- is the public PLY format, restated in freesplat_amd.ply_export.)"""
+    rec = {}
+    m = types.ModuleType("plyfile")
+
+    class PlyElement:
+        @staticmethod
+        def describe(elements, name):
+            rec["elements"], rec["name"] = elements.copy(), name
+            return ("element", name)
+
+    class PlyData:
+        def __init__(self, elements):
+            rec["n_elements"] = len(elements)
+
+        def write(self, path):
+            rec["path"] = str(path)
+    m.PlyElement, m.PlyData = PlyElement, PlyData
+    sys.modules["plyfile"] = m
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_ply_export", os.path.join(REF, "src", "model", "ply_export.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from pathlib import Path
+    g = torch.Generator().manual_seed(11)
+    G = 400
+    a, b = 0.4, -0.2
+    Ry = torch.tensor([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=torch.float32)
+    Rx = torch.tensor([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]], dtype=torch.float32)
+    E = torch.eye(4); E[:3, :3] = Ry @ Rx; E[:3, 3] = torch.tensor([0.3, -0.1, 1.2])
+    means = torch.randn(G, 3, generator=g) * torch.tensor([2.0, 1.0, 3.0]) + torch.tensor([0.5, -1.0, 4.0])
+    scales = torch.rand(G, 3, generator=g) * 0.05 + 0.001
+    q = torch.randn(G, 4, generator=g); q = q / q.norm(dim=-1, keepdim=True)
+    sh = torch.randn(G, 3, 9, generator=g)
+    op = torch.rand(G, generator=g)
+    out_dir = tempfile.mkdtemp(prefix="fs_ply_")
+    mod.export_ply(E, means, scales, q, sh, op, Path(out_dir) / "sub" / "scene.ply")
+    el = rec["elements"]
+    assert rec["name"] == "vertex" and rec["n_elements"] == 1 and rec["path"].endswith("scene.ply")
+    table = np.stack([el[n] for n in el.dtype.names], axis=1).astype(np.float32)
+    assert all(el.dtype[n] == np.dtype("f4") for n in el.dtype.names)
+    save("ply_small", extrinsics=E, means=means, scales=scales, rotations=q, harmonics=sh, opacities=op,
+         table=table, names=np.array(el.dtype.names))
+
+
 if __name__ == "__main__":
     install_shim()
+    gen_ply()
     gen_depth_tail()
     gen_glue()
     gen_framing()

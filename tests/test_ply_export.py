@@ -49,3 +49,28 @@ def test_round_trip(tmp_path):
     assert names == construct_list_of_attributes(0) and len(names) == 17
     np.testing.assert_array_equal(data, ply_attributes(E, means, scales, q, sh, op))
     assert open(path, "rb").read(3) == b"ply"
+
+
+def test_attributes_match_reference_fixture(tmp_path):
+    """tests/golden/ply_small.npz: the attribute table the REFERENCE's export_ply (ply_export.py:26-92) handed to
+    plyfile for a seeded 400-Gaussian scene (make_golden.gen_ply).  Same names in the same order; same numbers
+    (quaternions up to the q / -q sign, which scipy's from_matrix picks differently in places)."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ply_small.npz"))
+    t = lambda k: torch.from_numpy(fx[k])
+    args = (t("extrinsics"), t("means"), t("scales"), t("rotations"), t("harmonics"), t("opacities"))
+    assert list(fx["names"]) == construct_list_of_attributes(0)
+    tab, ref = ply_attributes(*args), fx["table"]
+    np.testing.assert_allclose(tab[:, 0:3], ref[:, 0:3], atol=2e-6)          # normalised, rotated means
+    np.testing.assert_array_equal(tab[:, 3:10], ref[:, 3:10])                # normals (0), DC band, opacity: copies
+    np.testing.assert_allclose(tab[:, 10:13], ref[:, 10:13], atol=1e-6)      # log scales
+    sign = np.sign((tab[:, 13:17] * ref[:, 13:17]).sum(-1, keepdims=True))
+    np.testing.assert_allclose(tab[:, 13:17] * sign, ref[:, 13:17], atol=2e-6)
+    assert (sign > 0).mean() > 0.3                                           # (not a degenerate all-flipped match)
+    path = tmp_path / "scene.ply"
+    export_ply(*args, path)
+    names, data = read_ply(path)
+    assert names == list(fx["names"])
+    np.testing.assert_array_equal(data, tab)
+    head = open(path, "rb").read(200).decode("ascii", "replace")
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex 400\nproperty float x\n")
