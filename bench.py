@@ -100,6 +100,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
     from freesplat_amd.view_sharding import AsyncViewGather, GradExchange, shard_range
 
     H, W, N = synthetic.WORKLOADS[workload]
+    from freesplat_amd.rasterizer import _state as _rstate
+    _rstate(dev).last_instances = 0      # (capacity history of a previous workload in this process)
     scene = synthetic.make_scene(N)
     n_total_views = views * world
     cams_all = synthetic.target_cameras(n_total_views)

@@ -17,13 +17,13 @@ def find(src, sub, name):
 def main(src, tag, cmd):
     f = find(src, "trace", "kernel_stats.csv")
     rows = list(csv.DictReader(open(f))) if f else []
-    ours = [r for r in rows if r["Name"].startswith("fs::")]
+    ours = [r for r in rows if "fs::" in r["Name"].split("(")[0]]      # (templated kernels read "void fs::name<...>(")
     total = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as o:
         o.write("# rocprofv3 --kernel-trace --stats -- " + cmd + "\n")
         o.write("kernel,calls,avg_us,min_us,max_us,pct_of_gpu_time\n")
         for r in ours:
-            o.write(f"{r['Name'].split('(')[0]},{r['Calls']},{float(r['AverageNs'])/1e3:.1f},"
+            o.write(f"{r['Name'].split('(')[0].replace('void ', '')},{r['Calls']},{float(r['AverageNs'])/1e3:.1f},"
                     f"{float(r['MinNs'])/1e3:.1f},{float(r['MaxNs'])/1e3:.1f},{100*float(r['TotalDurationNs'])/total:.2f}\n")
         other = total - sum(float(r["TotalDurationNs"]) for r in ours)
         o.write(f"(torch / rocBLAS / rocclr kernels of the host glue),,,,,{100*other/total:.2f}\n")
@@ -33,8 +33,8 @@ def main(src, tag, cmd):
         agg = collections.defaultdict(list)
         if f:
             for r in csv.DictReader(open(f)):
-                if r["Kernel_Name"].startswith("fs::"):
-                    agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+                if "fs::" in r["Kernel_Name"].split("(")[0]:
+                    agg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
         return {k: sum(v) / len(v) for k, v in agg.items()}
 
     traffic = collections.defaultdict(dict)
@@ -51,10 +51,13 @@ def main(src, tag, cmd):
     for sub in ("sq1", "sq2"):
         for (k, c), v in mean_counters(sub).items():
             sq[k][c] = v
+    avg_us = {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) / 1e3 for r in ours}
     for k, d in sq.items():
-        if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("SQ_BUSY_CYCLES"):
-            # MI355X_MICROARCH.md: MFMA utilisation = MFMA-busy cycles / (busy cycles x 4 SIMDs per CU-cycle bucket)
-            d["mfma_busy_over_sq_busy_x4"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * d["SQ_BUSY_CYCLES"])
+        if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and avg_us.get(k):
+            # SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles summed over the 1024 SIMDs (MI355X_MICROARCH.md, PMC units);
+            # utilisation = busy cycles / (SIMDs x kernel duration x 2.4 GHz); duration from the kernel-trace pass
+            d["avg_us_kernel_trace"] = avg_us[k]
+            d["mfma_busy_frac_at_2.4GHz"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * avg_us[k] * 2400.0)
     json.dump({"command": cmd, "note": "mean per launch, separate --pmc passes", "kernels": sq},
               open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
     print(open(f"profiles/{tag}_kernel_stats.csv").read())
