@@ -748,30 +748,139 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
     FS_PT(2, 6);  // stored
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Bucket sort of one tile's keys in LDS (lists of <= 2048 keys: every tile of the BASELINE configs).
+// A tile sees a narrow depth band, and inside it the depth bits of its Gaussians are spread fairly evenly
+// (measured on config 3: 2048 buckets over [zmin, zmax] hold <= 10 keys each, 2.4 key comparisons per key), so an
+// O(n) distribution sort replaces the O(n log^2 n) network: ~60 VALU per key instead of ~550
+// (profiles/r1j_sq_counters.json: tile_sort was 49 M of the pipeline's 201 M VALU wave-instructions per view).
+//   1. zmin / zmax of the tile (wave shuffles + 8 LDS words);
+//   2. bucket = floor((z - zmin) * CAP / (zmax - zmin + 1)) -- a monotone function of the depth bits, so buckets are
+//      ordered front to back --, slot in the bucket by an LDS atomic (arrival order, arbitrary);
+//   3. exclusive scan of the CAP bucket counts (each thread owns EPT consecutive buckets);
+//   4. keys staged bucket by bucket in LDS; every key counts the keys of ITS bucket that are smaller (full 64-bit
+//      compare: equal depths order by Gaussian index, as the reference's stable sort does) -> final position.
+// The result is the same total order by (depth bits, id) as before, bit for bit.  Degenerate tiles (a bucket of more
+// than kMaxBucket keys: many identical depths) fall back to the register bitonic network on the keys already loaded.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kMaxBucket = 24;
+template <int EPT>
+__device__ __forceinline__ void sort_tile_buckets(const unsigned long long* __restrict__ keys, uint32_t* __restrict__ out,
+                                                  uint32_t n, unsigned long long* sk, uint32_t* cnt, uint32_t* s_red)
+{
+    constexpr int CAP = 256 * EPT;  // capacity == number of buckets
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned long long k[EPT];
+    uint32_t zmin = 0xFFFFFFFFu, zmax = 0u;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = (uint32_t)(e * 256 + t);
+        k[e] = i < n ? keys[i] : ~0ull;
+        cnt[i] = 0u;
+        if (i < n) {
+            const uint32_t z = (uint32_t)(k[e] >> 32);
+            zmin = min(zmin, z);
+            zmax = max(zmax, z);
+        }
+    }
+    if (t == 0) cnt[CAP] = 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        zmin = min(zmin, (uint32_t)__shfl_xor((int)zmin, m, 64));
+        zmax = max(zmax, (uint32_t)__shfl_xor((int)zmax, m, 64));
+    }
+    if (lane == 0) { s_red[wave] = zmin; s_red[4 + wave] = zmax; }
+    __syncthreads();
+    zmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    zmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    const float scale = (float)CAP / (float)(zmax - zmin + 1u);
+    uint32_t bs[EPT];  // bucket << 8 | slot   (slot <= kMaxBucket matters only when not degenerate)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = (uint32_t)(e * 256 + t);
+        bs[e] = 0u;
+        if (i < n) {
+            const uint32_t z = (uint32_t)(k[e] >> 32);
+            const uint32_t b = min((uint32_t)(CAP - 1), (uint32_t)((float)(z - zmin) * scale));
+            const uint32_t slot = atomicAdd(&cnt[b], 1u);
+            bs[e] = (b << 8) | min(slot, 255u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: thread t owns buckets [t*EPT, (t+1)*EPT)
+    uint32_t c[EPT], sum = 0u, mx = 0u;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        c[j] = cnt[t * EPT + j];
+        sum += c[j];
+        mx = max(mx, c[j]);
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_red[8 + wave] = inc;
+    const bool degenerate = __syncthreads_or(mx > kMaxBucket) != 0;
+    uint32_t run = inc - sum;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) run += w < wave ? s_red[8 + w] : 0u;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        cnt[t * EPT + j] = run;
+        run += c[j];
+    }
+    if (t == 255) cnt[CAP] = run;  // == n
+    if (degenerate) {
+        Stages<EPT, CAP>::run(k, t, sk);  // (its exchanges synchronise the workgroup themselves)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const uint32_t i = (uint32_t)t * EPT + e;
+            if (i < n) out[i] = (uint32_t)k[e];
+        }
+        return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if ((uint32_t)(e * 256 + t) < n) sk[cnt[bs[e] >> 8] + (bs[e] & 255u)] = k[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if ((uint32_t)(e * 256 + t) < n) {
+            const uint32_t b = bs[e] >> 8;
+            const uint32_t lo = cnt[b], hi = cnt[b + 1];
+            uint32_t r = 0u;
+            for (uint32_t j = lo; j < hi; ++j) r += sk[j] < k[e] ? 1u : 0u;
+            out[lo + r] = (uint32_t)k[e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_sort_kernel(int gx, int gy, const uint32_t* __restrict__ offsets,
                                                         unsigned long long* __restrict__ keys,
                                                         uint32_t* __restrict__ point_list,
                                                         const uint32_t* __restrict__ counters)
 {
     __shared__ unsigned long long sk[kSortLds];
+    __shared__ uint32_t s_cnt[kSortLds + 1];
+    __shared__ uint32_t s_red[16];
     if (counters[1]) return;  // overflowed capacity: ranges are not backed by memory
     const int tile = tile_for_block(blockIdx.x, gx, gy);  // XCD-aware, balanced (fs_common.h)
     if (tile < 0) return;
     const uint32_t a = offsets[tile], b = offsets[tile + 1];
     const uint32_t n = b - a;
     if (n == 0) return;
-    if (n <= 512u) {
-        sort_tile_in_registers<2>(keys + a, point_list + a, n, sk);
-    } else if (n <= 768u) {
-        sort_tile_two_runs<2, 1>(keys + a, point_list + a, n, sk);
+    if (n <= 256u) {
+        sort_tile_buckets<1>(keys + a, point_list + a, n, sk, s_cnt, s_red);
+    } else if (n <= 512u) {
+        sort_tile_buckets<2>(keys + a, point_list + a, n, sk, s_cnt, s_red);
     } else if (n <= 1024u) {
-        sort_tile_in_registers<4>(keys + a, point_list + a, n, sk);
-    } else if (n <= 1280u) {
-        sort_tile_two_runs<4, 1>(keys + a, point_list + a, n, sk);
-    } else if (n <= 1536u) {
-        sort_tile_two_runs<4, 2>(keys + a, point_list + a, n, sk);
+        sort_tile_buckets<4>(keys + a, point_list + a, n, sk, s_cnt, s_red);
     } else if (n <= 2048u) {
-        sort_tile_in_registers<8>(keys + a, point_list + a, n, sk);
+        sort_tile_buckets<8>(keys + a, point_list + a, n, sk, s_cnt, s_red);
     } else if (n <= 2560u) {
         sort_tile_two_runs<8, 2>(keys + a, point_list + a, n, sk);
     } else if (n <= 3072u) {

@@ -176,6 +176,23 @@ def test_depth_ties_break_by_index(hip_device, monkeypatch):
     np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
 
 
+@pytest.mark.parametrize("copies,N", [(30, 40), (3, 700)])
+def test_tile_sort_heavy_depth_ties(hip_device, monkeypatch, copies, N):
+    """Many Gaussians with bit-identical depth in one tile: the tile sort's depth buckets overflow (30 copies -> the
+    bitonic fallback) or hold multi-way ties (3 copies, resolved by the in-bucket 64-bit compare); either way the
+    list order is (depth, index) exactly as the oracle's stable sort gives it."""
+    _set_cull(monkeypatch, False)
+    H = W = 32
+    scene, cams = small_scene(N=N, H=H, W=W, seed=16)
+    for k in ("means", "covariances", "harmonics", "opacities"):
+        scene[k] = torch.cat([scene[k]] * copies)
+    vi = view_inputs(scene, cams, 0, H, W)
+    st, _, _ = _check_forward(vi, hip_device)
+    dbg, _, _ = _internal_state(vi, hip_device)
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    assert (np.diff(dbg["offsets"]) > 24).any()
+
+
 def test_capacity_overflow_retry(hip_device, monkeypatch):
     from freesplat_amd import rasterizer as R
     scene, cams = small_scene(N=3000, H=64, W=64, seed=8)
