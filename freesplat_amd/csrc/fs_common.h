@@ -208,7 +208,7 @@ __device__ __forceinline__ Cov2D project_cov(const float* __restrict__ V, float3
 
 // ---- rasterizer buffer layouts (opaque to the caller; see fs_raster_buffer_sizes) ------------
 // geom: [N] x 3 float4 screen-space records, [N] ushort4 tile rects, [N] u8 clamp bits, [N] u64
-// packed quadrant masks (valid for rects of <= 16 tiles; larger rects recompute them).
+// packed quadrant masks (valid for rects of <= 16 tiles; larger rects recompute them), [N] f32 depths.
 //   r0 = {px, py, -A/2, -C/2}   r1 = {-B, opacity, power_skip_threshold, view_z}
 //   r2 = {r, g, b, 0}           (A,B,C) = conic (inverse dilated 2D covariance)
 struct GeomView {
@@ -216,10 +216,12 @@ struct GeomView {
     ushort4* rect;
     uint8_t* clamp;
     unsigned long long* qmask;  // 4 quadrant bits per tile of the rect (row-major), rects <= 16 tiles
+    float* depth;               // view-space z again, densely packed: all the emit pass needs of a record for small rects
 };
 __host__ __device__ inline size_t geom_bytes(int N)
 {
-    return align_up((size_t)N * 48, 256) + 2 * align_up((size_t)N * 8, 256) + align_up((size_t)N, 256);
+    return align_up((size_t)N * 48, 256) + 2 * align_up((size_t)N * 8, 256) + align_up((size_t)N, 256) +
+           align_up((size_t)N * 4, 256);
 }
 __host__ __device__ inline GeomView geom_view(void* base, int N)
 {
@@ -232,6 +234,8 @@ __host__ __device__ inline GeomView geom_view(void* base, int N)
     g.clamp = (uint8_t*)p;
     p += align_up((size_t)N, 256);
     g.qmask = (unsigned long long*)p;
+    p += align_up((size_t)N * 8, 256);
+    g.depth = (float*)p;
     return g;
 }
 // Tile -> workgroup order of the per-tile kernels (tile_sort, render, render_bwd).  Workgroup b runs on XCD b % 8

@@ -3,13 +3,15 @@
 // Replaces the CUDA extension FreeSplat calls at src/model/decoder/cuda_splatting.py:114-127
 // (semantics: SURVEY.md Appendix A.1-A.4).  Pipeline, all on one stream, no host sync:
 //
-//   preprocess   1 thread / Gaussian   project, cull, EWA conic, SH->RGB, tile rect,
-//                                      atomic per-tile instance count
-//   tile_scan    1 workgroup           exclusive scan of the T tile counts -> tile ranges
-//   emit         1 thread / Gaussian   scatter (depth_bits<<32 | id) keys into the tile ranges
-//   tile_sort    1 workgroup / tile    LDS bitonic sort of the tile's keys -> id list
-//   render       1 workgroup / tile    16x16 px = 4 wavefronts, LDS-staged batches of 256
-//                                      Gaussian records, front-to-back alpha compositing
+//   preprocess   1 thread / Gaussian    project, cull, EWA conic, SH->RGB, tile rect, 8x8-quadrant masks of the
+//                                       alpha >= 1/255 ellipse, per-tile instance counts (LDS-privatised per workgroup)
+//   tile_scan    1 workgroup            exclusive scan of the T tile counts -> tile ranges, overflow flag
+//   emit         1 thread / Gaussian    scatter (depth_bits<<32 | id<<4 | quadrant mask) keys into the tile ranges
+//   tile_sort    1 workgroup / tile     LDS bucket sort by depth (O(n); bitonic network for lists > 2048 keys and
+//                                       degenerate tiles) -> list words (id<<4 | mask) in (depth, id) order
+//   render       1 single-wavefront workgroup per 8x8 QUADRANT of a tile, no barrier anywhere: survivors of 64 list
+//                                       entries compacted pairwise into wavefront-private LDS, packed-fp32 exponent /
+//                                       exp / alpha over pairs of Gaussians, front-to-back alpha compositing
 //
 // Design notes (MI355X-first, not the CUDA layout):
 //   * no global 64-bit radix sort over all instances: instances are binned per tile with
@@ -18,8 +20,9 @@
 //     (tile, depth) keys emitted in Gaussian order would give -- "identical tile/depth ordering";
 //   * nothing on the path needs the instance count on the host;
 //   * per-Gaussian screen-space state is one 48-byte record (3 x dwordx4 gather per instance);
-//   * tile -> workgroup mapping is XCD-aware: workgroup b runs on XCD b%8, so each XCD gets a
-//     contiguous band of tiles and neighbouring tiles share their Gaussians' records in one L2.
+//   * tile -> workgroup mapping is XCD-aware and balanced: workgroup b runs on XCD b % 8; tiles are grouped in 4x4
+//     super-tiles (neighbours share most of their Gaussians -> one L2) and super-tile s goes to XCD s % 8
+//     (fs_common.h:tile_for_block).
 #include "fs_common.h"
 
 namespace fs {
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         g.rec[3 * (size_t)i + 2] = r2;
         g.rect[i] = rect;
         g.clamp[i] = cb;
+        g.depth[i] = r1.w;
         radii[i] = rad;
     }
 
@@ -465,13 +469,16 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, Geo
     const bool valid = rc.z > rc.x && rc.w > rc.y;
     const bool cull = (flags & FS_RASTER_TILE_CULL) != 0;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+    float zdepth = 0.0f;
     if (valid) {
-        r1 = g.rec[3 * (size_t)i + 1];
-        if ((rc.z - rc.x) * (rc.w - rc.y) > 16) r0 = g.rec[3 * (size_t)i];
+        // small rects (the common case) carry their masks precomputed: only the 4-byte depth is read, not the
+        // 48-byte record (whose lines the dense depth array spares: 65 -> ~25 MB of reads per view at config 3)
+        zdepth = g.depth[i];
+        if ((rc.z - rc.x) * (rc.w - rc.y) > 16) { r0 = g.rec[3 * (size_t)i]; r1 = g.rec[3 * (size_t)i + 1]; }
     }
     // key = depth bits : (gaussian id << 4 | quadrant mask); the mask is a function of (id, tile), so
     // ordering by the key is ordering by (depth, id)
-    const unsigned long long key_hi = ((unsigned long long)__float_as_uint(r1.w) << 32) | ((uint32_t)i << 4);
+    const unsigned long long key_hi = ((unsigned long long)__float_as_uint(zdepth) << 32) | ((uint32_t)i << 4);
     const int area = (rc.z - rc.x) * (rc.w - rc.y);
     const bool small = area <= 16;
     const unsigned long long qm = (valid && small) ? g.qmask[i] : 0ull;
