@@ -295,6 +295,152 @@ __global__ __launch_bounds__(256) void ptf_write_state_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Training path: backward of one fold step's data movement (the differentiable part of
+// encoder_freesplat.py:485-519 around the GRU).  Forward of a step:
+//   out = [ in[keep] | fused rows | view rows[app] ],   fused row t (m = fuse[t], p = fpix[t], w0 = R[m], w1 = rho_i[p]):
+//     G = GRU(cat[t]);  X, E, D = (in * w0 + view * w1) / (w0 + w1);  R = w0 + w1;  O = O[m] + om_i[p]
+// ptf_write_state_bwd turns the gradient of `out` into the gradient of `in` (every in-row is kept or fused exactly
+// once: plain stores) and of the view's arrays (a pixel may be fused by several tied Gaussians: float atomics into
+// zero-initialised arrays); the GRU rows' gradient is the contiguous block d_out.G[n_keep : n_keep+n_fuse].
+// ptf_gru_inputs_bwd scatters the gradient of the GRU's concatenated input rows [hid | he | x | xe] back through
+// the gather and the positional encodings (he = PE(rho_i[p], O[m]), xe = PE(R[m], om_i[p]); :62-77, 485-486).
+// ------------------------------------------------------------------------------------------
+struct PtfGrad { float *G, *X, *R, *O, *E, *D; };   // any member may be NULL (no gradient for that field)
+
+__global__ __launch_bounds__(256) void ptf_write_state_bwd_kernel(
+    int n_keep, int n_fuse, int n_app, const long long* __restrict__ keep_idx, const long long* __restrict__ fuse_idx,
+    const long long* __restrict__ fuse_pix, const long long* __restrict__ app_pix, PtfState s,
+    const float* __restrict__ x_i, const float* __restrict__ rho_i, const float* __restrict__ d_i,
+    const float* __restrict__ E_i, PtfGrad go, PtfGrad gs, float* __restrict__ g_lat_i, float* __restrict__ g_x_i,
+    float* __restrict__ g_rho_i, float* __restrict__ g_om_i, float* __restrict__ g_d_i)
+{
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
+    const int n_out = n_keep + n_fuse + n_app;
+    if (row >= n_out) return;
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 dG = go.G ? ((const float4*)(go.G + (size_t)row * 64))[c] : z4;
+    if (row < n_keep) {
+        const long long m = keep_idx[row];
+        ((float4*)(gs.G + m * 64))[c] = dG;
+        if (c < 4) ((float4*)(gs.E + m * 16))[c] = go.E ? ((const float4*)(go.E + (size_t)row * 16))[c] : z4;
+        if (c == 4) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gs.X[3 * m + k] = go.X ? go.X[3 * (size_t)row + k] : 0.0f;
+        }
+        if (c == 5) {
+            gs.R[m] = go.R ? go.R[row] : 0.0f;
+            gs.O[m] = go.O ? go.O[row] : 0.0f;
+            gs.D[m] = go.D ? go.D[row] : 0.0f;
+        }
+    } else if (row < n_keep + n_fuse) {
+        const int t = row - n_keep;
+        const long long m = fuse_idx[t], p = fuse_pix[t];
+        const float w0 = s.R[m], w1 = rho_i[p], ws = w0 + w1, inv = 1.0f / ws;
+        // (the latent row's gradient goes through the GRU: ptf_gru_inputs_bwd writes gs.G[m])
+        float dw0 = 0.0f, dw1 = 0.0f;  // partial sums of this lane; reduced over the 16-lane group below
+        if (c < 4) {
+            const float4 a = ((const float4*)(s.E + m * 16))[c], b = ((const float4*)E_i)[c];
+            const float4 g = go.E ? ((const float4*)(go.E + (size_t)row * 16))[c] : z4;
+            const float ox = (a.x * w0 + b.x * w1) * inv, oy = (a.y * w0 + b.y * w1) * inv;
+            const float oz = (a.z * w0 + b.z * w1) * inv, ow = (a.w * w0 + b.w * w1) * inv;
+            ((float4*)(gs.E + m * 16))[c] = make_float4(g.x * w0 * inv, g.y * w0 * inv, g.z * w0 * inv, g.w * w0 * inv);
+            dw0 += (g.x * (a.x - ox) + g.y * (a.y - oy) + g.z * (a.z - oz) + g.w * (a.w - ow)) * inv;
+            dw1 += (g.x * (b.x - ox) + g.y * (b.y - oy) + g.z * (b.z - oz) + g.w * (b.w - ow)) * inv;
+        }
+        if (c == 4) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float a = s.X[3 * m + k], b = x_i[3 * p + k], g = go.X ? go.X[3 * (size_t)row + k] : 0.0f;
+                const float o = (a * w0 + b * w1) * inv;
+                gs.X[3 * m + k] = g * w0 * inv;
+                atomicAdd(&g_x_i[3 * p + k], g * w1 * inv);
+                dw0 += g * (a - o) * inv;
+                dw1 += g * (b - o) * inv;
+            }
+        }
+        if (c == 5) {
+            const float a = s.D[m], b = d_i[p], g = go.D ? go.D[row] : 0.0f;
+            const float o = (a * w0 + b * w1) * inv;
+            gs.D[m] = g * w0 * inv;
+            atomicAdd(&g_d_i[p], g * w1 * inv);
+            dw0 += g * (a - o) * inv;
+            dw1 += g * (b - o) * inv;
+            const float gR = go.R ? go.R[row] : 0.0f, gO = go.O ? go.O[row] : 0.0f;
+            dw0 += gR; dw1 += gR;          // R_out = w0 + w1
+            gs.O[m] = gO;                  // O_out = O[m] + om_i[p]
+            atomicAdd(&g_om_i[p], gO);
+        }
+        // sum dw0 / dw1 over lanes 0..5 of the 16-lane group (xor shuffles stay inside the group)
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+            dw0 += __shfl_xor(dw0, d, 64);
+            dw1 += __shfl_xor(dw1, d, 64);
+        }
+        if (c == 0) {
+            gs.R[m] = dw0;                 // (+ the positional-encoding term: ptf_gru_inputs_bwd adds it)
+            atomicAdd(&g_rho_i[p], dw1);
+        }
+    } else {
+        const long long p = app_pix[row - n_keep - n_fuse];
+        float4* q = (float4*)(g_lat_i + p * 64) + c;   // an appended pixel is appended once and never fused
+        const float4 v = *q;
+        *q = make_float4(v.x + dG.x, v.y + dG.y, v.z + dG.z, v.w + dG.w);
+        if (c == 4 && go.X) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g_x_i[3 * p + k] += go.X[3 * (size_t)row + k];
+        }
+        if (c == 5) {
+            if (go.R) g_rho_i[p] += go.R[row];
+            if (go.O) g_om_i[p] += go.O[row];
+            if (go.D) g_d_i[p] += go.D[row];
+        }
+    }
+}
+
+__device__ __forceinline__ void pos_enc2_bwd(float a, float b, const float* __restrict__ g, float& da, float& db)
+{   // out[2k] = sin(a f), out[2k+1] = cos(a f), out[12+2k] = sin(b f), out[12+2k+1] = cos(b f), f = 2^k
+    da = 0.0f; db = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float f = (float)(1 << k);
+        da += f * (g[2 * k] * cosf(a * f) - g[2 * k + 1] * sinf(a * f));
+        db += f * (g[12 + 2 * k] * cosf(b * f) - g[12 + 2 * k + 1] * sinf(b * f));
+    }
+}
+
+__global__ __launch_bounds__(256) void ptf_gru_inputs_bwd_kernel(int n_fuse, const long long* __restrict__ fuse_idx,
+                                                                const long long* __restrict__ fuse_pix,
+                                                                const float* __restrict__ R, const float* __restrict__ O,
+                                                                const float* __restrict__ rho_i,
+                                                                const float* __restrict__ om_i,
+                                                                const float* __restrict__ dcat, float* __restrict__ gG,
+                                                                float* __restrict__ gR, float* __restrict__ gO,
+                                                                float* __restrict__ g_lat_i, float* __restrict__ g_rho_i,
+                                                                float* __restrict__ g_om_i)
+{
+    const int t = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
+    if (t >= n_fuse) return;
+    const long long m = fuse_idx[t], p = fuse_pix[t];
+    const float* row = dcat + (size_t)t * 176;
+    ((float4*)(gG + m * 64))[c] = ((const float4*)row)[c];                    // hid: in-row m is fused exactly once
+    const float4 gx = ((const float4*)(row + 88))[c];                         // x: several tied rows may share pixel p
+    float* q = g_lat_i + p * 64 + 4 * c;
+    atomicAdd(q, gx.x); atomicAdd(q + 1, gx.y); atomicAdd(q + 2, gx.z); atomicAdd(q + 3, gx.w);
+    if (c == 0) {   // he = PE(rho_i[p], O[m])
+        float da, db;
+        pos_enc2_bwd(rho_i[p], O[m], row + 64, da, db);
+        atomicAdd(&g_rho_i[p], da);
+        gO[m] += db;
+    }
+    if (c == 1) {   // xe = PE(R[m], om_i[p])
+        float da, db;
+        pos_enc2_bwd(R[m], om_i[p], row + 152, da, db);
+        gR[m] += da;
+        atomicAdd(&g_om_i[p], db);
+    }
+}
+
 __host__ __device__ inline size_t ptf_scratch_layout(int M, int P, size_t off[7])
 {
     const int nbM = (M + kScanBlock - 1) / kScanBlock, nbP = (P + kScanBlock - 1) / kScanBlock;
@@ -534,5 +680,73 @@ FS_API int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const 
         if (rc != FS_OK) return rc;
         for (int k = 0; k < 6; ++k) cur[k] = out[k];
     }
+    return FS_OK;
+}
+
+
+// ---- training path ------------------------------------------------------------------------------------------
+// The four ordered index lists of the fold step that last used `scratch` (fs_ptf_fold_step keeps them there):
+// lists[0..3] = keep_idx, fuse_idx, fuse_pix, append_pix (device pointers into scratch; lengths = counts[0..2]).
+FS_API int fs_ptf_fold_step_lists(int32_t M_max, int32_t h, int32_t w, void* scratch, int64_t** lists)
+{
+    if (M_max <= 0 || h <= 0 || w <= 0 || !scratch || !lists) return FS_ERR_INVALID_ARG;
+    const FoldLayout L = fold_layout(M_max, h * w);
+    char* s = (char*)scratch;
+    lists[0] = (int64_t*)(s + L.keep); lists[1] = (int64_t*)(s + L.fuse);
+    lists[2] = (int64_t*)(s + L.fpix); lists[3] = (int64_t*)(s + L.app);
+    return FS_OK;
+}
+
+// Backward of fs_ptf_write_state.  g_out[6] / g_in[6]: gradients of the out / in state arrays in the order
+// G, X, R, O, E, D (entries of g_out may be NULL = zero gradient; g_in all required, every row is written except
+// g_in G of the fused rows, which fs_ptf_gru_inputs_backward writes).  The gradients of the view's arrays
+// (g_lat_i [P,64], g_x_i [P,3], g_rho_i / g_om_i / g_d_i [P]) are ACCUMULATED: zero them before the first step.
+// The gradient of the GRU output rows is g_out[0] + n_keep*64 (n_fuse contiguous rows).
+FS_API int fs_ptf_write_state_backward(int32_t n_keep, int32_t n_fuse, int32_t n_app, const int64_t* keep_idx,
+                                       const int64_t* fuse_idx, const int64_t* fuse_pix, const int64_t* append_pix,
+                                       const float* X, const float* R, const float* E, const float* D,
+                                       const float* x_i, const float* rho_i, const float* d_i, const float* E_i,
+                                       float* const* g_out, float* const* g_in, float* g_lat_i, float* g_x_i,
+                                       float* g_rho_i, float* g_om_i, float* g_d_i, void* stream_)
+{
+    if (n_keep < 0 || n_fuse < 0 || n_app < 0 || !g_out || !g_in) return FS_ERR_INVALID_ARG;
+    const long long n_out = (long long)n_keep + n_fuse + n_app;
+    if (n_out == 0) return FS_OK;
+    if (!g_lat_i || !g_x_i || !g_rho_i || !g_om_i || !g_d_i || !x_i || !rho_i || !d_i || !E_i) return FS_ERR_INVALID_ARG;
+    if (n_keep || n_fuse) {
+        if (!X || !R || !E || !D) return FS_ERR_INVALID_ARG;
+        for (int k = 0; k < 6; ++k)
+            if (!g_in[k]) return FS_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    ScopedStage prof_(kStPtf, st);
+    PtfState s{nullptr, const_cast<float*>(X), const_cast<float*>(R), nullptr, const_cast<float*>(E), const_cast<float*>(D)};
+    PtfGrad go{g_out[0], g_out[1], g_out[2], g_out[3], g_out[4], g_out[5]};
+    PtfGrad gs{g_in[0], g_in[1], g_in[2], g_in[3], g_in[4], g_in[5]};
+    hipLaunchKernelGGL(ptf_write_state_bwd_kernel, dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
+                       n_app, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
+                       (const long long*)append_pix, s, x_i, rho_i, d_i, E_i, go, gs, g_lat_i, g_x_i, g_rho_i, g_om_i, g_d_i);
+    FS_CHECK_LAUNCH("ptf_write_state_bwd");
+    return FS_OK;
+}
+
+// Backward of fs_ptf_gru_inputs: dcat [n_fuse,176] -> g_G [M,64] rows fuse_idx (stored), g_R / g_O [M] (added to what
+// fs_ptf_write_state_backward stored), g_lat_i / g_rho_i / g_om_i of the view (accumulated, atomics).
+FS_API int fs_ptf_gru_inputs_backward(int32_t n_fuse, const int64_t* fuse_idx, const int64_t* fuse_pix, const float* R,
+                                      const float* O, const float* rho_i, const float* om_i, const float* dcat,
+                                      float* g_G, float* g_R, float* g_O, float* g_lat_i, float* g_rho_i, float* g_om_i,
+                                      void* stream_)
+{
+    if (n_fuse < 0) return FS_ERR_INVALID_ARG;
+    if (n_fuse == 0) return FS_OK;
+    if (!fuse_idx || !fuse_pix || !R || !O || !rho_i || !om_i || !dcat || !g_G || !g_R || !g_O || !g_lat_i || !g_rho_i ||
+        !g_om_i)
+        return FS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    ScopedStage prof_(kStPtf, st);
+    hipLaunchKernelGGL(ptf_gru_inputs_bwd_kernel, dim3((n_fuse + 15) / 16), dim3(256), 0, st, n_fuse,
+                       (const long long*)fuse_idx, (const long long*)fuse_pix, R, O, rho_i, om_i, dcat, g_G, g_R, g_O,
+                       g_lat_i, g_rho_i, g_om_i);
+    FS_CHECK_LAUNCH("ptf_gru_inputs_bwd");
     return FS_OK;
 }

@@ -6,15 +6,17 @@ outputs in the same ORDER) together with the modules it needs: `GRU`
 construction order kept so checkpoints and seeded inits carry over) and `positional_encoding`
 (encoder_freesplat.py:62-77).
 
-Split of work per fold step:
-  * everything data-dependent and non-differentiable -- projection of the M global Gaussians, the
-    per-pixel z-buffer, the depth-consistency mask, winner selection and the three ORDERED index
-    lists -- is fs_ptf_match in libfreesplat_hip.so (6 launches, no host sync, replaces
-    scatter_reduce_ + 2x torch.isin + boolean-mask indexing + 4 syncs of the reference);
-  * the differentiable part (gather by those indices, GRU, density-weighted blends, concatenation)
-    stays in torch ops on the device, so autograd gives the reference's gradients unchanged; the GRU's
-    176/152 -> 64 -> 64 linears are plain library GEMMs (rocBLAS).
-One host sync per view remains (the three list lengths size the torch tensors).
+The fold is HIP in both modes (b = 1, the only shape the reference's indexing supports):
+  * forward (inference AND training): per view fs_ptf_fold_step = match (projection of the M global Gaussians,
+    per-pixel z-buffer, depth-consistency mask, winner selection, the ORDERED index lists) -> GRU inputs (gather +
+    positional encodings) -> GRU on the fp32 matrix cores -> next state, every data-dependent size device-resident;
+    ONE host sync per fold (the reference: four per view);
+  * backward (_PtfFold): per step, in reverse, fs_ptf_write_state_backward (density-weighted blends, keep / append
+    copies) and fs_ptf_gru_inputs_backward (gather + positional encodings) are HIP kernels; the GRU's own backward --
+    six plain linear layers, dW = dY^T X over ~10^5 pairs -- re-runs the GRU on the re-gathered input rows and lets
+    rocBLAS form the weight gradients (plain library GEMMs);
+  * `fuse_gaussians_torch` keeps the op-by-op torch formulation (fs_ptf_match indices + autograd) for b > 1 inputs and
+    as the cross-check of the HIP backward in tests/test_ptf_hip.py.
 """
 from __future__ import annotations
 
@@ -170,19 +172,172 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
     return G[None, :n], X[None, :n], E[:n].view(1, n, 4, 4), D[None, :n, 0]
 
 
+def _gru_params(gru: "GRU") -> list:
+    return [gru.mlp_r[0].weight, gru.mlp_r[0].bias, gru.mlp_r[2].weight, gru.mlp_r[2].bias,
+            gru.mlp_z[0].weight, gru.mlp_z[0].bias, gru.mlp_z[2].weight, gru.mlp_z[2].bias,
+            gru.mlp_n[0].weight, gru.mlp_n[0].bias, gru.mlp_n[2].weight, gru.mlp_n[2].bias]
+
+
+def _gru_from_cat(params: list, cat: Tensor) -> Tensor:
+    """The GRU (networks.py:201-214) on concatenated rows cat = [hid(64) | he(24) | x(64) | xe(24)] with explicit
+    parameters (so torch.autograd.grad can be asked for exactly these)."""
+    F = torch.nn.functional
+    Wr1, br1, Wr2, br2, Wz1, bz1, Wz2, bz2, Wn1, bn1, Wn2, bn2 = params
+    hid = cat[:, :64]
+    r = torch.sigmoid(F.linear(F.relu(F.linear(cat, Wr1, br1)), Wr2, br2))
+    z = torch.sigmoid(F.linear(F.relu(F.linear(cat, Wz1, bz1)), Wz2, bz2))
+    q = torch.tanh(F.linear(F.relu(F.linear(torch.cat((r * hid, cat[:, 88:]), dim=-1), Wn1, bn1)), Wn2, bn2))
+    return (1 - z) * hid + z * q
+
+
+class _PtfFold(torch.autograd.Function):
+    """Differentiable fold of V views (b = 1) on the HIP kernels.  Inputs: lat [V,P,64], xs [V,P,3], rho / om / dep
+    [V,P], Es [V,16] and Kn [V,9] (no gradient), then the 12 GRU parameters.  Outputs: G [n,64], X [n,3], E [n,16],
+    D [n]."""
+
+    @staticmethod
+    def forward(ctx, lat, xs, rho, om, dep, Es, Kn, h, w, depth_thres, tables, *params):
+        L = _lib.lib()
+        p = _lib.ptr
+        V, P = lat.shape[0], lat.shape[1]
+        dev = lat.device
+        w2c = torch.linalg.inv_ex(Es.view(V, 4, 4)).inverse.reshape(V, 16).contiguous()   # (the reference's own inverse)
+        kpix = (Kn.view(V, 3, 3)[:, [0, 1, 0, 1], [0, 1, 2, 2]] * torch.tensor([w, h, w, h], dtype=torch.float32, device=dev)).contiguous()
+        E0 = Es[0].reshape(1, 16).repeat(P, 1)
+        counts = torch.empty(V, 4, dtype=torch.int32, device=dev)
+        state = (lat[0], xs[0], rho[0], om[0], E0, dep[0])         # G, X, R, O, E, D of the state after view 0
+        states, scratches = [state], [None]
+        for i in range(1, V):
+            M_max = i * P
+            rows = M_max + P
+            out = tuple(torch.empty(rows, n, device=dev) for n in (64, 3, 1, 1, 16, 1))
+            scratch = torch.empty(L.fs_ptf_fold_scratch_bytes(M_max, h, w), dtype=torch.uint8, device=dev)
+            G, X, R, O, E, D = state
+            _lib.check(L.fs_ptf_fold_step(
+                M_max, None if i == 1 else p(counts[i - 1, 3:]), h, w, p(G), p(X), p(R), p(O), p(E), p(D),
+                p(lat[i]), p(xs[i]), p(rho[i]), p(om[i]), p(dep[i]), p(Es[i]), p(w2c[i]), p(kpix[i]),
+                C.c_float(depth_thres), p(tables), p(scratch), *[p(t) for t in out], p(counts[i]),
+                _lib.current_stream()), "fs_ptf_fold_step")
+            state = out
+            states.append(out)
+            scratches.append(scratch)
+        global LAST_FOLD_COUNTS
+        LAST_FOLD_COUNTS = counts
+        cnt = counts.tolist()                          # the only host sync of the fold
+        cnt[0] = [P, 0, 0, P]
+        n = cnt[V - 1][3]
+        ctx.cnt, ctx.hw, ctx.states, ctx.scratches = cnt, (h, w), states, scratches
+        ctx.save_for_backward(lat, xs, rho, om, dep, Es, *params)
+        G, X, R, O, E, D = state
+        return G[:n], X[:n], E[:n], D[:n, 0]
+
+    @staticmethod
+    def backward(ctx, gG, gX, gE, gD):
+        lat, xs, rho, om, dep, Es, *params = ctx.saved_tensors
+        L = _lib.lib()
+        p = _lib.ptr
+        h, w = ctx.hw
+        V, P = lat.shape[0], lat.shape[1]
+        dev = lat.device
+        cnt = ctx.cnt
+        n = cnt[V - 1][3]
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        g_lat, g_xs, g_rho, g_om, g_dep = z(V, P, 64), z(V, P, 3), z(V, P), z(V, P), z(V, P)
+        g_params = [None] * len(params)
+        # gradient of the current out state: G, X, R, O, E, D (None = zero)
+        c = lambda t: None if t is None else t.contiguous()
+        g_out = [c(gG), c(gX), None, None, c(gE), None if gD is None else gD.contiguous().view(n, 1)]
+        vp = lambda ts: (C.c_void_p * 6)(*[None if t is None else t.data_ptr() for t in ts])
+        for i in range(V - 1, 0, -1):
+            nk, nf, na, _ = cnt[i]
+            M_in = cnt[i - 1][3]
+            G, X, R, O, E, D = ctx.states[i - 1]
+            lists = (C.c_void_p * 4)()
+            _lib.check(L.fs_ptf_fold_step_lists(i * P, h, w, p(ctx.scratches[i]), lists), "fs_ptf_fold_step_lists")
+            keep, fuse, fpix, app = (C.c_void_p(v) for v in lists)
+            g_in = [torch.empty(M_in, k, dtype=torch.float32, device=dev) for k in (64, 3, 1, 1, 16, 1)]
+            _lib.check(L.fs_ptf_write_state_backward(
+                nk, nf, na, keep, fuse, fpix, app, p(X), p(R), p(E), p(D), p(xs[i]), p(rho[i]), p(dep[i]), p(Es[i]),
+                vp(g_out), vp(g_in), p(g_lat[i]), p(g_xs[i]), p(g_rho[i]), p(g_om[i]), p(g_dep[i]),
+                _lib.current_stream()), "fs_ptf_write_state_backward")
+            if nf > 0:
+                # the GRU rows: re-gather their inputs (HIP), run the GRU's backward as plain library GEMMs
+                cat = torch.empty(nf, 176, dtype=torch.float32, device=dev)
+                _lib.check(L.fs_ptf_gru_inputs(nf, fuse, fpix, p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]), p(cat),
+                                               _lib.current_stream()), "fs_ptf_gru_inputs")
+                g_fused = g_out[0][nk: nk + nf] if g_out[0] is not None else z(nf, 64)
+                with torch.enable_grad():
+                    cat_ = cat.requires_grad_(True)
+                    ps = [q.detach().requires_grad_(True) for q in params]
+                    fused = _gru_from_cat(ps, cat_)
+                    grads = torch.autograd.grad(fused, [cat_] + ps, g_fused)
+                dcat = grads[0].contiguous()
+                for k, gq in enumerate(grads[1:]):
+                    g_params[k] = gq if g_params[k] is None else g_params[k] + gq
+                _lib.check(L.fs_ptf_gru_inputs_backward(nf, fuse, fpix, p(R), p(O), p(rho[i]), p(om[i]), p(dcat),
+                                                        p(g_in[0]), p(g_in[2]), p(g_in[3]), p(g_lat[i]), p(g_rho[i]),
+                                                        p(g_om[i]), _lib.current_stream()), "fs_ptf_gru_inputs_backward")
+            g_out = g_in
+        # what is left is the gradient of the state after view 0 = view 0's own arrays (its extrinsics are constants)
+        if g_out[0] is not None:
+            g_lat[0] += g_out[0]
+        if g_out[1] is not None:
+            g_xs[0] += g_out[1]
+        if g_out[2] is not None:
+            g_rho[0] += g_out[2].view(-1)
+        if g_out[3] is not None:
+            g_om[0] += g_out[3].view(-1)
+        if g_out[5] is not None:
+            g_dep[0] += g_out[5].view(-1)
+        need = ctx.needs_input_grad
+        pick = lambda k, t: t if need[k] else None
+        return (pick(0, g_lat), pick(1, g_xs), pick(2, g_rho), pick(3, g_om), pick(4, g_dep), None, None, None, None,
+                None, None) + tuple(g if need[11 + k] else None for k, g in enumerate(g_params))
+
+
+def _fuse_gaussians_train(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
+                          depth_thres):
+    """Training path (autograd): the same HIP fold as inference, with a HIP backward (_PtfFold)."""
+    h, w = image_shape
+    V = gaussians[0].shape[1]
+    f32 = lambda t: t.float().contiguous()
+    lat = f32(gaussians[0][0])                    # [V,P,64]
+    xs = f32(coords[0][0, :, :, 0, 0])            # [V,P,3]
+    rho = f32(densities[0, :, :, 0, 0])           # [V,P]
+    om = f32(weight_emb[0, :, :, 0, 0])
+    dep = f32(depths.reshape(V, -1))
+    Es = f32(extrinsics[0].detach()).reshape(V, 16)
+    P = h * w
+    if V == 1:
+        return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
+    Kn = f32(intrinsics[0].detach()).reshape(V, 9)
+    G, X, E, D = _PtfFold.apply(lat, xs, rho, om, dep, Es, Kn, h, w, float(depth_thres), gru_tables(gru), *_gru_params(gru))
+    n = G.shape[0]
+    return G[None], X[None], E.view(1, n, 4, 4), D[None]
+
+
 def fuse_gaussians(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
                    depth_thres=0.1):
     """Same contract as EncoderFreeSplat.fuse_gaussians (encoder_freesplat.py:431-522); `self` only
     needs a `.gru` attribute.  gaussians = [latents [1,V,P,64]], coords = [[1,V,P,1,1,3]],
     densities / weight_emb [1,V,P,1,1], depths [V,1,h,w], extrinsics [1,V,4,4], intrinsics [1,V,3,3].
     Returns (latents [1,M,64], xyz [1,M,3], extrinsics [1,M,4,4], depths [1,M]).
-    Without autograd (eval / torch.no_grad) the fold runs through the fused HIP data-movement kernels."""
+    The fold runs on the HIP kernels with or without autograd (module docstring)."""
     needs_grad = torch.is_grad_enabled() and (
         any(t.requires_grad for t in (gaussians[0], coords[0], densities, weight_emb, depths))
         or any(q.requires_grad for q in self.gru.parameters()))
-    if not needs_grad and gaussians[0].shape[0] == 1:
-        return _fuse_gaussians_fused(self.gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics,
-                                     image_shape, depth_thres)
+    if gaussians[0].shape[0] == 1:
+        fn = _fuse_gaussians_train if needs_grad else _fuse_gaussians_fused
+        return fn(self.gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
+                  depth_thres)
+    return fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
+                                depth_thres)
+
+
+def fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
+                         depth_thres=0.1):
+    """The fold step by step in torch device ops on the HIP index lists (fs_ptf_match), differentiable through
+    autograd; one host sync per view.  Used for b > 1 and as the cross-check of _PtfFold's backward."""
     length = gaussians[0].shape[1]
     G = gaussians[0][:, 0]
     R = densities[:, 0]
@@ -235,3 +390,4 @@ class PixelwiseTripletFusion(nn.Module):
         self.gru = GRU()
 
     fuse_gaussians = fuse_gaussians
+    fuse_gaussians_torch = fuse_gaussians_torch

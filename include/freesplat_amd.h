@@ -355,6 +355,27 @@ int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float*
                              float* dL_dcov3D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
                              int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream);
 
+/* ---- PTF training path: backward of one fold step's data movement (encoder_freesplat.py:485-519) ----
+ * fs_ptf_fold_step_lists: device pointers (into the step's scratch) of the four ordered index lists the step left
+ * behind, lists[0..3] = keep_idx, fuse_idx, fuse_pix, append_pix (lengths = counts[0..2] of that step).
+ * fs_ptf_write_state_backward: gradient of the step's out state -> gradient of its in state and of the view's
+ * arrays.  g_out[6] / g_in[6] in the order G, X, R, O, E, D (g_out entries may be NULL = zero; every row of g_in is
+ * written, except g_in G of the fused rows, which fs_ptf_gru_inputs_backward writes).  View gradients g_lat_i [P,64],
+ * g_x_i [P,3], g_rho_i / g_om_i / g_d_i [P] are ACCUMULATED (zero them first; tied Gaussians may share a pixel).
+ * The gradient of the GRU output rows is g_out[0] + n_keep*64 (n_fuse contiguous rows).
+ * fs_ptf_gru_inputs_backward: dcat [n_fuse,176] -> g_G rows fuse_idx (stored), g_R / g_O (added), view gradients
+ * (accumulated) through the gather and the positional encodings (:62-77, 485-486). */
+int fs_ptf_fold_step_lists(int32_t M_max, int32_t h, int32_t w, void* scratch, int64_t** lists);
+int fs_ptf_write_state_backward(int32_t n_keep, int32_t n_fuse, int32_t n_app, const int64_t* keep_idx,
+                                const int64_t* fuse_idx, const int64_t* fuse_pix, const int64_t* append_pix,
+                                const float* X, const float* R, const float* E, const float* D, const float* x_i,
+                                const float* rho_i, const float* d_i, const float* E_i, float* const* g_out,
+                                float* const* g_in, float* g_lat_i, float* g_x_i, float* g_rho_i, float* g_om_i,
+                                float* g_d_i, void* stream);
+int fs_ptf_gru_inputs_backward(int32_t n_fuse, const int64_t* fuse_idx, const int64_t* fuse_pix, const float* R,
+                               const float* O, const float* rho_i, const float* om_i, const float* dcat, float* g_G,
+                               float* g_R, float* g_O, float* g_lat_i, float* g_rho_i, float* g_om_i, void* stream);
+
 /* Debug/test accessors into the opaque buffers (device pointers, no copies). */
 const uint32_t* fs_raster_tile_ranges(const void* binning, int32_t H, int32_t W);  /* [T+1] offsets */
 const uint32_t* fs_raster_point_list(const void* binning, int32_t H, int32_t W);   /* [I] (id << 4) | 8x8-quadrant mask */

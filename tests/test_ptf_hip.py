@@ -84,7 +84,8 @@ def _run_fold(g, gru_params, dev):
 @pytest.mark.parametrize("grad", [False, True])
 @pytest.mark.parametrize("name", ["ptf_small.npz", "ptf_tie.npz"])
 def test_fold_matches_reference_golden(hip_device, name, grad):
-    """grad=False: fused HIP data-movement path; grad=True: differentiable torch-op path."""
+    """grad=False: inference (fs_ptf_fold, one library call); grad=True: the training path (_PtfFold: the same HIP
+    fold step by step, state kept for its HIP backward)."""
     g, gru = _load(name)
     with torch.set_grad_enabled(grad):
         _, out = _run_fold(g, gru, hip_device)
@@ -103,34 +104,74 @@ def test_fused_inference_path_equals_differentiable_path(hip_device, V, h, w):
     a = ([d(lat)], [d(coords)], d(dens), d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))
     with torch.no_grad():
         fused = m.fuse_gaussians(*a)
-    ref = m.fuse_gaussians(*a)   # GRU parameters require grad -> differentiable path
-    assert ref[0].requires_grad and not fused[0].requires_grad
-    for x, y, name in zip(fused, ref, ("latent", "xyz", "extrinsics", "depths")):
-        assert x.shape == y.shape, name
-        assert (x - y.detach()).abs().max().item() <= 2e-5, name
+    ref = m.fuse_gaussians(*a)   # GRU parameters require grad -> training path (HIP fold + HIP backward)
+    tor = m.fuse_gaussians_torch(*a)   # op-by-op torch formulation on the HIP index lists
+    assert ref[0].requires_grad and tor[0].requires_grad and not fused[0].requires_grad
+    for x, y, t, name in zip(fused, ref, tor, ("latent", "xyz", "extrinsics", "depths")):
+        assert x.shape == y.shape == t.shape, name
+        assert torch.equal(x, y.detach()), name                      # same kernels, same bits
+        assert (x - t.detach()).abs().max().item() <= 2e-5, name
 
 
 @pytest.mark.parametrize("V,h,w", [(2, 96, 128), (4, 48, 64)])
 def test_fold_vs_oracle_and_gradients(hip_device, V, h, w):
+    """Training path: outputs vs the oracle, and the gradients of EVERY differentiable input (latents, coords,
+    densities, weight embeddings, depths) and of the 12 GRU parameters, with cotangents on all four outputs,
+    against (i) the oracle's CPU autograd and (ii) the torch-op formulation on the same device."""
     from oracle import ptf_oracle as po
     from freesplat_amd.ptf import PixelwiseTripletFusion
     E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=40 + V)
     torch.manual_seed(9)
     m = PixelwiseTripletFusion()
-    params = {k: v.detach().clone() for k, v in m.gru.state_dict().items()}
-    # oracle with autograd (CPU)
-    lat_c, dens_c = lat.clone().requires_grad_(True), dens.clone().requires_grad_(True)
-    ref = po.fuse_gaussians(params, lat_c, coords, dens_c, wts, depths, E[None], Kn[None], (h, w))
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in m.gru.state_dict().items()}
+    names = ("latents", "coords", "densities", "weights", "depths")
+    cpu_in = [t.clone().requires_grad_(True) for t in (lat, coords, dens, wts, depths)]
+    ref = po.fuse_gaussians(params, cpu_in[0], cpu_in[1], cpu_in[2], cpu_in[3], cpu_in[4], E[None], Kn[None], (h, w))
+    gen = torch.Generator().manual_seed(1)
+    cot = [torch.randn(r.shape, generator=gen) for r in ref]
+    sum((r * c).sum() for r, c in zip(ref, cot)).backward()
     m = m.to(hip_device)
     d = lambda t: t.to(hip_device)
-    lat_g, dens_g = d(lat).requires_grad_(True), d(dens).requires_grad_(True)
-    out = m.fuse_gaussians([lat_g], [d(coords)], dens_g, d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))
+
+    def run(fn):
+        ins = [d(t).requires_grad_(True) for t in (lat, coords, dens, wts, depths)]
+        for q in m.gru.parameters():
+            q.grad = None
+        out = fn([ins[0]], [ins[1]], ins[2], ins[3], ins[4], d(E)[None], d(Kn)[None], (h, w))
+        sum((o * d(c)).sum() for o, c in zip(out, cot)).backward()
+        return out, [t.grad for t in ins], {k: q.grad.clone() for k, q in m.gru.named_parameters()}
+
+    out, gin, gpar = run(m.fuse_gaussians)
     assert out[0].shape == ref[0].shape and out[0].shape[1] < V * h * w   # something fused
     for a, b, name in zip(out, ref, ("latent", "xyz", "extrinsics", "depths")):
         assert (a.detach().cpu() - b.detach()).abs().max().item() <= 1e-4, name
-    wgt = torch.randn(ref[0].shape, generator=torch.Generator().manual_seed(1))
-    (ref[0] * wgt).sum().backward()
-    (out[0] * wgt.to(hip_device)).sum().backward()
-    for a, b, name in ((lat_g.grad, lat_c.grad, "d latents"), (dens_g.grad, dens_c.grad, "d densities")):
-        s = b.abs().max().item() + 1e-20
-        assert (a.cpu() - b).abs().max().item() / s < 1e-3, name
+    out_t, gin_t, gpar_t = run(m.fuse_gaussians_torch)
+    rel = lambda a, b: (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
+    for a, t, c, name in zip(gin, gin_t, cpu_in, names):
+        assert a is not None and a.shape == c.grad.shape, name
+        assert rel(a.cpu(), c.grad) < 1e-3, f"d {name} vs oracle autograd: {rel(a.cpu(), c.grad)}"
+        assert rel(a, t) < 1e-3, f"d {name} vs torch-op path: {rel(a, t)}"
+    for k in gpar:
+        assert rel(gpar[k].cpu(), params[k].grad) < 2e-3, f"d gru.{k} vs oracle autograd: {rel(gpar[k].cpu(), params[k].grad)}"
+        assert rel(gpar[k], gpar_t[k]) < 2e-3, f"d gru.{k} vs torch-op path"
+
+
+def test_fold_backward_with_tied_winners(hip_device):
+    """ptf_tie.npz (an exact z tie: two Gaussians fuse with the SAME pixel): the view-side gradients accumulate over
+    both fused rows (float atomics), as autograd's index_select backward does."""
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    g, gru = _load("ptf_tie.npz")
+    m = PixelwiseTripletFusion()
+    m.gru.load_state_dict(gru, strict=True)
+    m = m.to(hip_device)
+    d = lambda t: t.to(hip_device)
+    res = []
+    for fn in (m.fuse_gaussians, m.fuse_gaussians_torch):
+        ins = [d(g[k]).clone().requires_grad_(True) for k in ("latents", "coords", "densities", "weights", "depths")]
+        out = fn([ins[0]], [ins[1]], ins[2], ins[3], ins[4], d(g["extrinsics"])[None], d(g["intrinsics"])[None],
+                 (int(g["h"]), int(g["w"])))
+        gen = torch.Generator().manual_seed(4)
+        sum((o * d(torch.randn(o.shape, generator=gen))).sum() for o in out).backward()
+        res.append([t.grad for t in ins])
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-20)
