@@ -53,6 +53,14 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
         ms, cnt = _lib.profile_collect()["cost_volume"]
     flops = V * h4 * w4 * D * (480 * K + 5248)
     kern = ms / max(cnt, 1) * 1e-3
+    # training step of the volume: forward + backward w.r.t. both feature maps and the six MLP tensors
+    ga = {k: (v.clone().requires_grad_(True) if k in ("cur_feats", "src_feats") else v) for k, v in args.items()}
+
+    def train_step():
+        o = mg(**ga)
+        o.backward(torch.ones_like(o))
+    dt_train = timed(train_step, max(2, steps // 4), 1)
+    ws_bwd = _lib.lib().fs_cost_volume_backward_workspace_bytes(V, K, C, h4, w4, D)
     extra = {}
     if cpu:
         nv = V if cpu_views is None else min(V, cpu_views)
@@ -73,6 +81,9 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
     return dict({"metric": f"cost-volume views/sec @ {h4}x{w4} match res, D={D}, K={K}", "value": V / dt, "unit": "views/s",
             "ms_per_call": dt * 1e3, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cv_native", "views": V, "sources": K, "channels": C},
+            "train_fwd_bwd": {"ms": dt_train * 1e3, "backward_workspace_bytes": int(ws_bwd),
+                              "what": "forward + backward (features and all six MLP tensors; weight gradients accumulated "
+                                      "on the matrix cores in the kernel: workspace independent of the plane count)"},
             "roofline": {"bound": "mfma", "kernel": "cost_volume (relayout + sweep)", "achieved": flops / kern / 1e12,
                          "peak": 157.3, "unit": "TFLOP/s", "frac": flops / kern / 1e12 / 157.3,
                          "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern * 1e3, "launches": cnt,

@@ -55,7 +55,7 @@ SIGNATURES = {
     "fs_cost_volume_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
     "fs_cost_volume_forward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 9),
     "fs_cost_volume_backward_workspace_bytes": (C.c_size_t, [C.c_int32] * 6),
-    "fs_cost_volume_backward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 15),
+    "fs_cost_volume_backward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 16),
     "fs_unproject_forward": (C.c_int, [C.c_int32] * 3 + [_VP] * 5),
     "fs_unproject_backward": (C.c_int, [C.c_int32] * 3 + [_VP] * 5),
     "fs_gaussian_head_forward": (C.c_int, [C.c_int64] + [_VP] * 4 + [C.c_int64, _VP, C.c_float, C.c_float] + [_VP] * 5),

@@ -77,33 +77,19 @@ class _CostVolumeFn(torch.autograd.Function):
         D, strides = ctx.D, ctx.strides
         dev = g.device
         L = _lib.lib()
-        pts = B * D * h * w
         ws = torch.empty(L.fs_cost_volume_backward_workspace_bytes(B, K, C, h, w, D), dtype=torch.uint8, device=dev)
         d_cur, d_src = torch.empty_like(cur_feats), torch.empty_like(src_feats)
-        DZ1 = torch.empty(pts, 32, device=dev)
-        XP = torch.empty(pts, C + 2, device=dev)
-        DZ2 = torch.empty(pts, 32, device=dev)
-        H1 = torch.empty(pts, 32, device=dev)
-        d_w3 = torch.empty(1, 32, device=dev)
-        d_b3 = torch.empty(1, device=dev)
+        e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        d_w1, d_b1, d_w2, d_b2, d_w3, d_b3 = e(32, C + 1), e(32), e(32, 32), e(32), e(1, 32), e(1)
         p = _lib.ptr
+        g_ = g.contiguous()
         _lib.check(L.fs_cost_volume_backward(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
                                              p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
                                              p(w1.detach()), p(b1.detach()), p(w2.detach()), p(b2.detach()),
-                                             p(w3.detach()), p(g.contiguous()), p(ws), p(d_cur), p(d_src), p(DZ1),
-                                             p(XP), p(DZ2), p(H1), p(d_w3), p(d_b3), _lib.current_stream()),
+                                             p(w3.detach()), p(g_), p(ws), p(d_cur), p(d_src), p(d_w1), p(d_b1),
+                                             p(d_w2), p(d_b2), p(d_w3), p(d_b3), _lib.current_stream()),
                    "fs_cost_volume_backward")
-        # weight gradients = sums of outer products over all points: four plain GEMMs / reductions
-        HC = C // 2
-        dW1p = DZ1.t() @ XP                                        # [32, 2*(HC+1)], columns [parity][slot]
-        dW1p = dW1p.view(32, 2, HC + 1)
-        d_w1 = torch.empty(32, C + 1, device=dev)
-        d_w1[:, 0:C:2] = dW1p[:, 0, :HC]
-        d_w1[:, 1:C:2] = dW1p[:, 1, :HC]
-        d_w1[:, C] = dW1p[:, 0, HC]
-        d_b1 = dW1p[:, 1, HC].contiguous()
-        d_w2 = DZ2.t() @ H1
-        d_b2 = DZ2.sum(0)
+        # (every gradient, the MLP's included, comes out of the one kernel: no per-point workspace, no GEMMs here)
         return d_cur, d_src, None, None, None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
 
 

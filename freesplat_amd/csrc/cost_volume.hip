@@ -211,9 +211,13 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
 //   exactly the channels it owns (2 x 16 MFMA) -- again no cross-lane traffic;
 //   d warped_k = valid_k/cnt * df + m_k/cnt * ddot * cur   -> scattered to the source maps with
 //   float atomics through the same 4 bilinear taps;  d cur += m_k/cnt * ddot * warped_k.
-// The MLP's weight gradients are sums of outer products over ALL (pixel, plane) points; the kernel
-// writes the per-point factors (dz1, permuted x, dz2, h1) to HBM and the host finishes them with
-// four plain GEMMs (rocBLAS) -- 584 B/point, 1.8 GB at the native 96x128x128x2 (HBM is 288 GB).
+// The MLP's weight gradients are sums of outer products over ALL (pixel, plane) points,
+//   dW1 = sum_pt dz1[pt] (x) x[pt],   dW2 = sum_pt dz2[pt] (x) h1[pt],   db = sum_pt dz,
+// i.e. GEMMs whose contraction index is the point -- which in this kernel's layout runs along the LANES.  Per plane
+// the wavefront transposes its 32 points' factors through a private LDS tile (padded rows: conflict-free both ways)
+// and accumulates the products with 48 more MFMAs into 48 registers that live across the plane loop; the workgroup's
+// four wavefronts are summed in LDS and leave as one atomic per weight and workgroup.  (The first version wrote the
+// factors to HBM for rocBLAS: 584 B per point -- 1.8 GB per call at the native size, 17.6 GB at config 3's.)
 // ==========================================================================================
 __global__ __launch_bounds__(256) void cv_relayout_back_kernel(const float* __restrict__ srcT,
                                                                float* __restrict__ dst, int C, int hw,
@@ -297,12 +301,16 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
     const float* __restrict__ g_out, float* __restrict__ d_curT, float* __restrict__ d_srcT,
-    float* __restrict__ DZ1, float* __restrict__ XP, float* __restrict__ DZ2, float* __restrict__ H1,
+    float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
     float* __restrict__ gw3, float* __restrict__ gb3)
 {
     constexpr int C = 2 * HC;
     constexpr int NBLK = (HC + 1 + 15) / 16;  // row blocks of the permuted W1^T
-    constexpr int XW = 2 * (HC + 1);          // row width of XP
+    constexpr int XW = 2 * (HC + 1);          // features of a point: C channels, dot, 1
+    // wavefront-private LDS tile: [32 points][row] with odd row strides (33 / XS)
+    constexpr int XS = XW | 1, kTile1 = 32 * 33, kTileX = 32 * XS, kStage = 3 * kTile1 + kTileX;
+    constexpr int NCB = (XW + 31) / 32;       // column blocks of dW1
+    __shared__ float s_stage[4 * kStage];
     const int hw = h * w;
     const int groups = (hw + 31) / 32;
     const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
@@ -355,10 +363,17 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
     const int dchunk = (D + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4);
     const int d0 = min(D, ((int)blockIdx.y * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
-    float gw3r[16];
+    float gw3r[16], gb2r[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gw3r[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { gw3r[r] = 0.0f; gb2r[r] = 0.0f; }
     float gb3r = 0.0f;
+    f32x16 gW2, gW1[NCB];   // dW2[unit acc_row(r,hf)][col p],  dW1[unit acc_row(r,hf)][feature 32 cb + p]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        gW2[r] = 0.0f;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) gW1[cb][r] = 0.0f;
+    }
     SrcWarp<HC> W;
 
     for (int d = d0; d < d1; ++d) {
@@ -427,20 +442,35 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
             }
         }
         ddot = __shfl(ddot, p, 64);  // both parities of the pixel need it
-        // ---- per-point factors of the weight gradients ----
-        if (live) {
+        // ---- weight gradients: transpose this plane's factors through LDS, accumulate the outer products ----
+        {
+            float* tz1 = s_stage + wave * kStage, *tz2 = tz1 + kTile1, *th1 = tz2 + kTile1, *tx = th1 + kTile1;
+            const float lv = live ? 1.0f : 0.0f;   // points past the image contribute nothing
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const size_t o = pt * 32 + 8 * g4 + 4 * hf;  // accumulator rows 8g+4hf .. +3 are contiguous
-                *(float4*)(DZ1 + o) = make_float4(dz1[4 * g4], dz1[4 * g4 + 1], dz1[4 * g4 + 2], dz1[4 * g4 + 3]);
-                *(float4*)(DZ2 + o) = make_float4(dz2[4 * g4], dz2[4 * g4 + 1], dz2[4 * g4 + 2], dz2[4 * g4 + 3]);
-                *(float4*)(H1 + o) = make_float4(lrelu(z1[4 * g4]), lrelu(z1[4 * g4 + 1]), lrelu(z1[4 * g4 + 2]),
-                                                 lrelu(z1[4 * g4 + 3]));
+            for (int r = 0; r < 16; ++r) {
+                const int u = acc_row(r, hf);
+                tz1[p * 33 + u] = dz1[r] * lv;
+                tz2[p * 33 + u] = dz2[r] * lv;
+                th1[p * 33 + u] = lrelu(z1[r]);
+                gb2r[r] += dz2[r] * lv;
             }
-            float* xp = XP + pt * XW + (size_t)hf * (HC + 1);
 #pragma unroll
-            for (int s = 0; s < HC; ++s) xp[s] = favg[s] * inv;
-            xp[HC] = xlast;
+            for (int s = 0; s < HC; ++s) tx[p * XS + 2 * s + hf] = favg[s] * inv;
+            tx[p * XS + C + hf] = xlast;
+            wave_lds_sync();
+            // k-step m contracts points 2m and 2m+1: A = dz[pt][unit = lane&31], B = x / h1 [pt][column = lane&31]
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int pt = 2 * m + hf;
+                const float az1 = tz1[pt * 33 + p], az2 = tz2[pt * 33 + p];
+                gW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(az2, th1[pt * 33 + p], gW2, 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const float bx = (32 * cb + p < XW) ? tx[pt * XS + 32 * cb + p] : 0.0f;
+                    gW1[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(az1, bx, gW1[cb], 0, 0, 0);
+                }
+            }
+            wave_lds_sync();   // (the next plane overwrites the tile)
         }
         // ---- back to the features ----
         for (int k = 0; k < K; ++k) {
@@ -486,6 +516,38 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
         for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
         if (lane == 0) atomicAdd(gb3, v);
     }
+    // b2: sum over the 32 pixels of each half
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = gb2r[r];
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+        if (p == 0) atomicAdd(&gb2[acc_row(r, hf)], v);
+    }
+    // W1 (+ b1 = its "1" column) and W2: sum the workgroup's four wavefronts in LDS, one atomic per weight
+    __syncthreads();
+    {
+        float* mine = s_stage + wave * kStage;          // (1 + NCB) * 16 * 64 floats <= kStage
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mine[r * 64 + lane] = gW2[r];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) mine[(16 * (1 + cb) + r) * 64 + lane] = gW1[cb][r];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (1 + NCB) * 16 * 64; e += 256) {
+        const float v = s_stage[e] + s_stage[kStage + e] + s_stage[2 * kStage + e] + s_stage[3 * kStage + e];
+        const int blk = e >> 10, r = (e >> 6) & 15, l = e & 63;
+        const int unit = acc_row(r, l >> 5), col = l & 31;
+        if (blk == 0) {
+            atomicAdd(&gw2[unit * 32 + col], v);
+        } else {
+            const int f = 32 * (blk - 1) + col;        // feature: channels 0..C-1, dot, 1
+            if (f <= C) atomicAdd(&gw1[unit * (C + 1) + f], v);
+            else if (f == C + 1) atomicAdd(&gb1[unit], v);
+        }
+    }
 }
 
 }  // namespace fs
@@ -498,6 +560,15 @@ static int cv_plane_split(int B, int groups, int D)
 {
     int split = 1;
     while (split * 4 * 4 < D && (long long)B * groups * 4 * split < 12288) split *= 2;
+    return split;
+}
+
+// Backward: one wavefront per SIMD (registers) and every workgroup ends with 3 k weight atomics, so only as many plane
+// slices as it takes to give each of the chip's 256 CUs a few workgroups.
+static int cv_bwd_plane_split(int B, int groups, int D)
+{
+    int split = 1;
+    while (split * 4 * 8 < D && (long long)B * groups * split < 1024) split *= 2;
     return split;
 }
 
@@ -566,12 +637,12 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
                                    int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
                                    const float* b1, const float* w2, const float* b2, const float* w3,
                                    const float* grad_out, void* workspace, float* d_cur_feats,
-                                   float* d_src_feats, float* DZ1, float* XP, float* DZ2, float* H1,
+                                   float* d_src_feats, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
                                    float* d_w3, float* d_b3, void* stream_)
 {
     if (B <= 0 || K <= 0 || h <= 0 || w <= 0 || D <= 0) return FS_ERR_INVALID_ARG;
     if (!cur_feats || !src_feats || !src_extrinsics || !src_Ks || !cur_invK || !planes || !w1 || !b1 || !w2 ||
-        !b2 || !w3 || !grad_out || !workspace || !d_cur_feats || !d_src_feats || !DZ1 || !XP || !DZ2 || !H1 ||
+        !b2 || !w3 || !grad_out || !workspace || !d_cur_feats || !d_src_feats || !d_w1 || !d_b1 || !d_w2 || !d_b2 ||
         !d_w3 || !d_b3)
         return FS_ERR_INVALID_ARG;
     if (C != 48 && C != 16) return FS_ERR_UNSUPPORTED;
@@ -586,6 +657,10 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
     ScopedStage prof_(kStCostVolume, st);
     hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics, Pmat);
     if (hipMemsetAsync(d_curT, 0, (n_cur + n_src) * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_w1, 0, 32 * (size_t)(C + 1) * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_b1, 0, 32 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_w2, 0, 32 * 32 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_b2, 0, 32 * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(d_w3, 0, 32 * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(d_b3, 0, sizeof(float), st) != hipSuccess) {
         set_last_error("cost volume backward memset", hipGetLastError());
@@ -596,15 +671,15 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
     hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_src), dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
     const int groups = (hw + 31) / 32;
     if (C == 48)
-        hipLaunchKernelGGL(cost_volume_bwd_kernel<24>, dim3(B * groups, cv_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
+        hipLaunchKernelGGL(cost_volume_bwd_kernel<24>, dim3(B * groups, cv_bwd_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
-                           d_curT, d_srcT, DZ1, XP, DZ2, H1, d_w3, d_b3);
+                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3);
     else
-        hipLaunchKernelGGL(cost_volume_bwd_kernel<8>, dim3(B * groups, cv_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
+        hipLaunchKernelGGL(cost_volume_bwd_kernel<8>, dim3(B * groups, cv_bwd_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
-                           d_curT, d_srcT, DZ1, XP, DZ2, H1, d_w3, d_b3);
+                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3);
     hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_cur), dim3(256), 0, st, d_curT, d_cur_feats, C, hw, B);
     hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_src), dim3(256), 0, st, d_srcT, d_src_feats, C, hw, B * K);
     FS_CHECK_LAUNCH("cost_volume_backward");

@@ -184,12 +184,11 @@ size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int32_t C, 
 
 /*
  * Backward of fs_cost_volume_forward w.r.t. the features and the MLP.  grad_out[B,D,h,w] ->
- * d_cur_feats[B,C,h,w], d_src_feats[B,K,C,h,w] (overwritten), d_w3[32], d_b3[1], and the per-point
- * factors of the remaining weight gradients, one row per (b, d, pixel) point, pts = B*D*h*w:
- *   DZ1[pts,32], XP[pts,C+2] (layer-1 input, columns ordered [parity][slot]: column p*(C/2+1)+s is
- *   channel 2s+p for s < C/2, column C/2 of parity 0 is the dot feature, of parity 1 the constant 1),
- *   DZ2[pts,32], H1[pts,32]  =>  dW1 = DZ1^T XP (un-permute the columns; the constant-1 column is db1),
- *   dW2 = DZ2^T H1, db2 = column sums of DZ2 -- plain GEMMs the caller runs (rocBLAS).
+ * d_cur_feats[B,C,h,w], d_src_feats[B,K,C,h,w] and ALL six parameter gradients d_w1[32,C+1], d_b1[32],
+ * d_w2[32,32], d_b2[32], d_w3[32], d_b3[1] (everything overwritten).  The weight gradients -- sums of outer products
+ * over all B*D*h*w points -- are accumulated on the matrix cores inside the kernel; the workspace
+ * (fs_cost_volume_backward_workspace_bytes: pixel-major copies of the feature maps and of their gradients) does not
+ * depend on D.
  */
 int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
                             const float* cur_feats, const float* src_feats,
@@ -197,8 +196,8 @@ int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
                             const float* planes, int64_t plane_stride_b, int64_t plane_stride_d,
                             int64_t plane_stride_pix, const float* w1, const float* b1,
                             const float* w2, const float* b2, const float* w3, const float* grad_out,
-                            void* workspace, float* d_cur_feats, float* d_src_feats, float* DZ1,
-                            float* XP, float* DZ2, float* H1, float* d_w3, float* d_b3, void* stream);
+                            void* workspace, float* d_cur_feats, float* d_src_feats, float* d_w1,
+                            float* d_b1, float* d_w2, float* d_b2, float* d_w3, float* d_b3, void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * Pixel-wise Triplet Fusion: matching step                                              *
