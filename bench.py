@@ -187,6 +187,29 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         _lib.profile_enable(False)
         _R.NUM_STREAMS = streams
         breakdown = _lib.profile_collect()
+    graph_views_per_s = None
+    if world == 1 and not train:
+        # the same step recorded once into a hipGraph (the C ABI never allocates or syncs: framing + 5 kernels per view
+        # over two forked streams capture as they are) and replayed: what is left when the host-side launch train is
+        # taken out of the loop
+        from freesplat_amd import decoder as _D
+        with torch.no_grad():
+            cap = torch.cuda.Stream(device=dev)
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(cap):
+                with torch.cuda.graph(graph, stream=cap):
+                    gc_color, gc_depth = step()
+            _D._pending_checks.clear()
+            graph.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            graph_views_per_s = n_total_views * steps / (time.perf_counter() - t1)
+            graph_ok = bool(torch.equal(gc_color, color))
+            del graph
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -211,6 +234,9 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                    "parallelism": f"view-sharded x{world}" + (f" + {args.grad_exchange}(gaussian grads)" if exchange else
                                                               " + all_gather(color,depth)" if gather else "")},
     }
+    if graph_views_per_s is not None:
+        out["hipgraph_replay"] = {"value": graph_views_per_s, "unit": "views/s", "same_image_as_eager": graph_ok,
+                                  "what": "one step captured into a hipGraph, replayed `steps` times"}
     if stages:
         ms, cnt = stages.get(dominant, (0.0, 0))
         per = ms / max(cnt, 1) * 1e-3
