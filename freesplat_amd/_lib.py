@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libfreesplat_hip.so")
+# FREESPLAT_LIB: an alternative build of the same library (A/B measurements of kernel variants inside one GPU session)
+LIB_PATH = os.environ.get("FREESPLAT_LIB") or os.path.join(_PKG, "libfreesplat_hip.so")
 _lib = None
 
 

@@ -27,6 +27,24 @@ namespace fs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- in-kernel phase timing of the sweep (debug builds: make EXTRA=-DFS_CV_TRACE; profiles/cv_phase_trace.py) ----
+// Per wavefront: shader cycles (s_memtime) between the top of a plane iteration and the point where the averaged
+// features are final (gather: depth, projection, taps, reduction), and from there to the plane's output value
+// (the two MFMA layers + glue), summed over the wavefront's planes.
+#ifdef FS_CV_TRACE
+constexpr int kCvTraceWaves = 16384;
+__device__ unsigned long long g_cv_trace[kCvTraceWaves * 4];
+__device__ __forceinline__ unsigned long long cv_stamp(float dep)
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+    return t;
+}
+#define FS_CV_T(var, dep) const unsigned long long var = cv_stamp(dep)
+#else
+#define FS_CV_T(var, dep) do {} while (0)
+#endif
+
 // ---- feature re-layout: [C,h,w] -> [h*w][2][C/2]  (channel c -> parity c&1, slot c>>1) --------
 __global__ __launch_bounds__(256) void cv_relayout_kernel(const float* __restrict__ src,
                                                           float* __restrict__ dst, int C, int hw,
@@ -116,14 +134,32 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
     const int dchunk = (D + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4);
     const int d0 = min(D, ((int)blockIdx.y * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
 
+    // Per plane the sweep used to pay three dependent memory round trips before its first MFMA: the plane's depth,
+    // the projection rows (scalar loads), then the taps.  The depth is now fetched one plane ahead and the projection
+    // rows of the first two sources stay in SGPRs for the whole sweep (the shipped configs have K <= 2 except the
+    // 9-nearest selection of config 4).
+    const float* pl = planes + b * ps_b + (live ? pix : 0) * ps_p;
+    float depth_next = d0 < d1 ? pl[d0 * ps_d] : 0.0f;
+    float P0[12], P1[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        P0[e] = Pmat[((size_t)b * K) * 12 + e];
+        P1[e] = K > 1 ? Pmat[((size_t)b * K + 1) * 12 + e] : 0.0f;
+    }
+#ifdef FS_CV_TRACE
+    unsigned long long tr_g = 0, tr_m = 0;
+    const unsigned long long tr_c0 = cv_stamp(rx), tr_w0 = wall_clock64();
+#endif
     for (int d = d0; d < d1; ++d) {
-        const float depth = planes[b * ps_b + d * ps_d + (live ? pix : 0) * ps_p];
+        FS_CV_T(t_top, rx);
+        const float depth = depth_next;
+        depth_next = pl[min(d + 1, d1 - 1) * ps_d];
         float favg[HC];
 #pragma unroll
         for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
         float dot_sum = 0.0f, cnt = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const float* P = Pmat + ((size_t)b * K + k) * 12;  // wave-uniform: scalar loads
+        auto one_source = [&](int k, const float* P) __attribute__((always_inline)) {
+
             // world point = depth * r (homogeneous 1): geometry_utils.py:56-58
             const float X = depth * rx, Y = depth * ry, Z = depth * rz;
             const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
@@ -176,8 +212,13 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
 #pragma unroll
                 for (int s = 0; s < HC; ++s) favg[s] += wv[s];
             }
-        }
+        
+        };
+        one_source(0, P0);
+        if (K > 1) one_source(1, P1);
+        for (int k = 2; k < K; ++k) one_source(k, Pmat + ((size_t)b * K + k) * 12);
         const float inv = 1.0f / (cnt + 1e-8f);                          // :595-598
+        FS_CV_T(t_gath, favg[0] + favg[HC - 1] + inv + dot_sum);
         // ---- layer 1: H1^T = W1 [f; dot; 1]^T  (K dimension = C + 2, two features per MFMA) ----
         f32x16 acc;
 #pragma unroll
@@ -199,7 +240,23 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
         for (int r = 0; r < 16; ++r) o += w3r[r] * lrelu(acc2[r]);
         o += __shfl_xor(o, 32, 64);
         if (live && hf == 0) out[((size_t)b * D + d) * hw + pix] = o + b3v;
+#ifdef FS_CV_TRACE
+        FS_CV_T(t_end, o);
+        tr_g += t_gath - t_top;
+        tr_m += t_end - t_gath;
+#endif
     }
+#ifdef FS_CV_TRACE
+    {
+        const int wid = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+        if (lane == 0 && wid < kCvTraceWaves) {
+            g_cv_trace[4 * wid] = tr_g; g_cv_trace[4 * wid + 1] = tr_m;
+            // [3]: shader ticks (s_memtime) << 32 | 100 MHz wall ticks of this wavefront's whole sweep -> effective clock
+            const unsigned long long dc = cv_stamp(rx) - tr_c0, dw = wall_clock64() - tr_w0;
+            g_cv_trace[4 * wid + 2] = (unsigned long long)(d1 - d0); g_cv_trace[4 * wid + 3] = (dc << 32) | (dw & 0xffffffffull);
+        }
+    }
+#endif
 }
 
 
@@ -551,6 +608,15 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
 }
 
 }  // namespace fs
+
+#ifdef FS_CV_TRACE
+extern "C" __attribute__((visibility("default"))) int fs_debug_cv_trace(unsigned long long* dst, int reset)
+{
+    static unsigned long long z[fs::kCvTraceWaves * 4];
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(fs::g_cv_trace), z, sizeof(z));
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fs::g_cv_trace), sizeof(z));
+}
+#endif
 
 using namespace fs;
 

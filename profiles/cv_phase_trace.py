@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Where a wavefront of the cost-volume sweep spends its time (debug build of the library with -DFS_CV_TRACE:
+  make -C freesplat_amd/csrc clean && make -C freesplat_amd/csrc EXTRA=-DFS_CV_TRACE
+or a separate .so selected with FREESPLAT_LIB).  Prints mean shader cycles per (32-pixel group, plane) in the gather
+phase (plane depth -> projection -> bilinear taps -> reduction) and in the MLP phase (41 MFMAs + glue)."""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.getcwd(), "tests", "golden"))
+import numpy as np
+import torch
+
+import inputs
+from freesplat_amd import _lib
+from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+
+
+def main(V=2, K=1, h4=96, w4=128, D=128):
+    dev = torch.device("cuda:0")
+    L = C.CDLL(_lib.LIB_PATH)
+    n = 16384 * 4
+    buf = (C.c_ulonglong * n)()
+    torch.manual_seed(0)
+    m = AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=48).to(dev)
+    kw = {k: v.to(dev) for k, v in inputs.cv_inputs(V, K, h4, w4, 48, seed=1).items()}
+    with torch.no_grad():
+        for _ in range(3):
+            m(**kw)
+        torch.cuda.synchronize()
+        L.fs_debug_cv_trace(buf, 1)
+        m(**kw)
+        torch.cuda.synchronize()
+        L.fs_debug_cv_trace(buf, 0)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).astype(np.float64)
+    raw = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)
+    raw = raw[raw[:, 3] > 0]
+    a = a[a[:, 3] > 0]
+    planes = a[:, 2].sum()
+    ticks, wall = (raw[:, 3] >> np.uint64(32)).astype(np.float64), (raw[:, 3] & np.uint64(0xffffffff)).astype(np.float64)
+    out = {"config": f"V={V} K={K} {h4}x{w4} D={D}", "wavefronts": int(len(a)), "planes_per_wavefront": float(a[:, 2].mean()),
+           "gather_cycles_per_plane": float(a[:, 0].sum() / planes), "mlp_cycles_per_plane": float(a[:, 1].sum() / planes),
+           "mfma_cycles_per_plane": 41 * 64,
+           "s_memtime_ticks_per_us": float(ticks.sum() / (wall.sum() / 100.0)),
+           "mean_wavefront_us": float(wall.mean() / 100.0)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
+    main(V=3, K=2, h4=242, w4=324)
