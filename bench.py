@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph capture / replay measurement")
     return ap.parse_args()
 
 
@@ -188,7 +189,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         _R.NUM_STREAMS = streams
         breakdown = _lib.profile_collect()
     graph_views_per_s = None
-    if world == 1 and not train:
+    if world == 1 and not train and not args.no_graph:
         # the same step recorded once into a hipGraph (the C ABI never allocates or syncs: framing + 5 kernels per view
         # over two forked streams capture as they are) and replayed: what is left when the host-side launch train is
         # taken out of the loop

@@ -37,12 +37,14 @@ def main(src, tag, cmd):
     json.dump({"command": cmd, "note": "read_bytes = 2 * FETCH_SIZE * 1024 (gfx950 correction), "
                "write_bytes = WRITE_SIZE * 1024; separate --pmc passes", "kernels": out},
               open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
+    sq = sq_summary(src)
+    if sq:
+        json.dump(sq, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
     print(open(f"profiles/{tag}_kernel_stats.csv").read())
-    print(json.dumps(out, indent=1))
-
-
-if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3])
+    print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in out.items()}), "MB per launch")
+    if sq:
+        print(json.dumps({k: {c: round(v.get(c, 0) / 1e6, 2) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
+                          for k, v in sq.items()}), "M wave-instructions per launch")
 
 
 def sq_summary(src):
@@ -60,3 +62,7 @@ def sq_summary(src):
         for (k, c), v in agg.items():
             out[k][c] = sum(v) / len(v)
     return out
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])
