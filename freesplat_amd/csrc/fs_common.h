@@ -111,6 +111,29 @@ __device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
     return __builtin_bit_cast(f32x2, e);
 }
 
+// The same exp for the NEGATED argument q = -x >= 0 (the blend loops carry -power so that "0 >= power >= skip threshold"
+// is ONE unsigned compare of the bit patterns): every product / sum below is the exact negation of its counterpart
+// above, so the result has the same bits as fs_exp2_nonpos(-q).
+__device__ __forceinline__ f32x2 fs_exp2_of_neg(f32x2 q)
+{
+    const f32x2 magic = splat2(12582912.0f);
+    const f32x2 t = magic - q * splat2(1.44269504088896341f);
+    const f32x2 n = t - magic;
+    f32x2 r = fma2(n, splat2(-0.693145751953125f), -q);
+    r = fma2(n, splat2(-1.42860676533018e-6f), r);
+    f32x2 p = fma2(r, splat2(1.0f / 720.0f), splat2(1.0f / 120.0f));
+    p = fma2(r, p, splat2(1.0f / 24.0f));
+    p = fma2(r, p, splat2(1.0f / 6.0f));
+    p = fma2(r, p, splat2(0.5f));
+    p = fma2(r, p, splat2(1.0f));
+    p = fma2(r, p, splat2(1.0f));
+    const i32x2 e = __builtin_bit_cast(i32x2, p) + (__builtin_bit_cast(i32x2, t) << 23);
+    return __builtin_bit_cast(f32x2, e);
+}
+// Skip threshold of a record (r1.z: power below it cannot reach alpha >= 1/255) as the bit pattern the unsigned compare
+// uses: -threshold for a negative threshold; 0 otherwise (opacity <= 1/255: only q == +0 passes, and fails the alpha test).
+__device__ __forceinline__ float skip_bits(float thr) { return thr < 0.0f ? -thr : 0.0f; }
+
 // ---- camera transforms: torch hands the matrices over transposed => column-major here -------
 __device__ __forceinline__ float3 xform43(const float* __restrict__ m, float3 p)
 {

@@ -144,15 +144,16 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
         if (hit) {
             const int k = __popcll(hits & ~((2ull << lane) - 1ull));  // survivors above this lane: back to front
             float* d = (float*)(cp + (k >> 1) * kBwdQuads) + (k & 1);
+            // (coefficients negated, threshold as unsigned-compare bits: see the forward's compaction)
             d[0] = a0.x; d[2] = a0.y;                    // [x_a x_b y_a y_b]
-            d[4] = a0.z; d[6] = a0.w;                    // [A_a A_b C_a C_b]   (A = -a/2, C = -c/2)
-            d[8] = a1.x; d[10] = a1.z;                   // [B_a B_b thr_a thr_b] (B = -b)
+            d[4] = -a0.z; d[6] = -a0.w;                  // [A_a A_b C_a C_b]   (A = a/2, C = c/2)
+            d[8] = -a1.x; d[10] = skip_bits(a1.z);       // [B_a B_b thr_a thr_b] (B = b; thr = bits of -threshold)
             d[12] = a1.y; d[14] = __int_as_float((bi << 6) + lane + 1);  // [op_a op_b pos_a pos_b]
             cp[(k >> 1) * kBwdQuads + 4 + (k & 1)] = make_float4(a2.x, a2.y, a2.z, a1.w);  // [r g b depth]
             d[24] = __uint_as_float(w_this >> 4);        // [id_a id_b . .]
             if (k == cnt - 1 && !(k & 1)) {
                 // odd count: the unused half of the last slot must hold finite numbers (it enters with weight 0)
-                d[1] = 0.0f; d[3] = 0.0f; d[5] = 0.0f; d[7] = 0.0f; d[9] = 0.0f; d[11] = 1.0f; d[13] = 0.0f;
+                d[1] = 0.0f; d[3] = 0.0f; d[5] = 0.0f; d[7] = 0.0f; d[9] = 0.0f; d[11] = 0.0f; d[13] = 0.0f;
                 d[15] = __int_as_float(0x7fffffff);
                 cp[(k >> 1) * kBwdQuads + 5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 d[25] = 0.0f;
@@ -166,10 +167,12 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
             const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
             const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx,
                                   fma2((f32x2){c1.z, c1.w} * dy, dy, ((f32x2){c2.x, c2.y} * dx) * dy));
-            bool on_a = (__float_as_int(c3.z) <= last) & (pw.x <= 0.0f) & (pw.x >= c2.z);
-            bool on_b = (__float_as_int(c3.w) <= last) & (pw.y <= 0.0f) & (pw.y >= c2.w);
+            // pw = -power; +0 <= pw <= -threshold as ONE unsigned compare of the bit patterns
+            bool on_a = __float_as_int(c3.z) <= last, on_b = __float_as_int(c3.w) <= last;
+            on_a = on_a & (__float_as_uint(pw.x) <= __float_as_uint(c2.z));
+            on_b = on_b & (__float_as_uint(pw.y) <= __float_as_uint(c2.w));
             if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) continue;  // wave-uniform
-            const f32x2 Gr = fs_exp2_nonpos(pw);
+            const f32x2 Gr = fs_exp2_of_neg(pw);
             const f32x2 oe = (f32x2){c3.x, c3.y} * Gr;
             const f32x2 al_raw = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
             on_a = on_a & (al_raw.x >= 1.0f / 255.0f);
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
             const f32x2 gdx = G * dx, gdy = G * dy;
             const f32x2 A2 = (f32x2){c1.x, c1.y} + (f32x2){c1.x, c1.y}, C2 = (f32x2){c1.z, c1.w} + (f32x2){c1.z, c1.w};
             const f32x2 Bm = {c2.x, c2.y};
-            const f32x2 dGx = fma2(A2, gdx, Bm * gdy);   // dG/d(delta x) = -(a gdx + b gdy),  A = -a/2, B = -b
-            const f32x2 dGy = fma2(C2, gdy, Bm * gdx);
+            const f32x2 dGx = -fma2(A2, gdx, Bm * gdy);  // dG/d(delta x) = -(a gdx + b gdy),  A = a/2, B = b
+            const f32x2 dGy = -fma2(C2, gdy, Bm * gdx);
             const f32x2 v_mx = (dL_dG * dGx) * splat2(half_wh.x);
             const f32x2 v_my = (dL_dG * dGy) * splat2(half_wh.y);
             const f32x2 hq = dL_dG * splat2(-0.5f);

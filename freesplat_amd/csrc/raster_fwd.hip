@@ -983,9 +983,11 @@ __global__ __launch_bounds__(64) void render_kernel(
         if (hit) {
             const int k = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0));
             float* d = (float*)(cp + (k >> 1) * kPairQuads) + (k & 1);
+            // (coefficients NEGATED: the walk evaluates q = -power >= 0, bit for bit the negation of the oracle's power,
+            //  so that "0 >= power >= threshold" is one unsigned compare of q's bits against skip_bits)
             d[0] = a0.x; d[2] = a0.y;                   // [x_a x_b y_a y_b]
-            d[4] = a0.z; d[6] = a0.w;                   // [A_a A_b C_a C_b]   (A = -a/2, C = -c/2)
-            d[8] = a1.x; d[10] = a1.z;                  // [B_a B_b thr_a thr_b] (B = -b)
+            d[4] = -a0.z; d[6] = -a0.w;                 // [A_a A_b C_a C_b]   (A = a/2, C = c/2)
+            d[8] = -a1.x; d[10] = skip_bits(a1.z);      // [B_a B_b thr_a thr_b] (B = b; thr = bits of -threshold)
             d[12] = a1.y; d[14] = __int_as_float(c + lane + 1);  // [op_a op_b pos_a pos_b]
             cp[(k >> 1) * kPairQuads + 4 + (k & 1)] = make_float4(a2.x, a2.y, a2.z, a1.w);  // [r g b depth]
             // odd count: the unused half of the last slot gets weight 0; its colour must still be finite
@@ -1020,16 +1022,17 @@ __global__ __launch_bounds__(64) void render_kernel(
             const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
             const f32x2 ex = (f32x2){e0.x, e0.y} - pfx, ey = (f32x2){e0.z, e0.w} - pfy;
             const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx,
-                                  fma2((f32x2){c1.z, c1.w} * dy, dy, ((f32x2){c2.x, c2.y} * dx) * dy));
+                                  fma2((f32x2){c1.z, c1.w} * dy, dy, ((f32x2){c2.x, c2.y} * dx) * dy));   // = -power
             const f32x2 pv = fma2((f32x2){e1.x, e1.y} * ex, ex,
                                   fma2((f32x2){e1.z, e1.w} * ey, ey, ((f32x2){e2.x, e2.y} * ex) * ey));
-            const bool ca = (pw.x <= 0.0f) & (pw.x >= c2.z);
-            const bool cb = has_b & (pw.y <= 0.0f) & (pw.y >= c2.w);
-            const bool cc = has_c & (pv.x <= 0.0f) & (pv.x >= e2.z);
-            const bool cd = has_d & (pv.y <= 0.0f) & (pv.y >= e2.w);
+            // +0 <= q <= -threshold  <=>  bits(q) <= bits(-threshold) as unsigned (negative q and NaN compare above)
+            const bool ca = __float_as_uint(pw.x) <= __float_as_uint(c2.z);
+            const bool cb = has_b & (__float_as_uint(pw.y) <= __float_as_uint(c2.w));
+            const bool cc = has_c & (__float_as_uint(pv.x) <= __float_as_uint(e2.z));
+            const bool cd = has_d & (__float_as_uint(pv.y) <= __float_as_uint(e2.w));
             if (__builtin_amdgcn_ballot_w64(((ca | cb) | (cc | cd)) & !done) == 0) continue;  // wave-uniform
             const float4 ka = q[4], kb = q[5], kc = q[10], kd = q[11];
-            const f32x2 ew = fs_exp2_nonpos(pw), ev = fs_exp2_nonpos(pv);
+            const f32x2 ew = fs_exp2_of_neg(pw), ev = fs_exp2_of_neg(pv);
             const f32x2 ow = (f32x2){c3.x, c3.y} * ew, ov = (f32x2){e3.x, e3.y} * ev;
             const f32x2 aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
             const f32x2 av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
