@@ -231,6 +231,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "mode": mode, "image_hw": [H, W], "gaussians": N,
                    "sh_degree": 2, "views_per_step_per_gpu": views, "raster_streams": R_NUM_STREAMS,
+                   "blend_exp": "hardware v_exp_f32" if _R_FAST() else "contract polynomial",
                    "instances_per_view": int(n_inst),
                    "parallelism": f"view-sharded x{world}" + (f" + {args.grad_exchange}(gaussian grads)" if exchange else
                                                               " + all_gather(color,depth)" if gather else "")},
@@ -261,6 +262,11 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
     if world == 1 and cpu_baseline:
         out.update(cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=train))
     return out
+
+
+def _R_FAST() -> bool:
+    from freesplat_amd import rasterizer
+    return bool(rasterizer.FAST_EXP)
 
 
 def committed_traffic(kernel: str):
@@ -314,8 +320,12 @@ def cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=False):
     err = float(np.abs(g - st0["color"]).max())
     mse = float(((g.clip(0, 1) - st0["color"].clip(0, 1)) ** 2).mean())
     psnr = None if mse == 0 else float(-10 * np.log10(mse))
-    parity = {"max_abs_err_vs_oracle": err, "psnr_db_vs_oracle": psnr if psnr is not None else "inf",
-              "bit_exact": bool((g == st0["color"]).all())}
+    from freesplat_amd import rasterizer as _R
+    from freesplat_amd import rasterizer as _R
+    dpx = np.abs(g - st0["color"]).max(axis=0)
+    parity = {"mode": "FS_RASTER_FAST_EXP (hardware exp, opt-in)" if _R.FAST_EXP else "contract exp (default)",
+              "max_abs_err_vs_oracle": err, "pixels_above_1e-4": int((dpx > 1e-4).sum()), "pixels": H * W,
+              "psnr_db_vs_oracle": psnr if psnr is not None else "inf", "bit_exact": bool((g == st0["color"]).all())}
     if train:
         (gc * torch.from_numpy(g_color).to(dev)).sum().backward()
         rel = {}
@@ -351,6 +361,17 @@ def main():
     sections = []
     if cx.world == 1 and args.sections != "raster":
         sections = ["train", "c2", "cost_volume", "ptf"] if args.sections == "all" else args.sections.split(",")
+    if sections and args.mode == "fwd" and not _R_FAST():
+        # the opt-in hardware exp of the blend (FS_RASTER_FAST_EXP): same workload, throughput + what it costs in parity
+        from freesplat_amd import rasterizer as _R
+        _R.FAST_EXP = True
+        try:
+            fx = bench_raster(cx, args.workload, "fwd", args.views, args.steps, args.warmup, cpu)
+        finally:
+            _R.FAST_EXP = False
+        out["fast_exp"] = {k: fx[k] for k in ("value", "unit", "ms_per_step", "roofline", "kernel_ms_per_view", "parity") if k in fx}
+        out["fast_exp"]["what"] = ("rasterizer.FAST_EXP = True: hardware v_exp_f32 in the blend loops; not the default because of "
+                                   "the threshold-flip pixels counted in parity.pixels_above_1e-4")
     if "train" in sections and args.mode != "train":
         out["train"] = bench_raster(cx, args.workload, "train", min(args.views, 8), max(3, args.steps // 2), 2, cpu)
     if "c2" in sections and not args.workload.startswith("c2"):

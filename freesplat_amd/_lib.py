@@ -29,6 +29,7 @@ RASTER_TILE_CULL = 1
 RASTER_SH_FP16 = 2
 RASTER_SH_CHANNEL_MAJOR = 4
 RASTER_COV_FULL = 8
+RASTER_FAST_EXP = 16
 
 
 def build(force: bool = False) -> str:

@@ -130,6 +130,19 @@ __device__ __forceinline__ f32x2 fs_exp2_of_neg(f32x2 q)
     const i32x2 e = __builtin_bit_cast(i32x2, p) + (__builtin_bit_cast(i32x2, t) << 23);
     return __builtin_bit_cast(f32x2, e);
 }
+// exp(-q) of the blend loops: FAST = hardware v_exp_f32 (2^x, <= 1 ulp; FS_RASTER_FAST_EXP), else the contract exp.
+// On gfx950 a wave64 v_fma_f32 issues in ~2.6 cycles, v_pk_fma_f32 in ~5.2 (no packed-fp32 throughput gain on this
+// chip), v_exp_f32 in ~8.4 (profiles/tools/valu_rates.hip): contract exp = 31 cycles per value, hardware = 11.
+template <bool FAST>
+__device__ __forceinline__ f32x2 blend_exp_of_neg(f32x2 q)
+{
+    if constexpr (FAST) {
+        const f32x2 t = q * splat2(-1.44269504088896341f);
+        return (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    } else {
+        return fs_exp2_of_neg(q);
+    }
+}
 // Skip threshold of a record (r1.z: power below it cannot reach alpha >= 1/255) as the bit pattern the unsigned compare
 // uses: -threshold for a negative threshold; 0 otherwise (opacity <= 1/255: only q == +0 passes, and fails the alpha test).
 __device__ __forceinline__ float skip_bits(float thr) { return thr < 0.0f ? -thr : 0.0f; }

@@ -72,6 +72,7 @@ constexpr int kBwdQuads = 7;  // float4 per slot of two survivors
 //   dL/da_j = T_j * sum_ch (c_j - R_j)_ch * dL/dC_ch  -  Tf / (1 - a_j) * (bg . dL/dC)
 // A survivor that does not touch the pixel enters with a_j = 0 and G_j = 0, which makes every update the identity
 // and every partial zero -- no per-value masking.
+template <bool FAST_EXP>
 __global__ __launch_bounds__(64) void render_bwd_kernel(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
             on_a = on_a & (__float_as_uint(pw.x) <= __float_as_uint(c2.z));
             on_b = on_b & (__float_as_uint(pw.y) <= __float_as_uint(c2.w));
             if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) continue;  // wave-uniform
-            const f32x2 Gr = fs_exp2_of_neg(pw);
+            const f32x2 Gr = blend_exp_of_neg<FAST_EXP>(pw);
             const f32x2 oe = (f32x2){c3.x, c3.y} * Gr;
             const f32x2 al_raw = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
             on_a = on_a & (al_raw.x >= 1.0f / 255.0f);
@@ -513,7 +514,11 @@ int launch_render_bwd(const fs_raster_dims& d, const float* bg, const void* geom
     const int nblk = tile_grid_blocks((d.W + kTile - 1) / kTile, (d.H + kTile - 1) / kTile);
     {
         ScopedStage prof_(kStRenderBwd, st);
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
+        if (d.flags & FS_RASTER_FAST_EXP)
+            hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
+                           point_list, g.rec, bg, counters, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
+        else
+            hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
                            point_list, g.rec, bg, counters, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
     }
     FS_CHECK_LAUNCH("render_bwd");

@@ -923,6 +923,7 @@ constexpr int kPairQuads = 6;  // float4 per slot of two survivors
 #ifdef FS_RENDER_TRACE
 __device__ unsigned long long g_render_trace[4 * 8192];
 #endif
+template <bool FAST_EXP>
 __global__ __launch_bounds__(64) void render_kernel(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
@@ -1032,7 +1033,7 @@ __global__ __launch_bounds__(64) void render_kernel(
             const bool cd = has_d & (__float_as_uint(pv.y) <= __float_as_uint(e2.w));
             if (__builtin_amdgcn_ballot_w64(((ca | cb) | (cc | cd)) & !done) == 0) continue;  // wave-uniform
             const float4 ka = q[4], kb = q[5], kc = q[10], kd = q[11];
-            const f32x2 ew = fs_exp2_of_neg(pw), ev = fs_exp2_of_neg(pv);
+            const f32x2 ew = blend_exp_of_neg<FAST_EXP>(pw), ev = blend_exp_of_neg<FAST_EXP>(pv);
             const f32x2 ow = (f32x2){c3.x, c3.y} * ew, ov = (f32x2){e3.x, e3.y} * ev;
             const f32x2 aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
             const f32x2 av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
@@ -1184,7 +1185,12 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     FS_CHECK_LAUNCH("tile_sort");
     {
         ScopedStage prof_(kStRender, st);
-        hipLaunchKernelGGL(render_kernel, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T,
+        if (d.flags & FS_RASTER_FAST_EXP)
+            hipLaunchKernelGGL(render_kernel<true>, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T,
+                           offsets, point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T,
+                           n_contrib);
+        else
+            hipLaunchKernelGGL(render_kernel<false>, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T,
                            offsets, point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T,
                            n_contrib);
     }

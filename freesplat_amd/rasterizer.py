@@ -30,6 +30,13 @@ from . import _lib
 # tile lists shrink to the instances that can actually contribute.  FREESPLAT_TILE_CULL=0 keeps the
 # reference's full 3-sigma-square lists.
 TILE_CULL = os.environ.get("FREESPLAT_TILE_CULL", "1") != "0"
+# Blend-loop exponential.  Default: the CPU-reproducible polynomial exp of the bit-exact contract (forward identical to
+# the oracle bit for bit).  FREESPLAT_FAST_EXP=1 (or rasterizer.FAST_EXP = True) selects the hardware v_exp_f32
+# (include/freesplat_amd.h FS_RASTER_FAST_EXP): +11 % views/s at config 3; lists / ordering / radii stay identical and
+# the image stays within ~1e-6 of the contract everywhere EXCEPT at a handful of pixels per view where the few-ulp
+# difference flips an alpha >= 1/255 or T >= 1e-4 decision (up to 4e-3 there; counted in tests and in bench.py's
+# `fast_exp` block) -- which is why it is opt-in.
+FAST_EXP = os.environ.get("FREESPLAT_FAST_EXP", "0") == "1"
 # Views of one render_views call are spread round-robin over this many HIP streams so that the short
 # latency-bound launches of one view (tile scan, kernel tails) overlap the VALU-bound blend of another.
 NUM_STREAMS = max(1, int(os.environ.get("FREESPLAT_RASTER_STREAMS", "2")))  # views of one call round-robin over this many streams
@@ -149,7 +156,8 @@ def make_dims(N, M, settings: GaussianRasterizationSettings, sh_fp16: bool = Fal
     d.H, d.W = int(settings.image_height), int(settings.image_width)
     d.sh_degree = int(settings.sh_degree)
     d.tanfovx, d.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
-    d.flags = (_lib.RASTER_TILE_CULL if TILE_CULL else 0) | (_lib.RASTER_SH_FP16 if sh_fp16 else 0)
+    d.flags = ((_lib.RASTER_TILE_CULL if TILE_CULL else 0) | (_lib.RASTER_SH_FP16 if sh_fp16 else 0)
+               | (_lib.RASTER_FAST_EXP if FAST_EXP else 0))
     if native_layout:
         d.flags |= _lib.RASTER_SH_CHANNEL_MAJOR | _lib.RASTER_COV_FULL
     return d

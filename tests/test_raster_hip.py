@@ -465,7 +465,8 @@ def test_full_size_parity_and_properties(hip_device, workload):
     assert (np.diff(key)[same] > 0).all()
 
 
-@pytest.mark.parametrize("workload", ["c2_640x480_300k", "c3_968x1296_1M"])
+@pytest.mark.parametrize("workload", ["c2_640x480_300k", "c3_968x1296_1M",
+                                      pytest.param("c3_968x1296_1M", marks=pytest.mark.fast_exp, id="c3_fast_exp")])
 def test_full_size_forward_backward_gradients(hip_device, workload):
     """BASELINE.json config 3 is a fwd+bwd training step at 968x1296 / 1.0 M Gaussians (config 2's size as well):
     ONE view, colour and depth cotangents, all five gradients (means3D, cov3D, SH, opacities, screen-space
@@ -481,8 +482,13 @@ def test_full_size_forward_backward_gradients(hip_device, workload):
     g_depth = (0.25 * rng.normal(size=(H, W))).astype(np.float32)
     ref = ro.backward(st, g_color, g_depth)
     (color, radii, depth, alpha), leaves = hip_forward(vi, hip_device, requires_grad=True)
-    np.testing.assert_array_equal(color.detach().cpu().numpy(), st["color"])   # the forward half: bit-exact
-    np.testing.assert_array_equal(depth.detach().cpu().numpy(), st["depth"])
+    from freesplat_amd import rasterizer as R
+    if R.FAST_EXP:     # opt-in hardware exp: threshold flips at a few pixels (test_fast_exp_mode_quantified); gradients below
+        d = np.abs(color.detach().cpu().numpy() - st["color"]).max(axis=0)
+        assert int((d > ATOL_PIXEL).sum()) <= 1e-4 * H * W and d.max() <= 5e-3
+    else:              # the forward half: bit-exact
+        np.testing.assert_array_equal(color.detach().cpu().numpy(), st["color"])
+        np.testing.assert_array_equal(depth.detach().cpu().numpy(), st["depth"])
     loss = (color * torch.from_numpy(g_color).to(hip_device)).sum() + (depth * torch.from_numpy(g_depth).to(hip_device)).sum()
     loss.backward()
     worst = {}
@@ -494,7 +500,8 @@ def test_full_size_forward_backward_gradients(hip_device, workload):
     worst["means2D"] = float(np.abs(m2[:, :2] - ref["means2D"]).max() / (np.abs(ref["means2D"]).max() + 1e-20))
     print(f"{workload} fwd+bwd: gradient error / max-abs = {worst}")
     assert (m2[:, 2] == 0).all()
-    assert max(worst.values()) < 2e-4, worst
+    # (hardware exp: a flipped alpha >= 1/255 decision moves one Gaussian's gradient at one pixel -- 1e-3-level bar there)
+    assert max(worst.values()) < (2e-3 if R.FAST_EXP else 2e-4), worst
     # culled Gaussians get exactly zero gradient
     dead = st["radii"] == 0
     assert dead.any() and not leaves["means3D"].grad.cpu().numpy()[dead].any()
@@ -566,3 +573,37 @@ def test_render_views_hipgraph_capture_and_replay(hip_device):
             ref_c, ref_d = call(); check_deferred()
             assert torch.equal(got_c, ref_c) and torch.equal(got_d, ref_d), f"replay {trial}"
         assert got_c.abs().max() > 0
+
+
+@pytest.mark.fast_exp
+@pytest.mark.parametrize("H,W,N,seed,workload", [(64, 80, 600, 7, None), (256, 256, 20000, 5, None),
+                                                 (0, 0, 0, 0, "c2_640x480_300k"), (0, 0, 0, 0, "c3_968x1296_1M")])
+def test_fast_exp_mode_quantified(hip_device, monkeypatch, H, W, N, seed, workload):
+    """The opt-in hardware exp (FS_RASTER_FAST_EXP) against the oracle: everything the exp does not touch is still
+    IDENTICAL -- radii, tile ranges, depth-sorted id lists -- and the image agrees to ~1e-6 except where the few-ulp
+    difference flips a discontinuous decision (alpha >= 1/255, T >= 1e-4).  Those pixels are COUNTED: at most 1e-4 of the
+    image above the north_star's 1e-4, none above 5e-3, PSNR > 90 dB -- this is what keeps the mode opt-in."""
+    _set_cull(monkeypatch, False)
+    if workload:
+        H, W, N = synthetic.WORKLOADS[workload]
+        scene, cams = synthetic.make_scene(N), synthetic.target_cameras(2)
+    else:
+        scene, cams = small_scene(N=N, H=H, W=W, seed=seed)
+    vi = view_inputs(scene, cams, 1, H, W, bg=(0.1, 0.2, 0.3))
+    from freesplat_amd import rasterizer as R
+    assert R.FAST_EXP
+    st = oracle_forward(vi)
+    (color, radii, depth, alpha), _ = hip_forward(vi, hip_device)
+    np.testing.assert_array_equal(radii.cpu().numpy(), st["radii"])
+    c = color.cpu().numpy()
+    d = np.abs(c - st["color"]).max(axis=0)
+    n_bad = int((d > ATOL_PIXEL).sum())
+    mse = float(((c.clip(0, 1) - st["color"].clip(0, 1)) ** 2).mean())
+    psnr = float("inf") if mse == 0 else -10 * np.log10(mse)
+    print(f"fast exp {workload or (H, W, N)}: max-abs {d.max():.2e}, median {np.median(d):.1e}, pixels > 1e-4: {n_bad} of {H * W}, "
+          f"PSNR {psnr:.1f} dB")
+    assert n_bad <= max(1, int(1e-4 * H * W)) and d.max() <= 5e-3 and psnr > 90.0 and np.median(d) <= 1e-6
+    dbg, _, _ = _internal_state(vi, hip_device)
+    np.testing.assert_array_equal(dbg["offsets"][1:], st["ranges"][:, 1])
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    assert float((dbg["n_contrib"] != st["n_contrib"]).mean()) < 1e-3
