@@ -153,14 +153,35 @@ __device__ __forceinline__ uint32_t quad_mask_row(const RowBands& rb, const floa
 }
 
 // Quadrant masks of every tile of a (small) rect packed 4 bits per tile, row-major: computed once in
-// preprocess, reused by both phases of emit.
+// preprocess, reused by both phases of emit.  Per tile row the two 8-pixel bands give two u-intervals; instead of
+// testing them against every quadrant column with float compares (28 VALU, 8 of them v_cmp, per tile), each interval is
+// turned ONCE into the range of 8-pixel cell columns it can touch -- a bit mask over the rect's <= 32 cells -- and a
+// tile's 4 bits are two 2-bit fields of those masks (7 integer ops).  Conservative like quad_mask_row (intervals
+// widened by 1e-3 cell on top of the band's own slack; NaNs keep everything); masks may differ from it only by keeping
+// a borderline quadrant.
+__device__ __forceinline__ uint32_t band_cells(const Band& b, float px, int cell0, int ncell)
+{
+    const uint32_t full = ncell >= 32 ? 0xFFFFFFFFu : ((1u << ncell) - 1u);
+    if (b.uL > b.uR) return 0u;          // empty band
+    if (!(b.uL <= b.uR)) return full;    // NaN: keep everything
+    // cell c = pixels [8c, 8c+7]; it meets [px+uL, px+uR] iff (px+uL-7)/8 <= c <= (px+uR)/8
+    const float lo_f = ceilf((b.uL + px - 7.0f) * 0.125f - 1e-3f), hi_f = floorf((b.uR + px) * 0.125f + 1e-3f);
+    const int lo = max((int)lo_f, cell0) - cell0, hi = min((int)hi_f, cell0 + ncell - 1) - cell0;   // (float -> int saturates)
+    if (lo > hi) return 0u;
+    return ((2u << hi) - (1u << lo)) & full;
+}
 __device__ __forceinline__ unsigned long long pack_quad_masks(const QuadForm& f, const float4 r0, ushort4 rc)
 {
     unsigned long long m = 0;
+    const int rw = rc.z - rc.x, cell0 = 2 * rc.x, ncell = 2 * rw;   // small rects: rw <= 16
     int k = 0;
     for (int y = rc.y; y < rc.w; ++y) {
         const RowBands rb = row_bands(f, r0, y);
-        for (int x = rc.x; x < rc.z; ++x, ++k) m |= (unsigned long long)quad_mask_row(rb, r0, x) << (4 * k);
+        const uint32_t top = band_cells(rb.top, r0.x, cell0, ncell), bot = band_cells(rb.bot, r0.x, cell0, ncell);
+        for (int x = 0; x < rw; ++x, ++k) {
+            const uint32_t nib = ((top >> (2 * x)) & 3u) | (((bot >> (2 * x)) & 3u) << 2);
+            m |= (unsigned long long)nib << (4 * k);
+        }
     }
     return m;
 }
