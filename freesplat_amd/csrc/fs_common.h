@@ -2,7 +2,7 @@
 //
 // Arithmetic contract for the rasterizer forward (see DESIGN.md "bit-reproducible forward"):
 // the translation units are compiled with -ffp-contract=off, every fused multiply-add is an
-// explicit fmaf(), exp() is fs_exp() (IEEE mul/sub/fma + v_rndne + v_ldexp only), sqrt and
+// explicit fmaf(), exp() is fs_exp() (IEEE fma / add + an integer add on the exponent only), sqrt and
 // division are the correctly rounded forms hipcc emits by default.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -43,18 +43,19 @@ struct ScopedStage {
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// ---- deterministic exp (x <= 0 on the hot path) ---------------------------------------------
+// ---- deterministic exp (x <= 0 on the hot path): the same operation sequence as oracle/raster_oracle.c:fso_exp ----
+constexpr float kExpC1 = 0.9999997019767761f, kExpC2 = 0.4999915063381195f, kExpC3 = 0.1666763573884964f, kExpC4 = 0.04189793020486832f, kExpC5 = 0.008290314115583897f;
 __device__ __forceinline__ float fs_exp(float x)
 {
     if (x < -80.0f) return 0.0f;
-    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    const float t = fmaf(x, 1.44269504088896341f, 12582912.0f);
+    const float n = t - 12582912.0f;
     float r = fmaf(n, -0.693145751953125f, x);       // Cody-Waite: ln2 = hi + lo
     r = fmaf(n, -1.42860676533018e-6f, r);
-    float p = fmaf(r, 1.0f / 720.0f, 1.0f / 120.0f);
-    p = fmaf(r, p, 1.0f / 24.0f);
-    p = fmaf(r, p, 1.0f / 6.0f);
-    p = fmaf(r, p, 0.5f);
-    p = fmaf(r, p, 1.0f);
+    float p = fmaf(r, kExpC5, kExpC4);
+    p = fmaf(r, p, kExpC3);
+    p = fmaf(r, p, kExpC2);
+    p = fmaf(r, p, kExpC1);
     p = fmaf(r, p, 1.0f);
     return ldexpf(p, (int)n);
 }
@@ -91,21 +92,20 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
 
-// fs_exp() of two arguments in [-80, 0], bit-identical to the scalar form: rint(m) = (m + 1.5*2^23) - 1.5*2^23
-// for |m| < 2^22, and the low bits of the biased sum are the integer for the exponent (ldexpf == integer add on
-// the exponent field while the result stays normal).  Arguments outside the range give garbage, never a trap.
+// fs_exp() of two arguments in [-80, 0], bit-identical to the scalar form: the low bits of the biased sum t are the
+// integer n for the exponent (ldexpf == integer add on the exponent field while the result stays normal).  Arguments
+// outside the range give garbage, never a trap.
 __device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
 {
     const f32x2 magic = splat2(12582912.0f);
-    const f32x2 t = x * splat2(1.44269504088896341f) + magic;
+    const f32x2 t = fma2(x, splat2(1.44269504088896341f), magic);
     const f32x2 n = t - magic;
     f32x2 r = fma2(n, splat2(-0.693145751953125f), x);
     r = fma2(n, splat2(-1.42860676533018e-6f), r);
-    f32x2 q = fma2(r, splat2(1.0f / 720.0f), splat2(1.0f / 120.0f));
-    q = fma2(r, q, splat2(1.0f / 24.0f));
-    q = fma2(r, q, splat2(1.0f / 6.0f));
-    q = fma2(r, q, splat2(0.5f));
-    q = fma2(r, q, splat2(1.0f));
+    f32x2 q = fma2(r, splat2(kExpC5), splat2(kExpC4));
+    q = fma2(r, q, splat2(kExpC3));
+    q = fma2(r, q, splat2(kExpC2));
+    q = fma2(r, q, splat2(kExpC1));
     q = fma2(r, q, splat2(1.0f));
     const i32x2 e = __builtin_bit_cast(i32x2, q) + (__builtin_bit_cast(i32x2, t) << 23);
     return __builtin_bit_cast(f32x2, e);
@@ -117,22 +117,21 @@ __device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
 __device__ __forceinline__ f32x2 fs_exp2_of_neg(f32x2 q)
 {
     const f32x2 magic = splat2(12582912.0f);
-    const f32x2 t = magic - q * splat2(1.44269504088896341f);
+    const f32x2 t = fma2(q, splat2(-1.44269504088896341f), magic);   // == fma(-q, log2 e, magic)
     const f32x2 n = t - magic;
     f32x2 r = fma2(n, splat2(-0.693145751953125f), -q);
     r = fma2(n, splat2(-1.42860676533018e-6f), r);
-    f32x2 p = fma2(r, splat2(1.0f / 720.0f), splat2(1.0f / 120.0f));
-    p = fma2(r, p, splat2(1.0f / 24.0f));
-    p = fma2(r, p, splat2(1.0f / 6.0f));
-    p = fma2(r, p, splat2(0.5f));
-    p = fma2(r, p, splat2(1.0f));
+    f32x2 p = fma2(r, splat2(kExpC5), splat2(kExpC4));
+    p = fma2(r, p, splat2(kExpC3));
+    p = fma2(r, p, splat2(kExpC2));
+    p = fma2(r, p, splat2(kExpC1));
     p = fma2(r, p, splat2(1.0f));
     const i32x2 e = __builtin_bit_cast(i32x2, p) + (__builtin_bit_cast(i32x2, t) << 23);
     return __builtin_bit_cast(f32x2, e);
 }
 // exp(-q) of the blend loops: FAST = hardware v_exp_f32 (2^x, <= 1 ulp; FS_RASTER_FAST_EXP), else the contract exp.
 // On gfx950 a wave64 v_fma_f32 issues in ~2.6 cycles, v_pk_fma_f32 in ~5.2 (no packed-fp32 throughput gain on this
-// chip), v_exp_f32 in ~8.4 (profiles/tools/valu_rates.hip): contract exp = 31 cycles per value, hardware = 11.
+// chip), v_exp_f32 in ~8.4 (profiles/tools/valu_rates.hip): contract exp = 26 cycles per value, hardware = 11.
 template <bool FAST>
 __device__ __forceinline__ f32x2 blend_exp_of_neg(f32x2 q)
 {

