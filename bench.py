@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--grad-exchange", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
                     help="N>1 train mode: how the per-Gaussian gradients of the view shards are summed")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image all-gather")
+    ap.add_argument("--gather-depth", action="store_true",
+                    help="N>1: all-gather the depth maps too (the reference's decoder returns depth only when depth_mode is "
+                         "set, decoder_splatting_cuda.py:64-70; colour alone is 15 MB per view, with depth 20 MB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph capture / replay measurement")
@@ -138,7 +141,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                                         check="deferred")
             if gather is not None:
                 gather.wait()  # previous step's gather must be done before its buffers are dropped
-                gather.launch(torch.cat([color, depth], dim=1))
+                gather.launch(torch.cat([color, depth], dim=1) if args.gather_depth else color)
         return color, depth
 
     for attempt in range(2):
@@ -234,7 +237,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                    "blend_exp": "hardware v_exp_f32" if _R_FAST() else "contract polynomial",
                    "instances_per_view": int(n_inst),
                    "parallelism": f"view-sharded x{world}" + (f" + {args.grad_exchange}(gaussian grads)" if exchange else
-                                                              " + all_gather(color,depth)" if gather else "")},
+                                                              (" + all_gather(color,depth)" if args.gather_depth else " + all_gather(color)") if gather else "")},
     }
     if graph_views_per_s is not None:
         out["hipgraph_replay"] = {"value": graph_views_per_s, "unit": "views/s", "same_image_as_eager": graph_ok,

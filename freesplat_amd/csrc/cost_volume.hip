@@ -20,6 +20,7 @@
 //     one wavefront overlaps the MFMAs of the other wavefronts of the SIMD.
 //   * bias of layer 1 rides in the padding column of the K dimension (feature 49 := 1).
 #include <algorithm>
+#include <cstdlib>
 
 #include "fs_common.h"
 
@@ -624,6 +625,8 @@ using namespace fs;
 // but at least 4 planes per wavefront so the per-wavefront weight loads stay amortised.
 static int cv_plane_split(int B, int groups, int D)
 {
+    static const int forced = getenv("FS_CV_SPLIT") ? atoi(getenv("FS_CV_SPLIT")) : 0;   // (tuning knob)
+    if (forced > 0) return forced;
     int split = 1;
     while (split * 4 * 4 < D && (long long)B * groups * 4 * split < 12288) split *= 2;
     return split;
