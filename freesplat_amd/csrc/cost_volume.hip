@@ -546,19 +546,47 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
                 dwv[s] = cf * dfavg[s] + cd * cur[s];
                 dcur[s] += cd * W.wv[s];
             }
+            // Scatter to the source map, TRANSPOSED through the wavefront's LDS tile: with lane = pixel one atomic
+            // instruction touched 64 different texel records (~40 cache lines, 4 bytes each); with lane = channel it
+            // covers ONE texel's contiguous record (2 lines).  The L2 executes atomics per 64-byte request, so the
+            // request count is what the 6e8 float atomics of a native call cost: 96 instructions x ~40 lines before,
+            // 128 x 2 now, per (32-pixel group, plane, source).
+            {
+                float* tD = s_stage + wave * kStage;                // [32 pixels][C slots]  (slot = parity * HC + s)
+                float* tW = tD + 32 * C;                            // [32][4] tap weights (0: tap unused)
+                uint32_t* tO = (uint32_t*)(tW + 32 * 4);            // [32][4] texel index of the tap in the source map
+                static_assert(32 * C + 2 * 32 * 4 <= kStage, "scatter staging exceeds the wavefront's LDS tile");
 #pragma unroll
-            for (int tap = 0; tap < 4; ++tap)
-                if (W.ok[tap]) {
-                    float* q = d_srcT + W.off[tap];
+                for (int s = 0; s < HC; ++s) tD[p * C + hf * HC + s] = dwv[s];
+                if (hf == 0) {
+                    const size_t map0 = (((size_t)b * K + k) * hw) * C;
 #pragma unroll
-                    for (int s = 0; s < HC; ++s) atomicAdd(q + s, W.wt[tap] * dwv[s]);
+                    for (int tap = 0; tap < 4; ++tap) {
+                        tW[p * 4 + tap] = W.ok[tap] ? W.wt[tap] : 0.0f;
+                        tO[p * 4 + tap] = W.ok[tap] ? (uint32_t)((W.off[tap] - map0) / C) : 0u;
+                    }
                 }
+                wave_lds_sync();
+                float* const dmap = d_srcT + (((size_t)b * K + k) * hw) * C;
+                for (int e = 0; e < 128; ++e) {                     // (pixel e >> 2, tap e & 3): wave-uniform
+                    const float wt = tW[e];
+                    if (wt == 0.0f) continue;
+                    if (lane < C) atomicAdd(dmap + (size_t)tO[e] * C + lane, wt * tD[(e >> 2) * C + lane]);
+                }
+                wave_lds_sync();
+            }
         }
     }
-    if (live) {
-        float* q = d_curT + ((size_t)b * hw + pix) * C + (size_t)hf * HC;
+    {   // d cur: same transposition (one atomic instruction per pixel record instead of 24 over 64 scattered records)
+        float* tD = s_stage + wave * kStage;
 #pragma unroll
-        for (int s = 0; s < HC; ++s) atomicAdd(q + s, dcur[s]);
+        for (int s = 0; s < HC; ++s) tD[p * C + hf * HC + s] = live ? dcur[s] : 0.0f;
+        wave_lds_sync();
+        const int npx = min(32, hw - grp * 32);
+        float* const dst = d_curT + ((size_t)b * hw + (size_t)grp * 32) * C;
+        for (int j = 0; j < npx; ++j)
+            if (lane < C) atomicAdd(dst + (size_t)j * C + lane, tD[j * C + lane]);
+        wave_lds_sync();
     }
     // w3 / b3 gradients: reduce over the 32 pixels of each half, one atomic per unit per wavefront
 #pragma unroll
