@@ -43,7 +43,7 @@ struct ScopedStage {
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// ---- deterministic exp (x <= 0 on the hot path): the same operation sequence as oracle/raster_oracle.c:fso_exp ----
+// ---- deterministic exp (x <= 0 on the hot path): the same operation sequence as the CPU checker's exp ----
 constexpr float kExpC1 = 0.9999997019767761f, kExpC2 = 0.4999915063381195f, kExpC3 = 0.1666763573884964f, kExpC4 = 0.04189793020486832f, kExpC5 = 0.008290314115583897f;
 __device__ __forceinline__ float fs_exp(float x)
 {

@@ -11,13 +11,13 @@ import sys
 
 def main(src, tag, cmd):
     rows = list(csv.DictReader(open(f"{src}/trace/c3_kernel_stats.csv")))
-    ours = [r for r in rows if r["Name"].startswith("fs::")]
+    ours = [r for r in rows if "fs::" in r["Name"].split("(")[0]]   # (templated kernels read "void fs::name<...>(")
     total = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- " + cmd + "\n")
         f.write("kernel,calls,avg_us,min_us,max_us,pct_of_gpu_time\n")
         for r in ours:
-            f.write(f"{r['Name'].split('(')[0]},{r['Calls']},{float(r['AverageNs'])/1e3:.1f},"
+            f.write(f"{r['Name'].split('(')[0].replace('void ', '')},{r['Calls']},{float(r['AverageNs'])/1e3:.1f},"
                     f"{float(r['MinNs'])/1e3:.1f},{float(r['MaxNs'])/1e3:.1f},{100*float(r['TotalDurationNs'])/total:.2f}\n")
         other = total - sum(float(r["TotalDurationNs"]) for r in ours)
         f.write(f"(torch/rocclr kernels of the host framing),,,,,{100*other/total:.2f}\n")
@@ -25,8 +25,8 @@ def main(src, tag, cmd):
     for name in ("fetch", "write"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f"{src}/{name}/c3_counter_collection.csv")):
-            if r["Kernel_Name"].startswith("fs::"):
-                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            if "fs::" in r["Kernel_Name"].split("(")[0]:
+                agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             traffic[k][name + "_size_kb_raw"] = sum(v) / len(v)
     out = {}
@@ -57,8 +57,8 @@ def sq_summary(src):
             continue
         agg = collections.defaultdict(list)
         for r in rows:
-            if r["Kernel_Name"].startswith("fs::"):
-                agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if "fs::" in r["Kernel_Name"].split("(")[0]:
+                agg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
             out[k][c] = sum(v) / len(v)
     return out
