@@ -607,3 +607,25 @@ def test_fast_exp_mode_quantified(hip_device, monkeypatch, H, W, N, seed, worklo
     np.testing.assert_array_equal(dbg["offsets"][1:], st["ranges"][:, 1])
     np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
     assert float((dbg["n_contrib"] != st["n_contrib"]).mean()) < 1e-3
+
+
+@pytest.mark.parametrize("N", [2300, 3000, 4000, 5200])
+def test_dense_tiles_long_lists(hip_device, monkeypatch, N):
+    """Every Gaussian of the scene lands on the same 2x2 tiles: per-tile lists of ~N entries drive the sort paths
+    beyond the LDS bucket sort (2048 < n <= 4096: register bitonic networks, two-run and full; n > 4096: the in-place
+    global-memory network) and the blend through 40-80 batches per quadrant.  Bit-exact images, identical lists."""
+    _set_cull(monkeypatch, False)
+    H = W = 32
+    scene, cams = small_scene(N=N, H=H, W=W, seed=44)
+    # pull every Gaussian towards the optical axis so that its 3-sigma square covers the whole 32x32 image
+    scene["means"][:, :2] = scene["means"][:, :2] * 0.02
+    scene["covariances"] = scene["covariances"] * 400.0
+    scene["opacities"] = scene["opacities"] * 0.004           # keep the pixels unsaturated: deep lists are blended
+    vi = view_inputs(scene, cams, 0, H, W, bg=(0.05, 0.1, 0.15))
+    st, _, _ = _check_forward(vi, hip_device)
+    n_tile = (st["ranges"][:, 1] - st["ranges"][:, 0])
+    assert n_tile.max() > min(N, 4096) * 0.55, n_tile
+    dbg, _, _ = _internal_state(vi, hip_device)
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    np.testing.assert_array_equal(dbg["n_contrib"], st["n_contrib"])
+    assert st["n_contrib"].max() > 0.4 * n_tile.max()           # deep lists really are walked
