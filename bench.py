@@ -387,6 +387,9 @@ def main():
                 "native_96x128_K1": be.bench_cost_volume(cx.dev, args.steps, args.warmup, cpu=cpu),
                 "c3scale_242x324_K2": be.bench_cost_volume(cx.dev, max(3, args.steps // 4), 1, V=3, K=2, h4=242, w4=324,
                                                            cpu=cpu, cpu_views=1),
+                # config 4's shape: 10 context views, the 9 pose-nearest as sources (K = 8); GPU timing only (its parity
+                # case runs at reduced size in tests/test_configs_4_5.py: the CPU oracle needs minutes at this size)
+                "fvt10_96x128_K8": be.bench_cost_volume(cx.dev, max(3, args.steps // 4), 1, V=10, K=8, cpu=False),
             }
         if "ptf" in sections:
             out["ptf"] = {
