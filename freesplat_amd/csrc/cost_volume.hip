@@ -75,7 +75,9 @@ __global__ void cv_proj_kernel(int n, const float* __restrict__ src_Ks, const fl
     P[e] = Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] + Ks[4 * i + 3] * Tx[12 + j];
 }
 
-__device__ __forceinline__ float lrelu(float x) { return fmaxf(x, 0.01f * x); }  // slope < 1: max picks the right branch
+// LeakyReLU(0.01) = 0.505 x + 0.495 |x|: two VALU operations (|x| is a free source modifier).  fmaxf(x, 0.01 x) costs four
+// here (the multiply, the max and two NaN-canonicalising v_max that IEEE mode puts in front of it).
+__device__ __forceinline__ float lrelu(float x) { return fmaf(0.495f, fabsf(x), 0.505f * x); }
 
 // accumulator row held by (reg r, half hf) of a 32x32 MFMA result (guide, "Fragment layout")
 __device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
@@ -185,14 +187,17 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
             float wv[HC];
 #pragma unroll
             for (int s = 0; s < HC; ++s) wv[s] = 0.0f;
-            const float* base = srcT + (((size_t)b * K + k) * hw) * C + (size_t)hf * HC;
+            // wave-uniform map base (SGPR pair) + a 32-bit per-lane byte offset: one address add per tap instead of
+            // 64-bit multiply-adds (a source map is far below 4 GB)
+            const char* base = (const char*)(srcT + (((size_t)b * K + k) * hw) * C);
+            const uint32_t off0 = (uint32_t)((y0 * w + x0) * C + hf * HC) * 4u;
 #pragma unroll
             for (int tap = 0; tap < 4; ++tap) {
                 const int ox = tap & 1, oy = tap >> 1;
                 const bool ok = live && (ox ? xin1 : xin0) && (oy ? yin1 : yin0);
                 const float wt = (ox ? tx : 1.0f - tx) * (oy ? ty : 1.0f - ty);
                 if (ok) {
-                    const float4* q = (const float4*)(base + ((size_t)(y0 + oy) * w + (x0 + ox)) * C);
+                    const float4* q = (const float4*)(base + (off0 + (uint32_t)((oy * w + ox) * C) * 4u));
 #pragma unroll
                     for (int s = 0; s < HC / 4; ++s) {
                         const float4 v = q[s];
