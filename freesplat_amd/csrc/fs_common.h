@@ -74,8 +74,25 @@ static __device__ unsigned long long g_phase_trace[kPtKernels * kPtBlocks * kPtS
 #define FS_PT(kern, k) do {} while (0)
 #endif
 
+// positional encoding of two scalars, 6 octaves each, (sin, cos) interleaved (encoder_freesplat.py:62-77): 24 floats
+__device__ __forceinline__ void pos_enc2(float a, float b, float* __restrict__ out)  // 24 floats
+{
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float f = (float)(1 << k);
+        // hardware v_sin_f32 / v_cos_f32 (arguments are densities and weights times <= 32: |error| ~1e-6, far inside the
+        // fold's 1e-4 bar; the libm forms cost ~40 VALU each, 48 of them per fused pair)
+        out[2 * k] = __sinf(a * f); out[2 * k + 1] = __cosf(a * f);
+        out[12 + 2 * k] = __sinf(b * f); out[12 + 2 * k + 1] = __cosf(b * f);
+    }
+}
+
 // ptf_gru.hip: the GRU of a fold step (n pairs, or at most n_max with the count in counts[1] on the device)
 int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const float* tables, float* fused, hipStream_t st);
+// ... with the input rows gathered and encoded inside the kernel (no [n,176] intermediate): the fold's own path
+int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fuse_idx, const long long* fuse_pix,
+                          const float* G, const float* R, const float* O, const float* g_i, const float* rho_i,
+                          const float* om_i, const float* tables, float* fused, hipStream_t st);
 
 // LDS operations of one wavefront execute in order: between phases of a wavefront-private LDS exchange only the
 // compiler must be kept from reordering them.

@@ -221,16 +221,6 @@ __global__ __launch_bounds__(256) void ptf_emit_kernel(int M, const int32_t* __r
 //                   [kept (copied) | fused (GRU output + density-weighted blends) | appended pixels]
 //                   -- replaces ~40 boolean-mask / cat launches and O(M) temporaries per field.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pos_enc2(float a, float b, float* __restrict__ out)  // 24 floats
-{
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const float f = (float)(1 << k);
-        out[2 * k] = sinf(a * f); out[2 * k + 1] = cosf(a * f);
-        out[12 + 2 * k] = sinf(b * f); out[12 + 2 * k + 1] = cosf(b * f);
-    }
-}
-
 // one 16-lane group per fused pair: lanes 0..15 move the two 64-float latents as float4, lane 0/1 the encodings
 __global__ __launch_bounds__(256) void ptf_gru_inputs_kernel(int n_fuse, const int32_t* __restrict__ counts,
                                                             const long long* __restrict__ fuse_idx,
@@ -602,10 +592,9 @@ FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int3
     if (rc != FS_OK) return rc;
     const int nf_max = M_max < P ? M_max : P;
     ScopedStage prof_(kStPtf, st);
-    hipLaunchKernelGGL(ptf_gru_inputs_kernel, dim3((nf_max + 15) / 16), dim3(256), 0, st, nf_max, (const int32_t*)counts,
-                       (const long long*)fuse, (const long long*)fpix, G, R, O, g_i, rho_i, om_i, cat);
-    FS_CHECK_LAUNCH("ptf_gru_inputs");
-    rc = launch_ptf_gru(nf_max, counts, cat, gru_tables, fused, st);
+    (void)cat;  // (the GRU gathers and encodes its input rows itself: no [n,176] intermediate)
+    rc = launch_ptf_gru_gather(nf_max, counts, (const long long*)fuse, (const long long*)fpix, G, R, O, g_i, rho_i, om_i,
+                               gru_tables, fused, st);
     if (rc != FS_OK) return rc;
     PtfState si{const_cast<float*>(G), const_cast<float*>(X), const_cast<float*>(R), const_cast<float*>(O),
                 const_cast<float*>(E), const_cast<float*>(D)};

@@ -33,8 +33,17 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 #define FS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// GATHER: the input row [hid | he | x | xe] of pair t is not read from a materialised `cat` array but assembled here:
+// hid = G[fuse_idx[t]], x = g_i[fuse_pix[t]] (the half of the lanes that owns them loads them), he / xe = the positional
+// encodings of the densities and weights (encoder_freesplat.py:485-486) -- 24 sin/cos per lane, every lane busy, instead
+// of a separate kernel in which 2 lanes of 16 did them and 141 MB of rows went to HBM and back per 10^5 pairs.
+struct GruGather {
+    const long long *fuse_idx, *fuse_pix;
+    const float *G, *R, *O, *g_i, *rho_i, *om_i;
+};
+template <bool GATHER>
 __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __restrict__ counts,
-                                                      const float* __restrict__ cat,
+                                                      const float* __restrict__ cat, GruGather ga,
                                                       const float* __restrict__ tab, float* __restrict__ fused)
 {
     if (counts) n = counts[1];  // (device-resident pair count: fs_ptf_fold_step)
@@ -44,22 +53,37 @@ __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __re
     const int p = lane & 31, hf = lane >> 5;
     const int t = grp * 32 + p;
     const bool live = t < n;
-    const float* row = cat + (size_t)(live ? t : 0) * 176;
     const float* T = tab + lane;  // T[r * 64] = row r of the tables for this lane
+    // sources of this pair: `row` = a materialised row, or (GATHER) the state latent / the view latent
+    const float* row = GATHER ? nullptr : cat + (size_t)(live ? t : 0) * 176;
+    const long long gm = GATHER ? ga.fuse_idx[live ? t : 0] : 0, gp = GATHER ? ga.fuse_pix[live ? t : 0] : 0;
+    const float* hrow = GATHER ? ga.G + gm * 64 : row;          // hid: 64 floats
+    const float* xrow = GATHER ? ga.g_i + gp * 64 : row + 88;   // x: 64 floats (xe follows only in a materialised row)
 
     // this half's contiguous half row, and hid in accumulator-row order (units acc rows of this half)
     float xh[88];
+    if (GATHER) {
+        const float* src = hf ? xrow : hrow;
 #pragma unroll
-    for (int k = 0; k < 22; ++k) {
-        const float4 v = ((const float4*)(row + 88 * hf))[k];
-        xh[4 * k] = v.x; xh[4 * k + 1] = v.y; xh[4 * k + 2] = v.z; xh[4 * k + 3] = v.w;
+        for (int k = 0; k < 16; ++k) {
+            const float4 v = ((const float4*)src)[k];
+            xh[4 * k] = v.x; xh[4 * k + 1] = v.y; xh[4 * k + 2] = v.z; xh[4 * k + 3] = v.w;
+        }
+        // half 0: he = PE(rho_i[p], O[m]); half 1: xe = PE(R[m], om_i[p])
+        pos_enc2(hf ? ga.R[gm] : ga.rho_i[gp], hf ? ga.om_i[gp] : ga.O[gm], xh + 64);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 22; ++k) {
+            const float4 v = ((const float4*)(row + 88 * hf))[k];
+            xh[4 * k] = v.x; xh[4 * k + 1] = v.y; xh[4 * k + 2] = v.z; xh[4 * k + 3] = v.w;
+        }
     }
     float hid[32];  // hid[16*blk + q] = unit (q&3) + 8*(q>>2) + 4*hf + 32*blk
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 v = *(const float4*)(row + 32 * blk + 8 * g4 + 4 * hf);
+            const float4 v = *(const float4*)(hrow + 32 * blk + 8 * g4 + 4 * hf);
             hid[16 * blk + 4 * g4] = v.x; hid[16 * blk + 4 * g4 + 1] = v.y;
             hid[16 * blk + 4 * g4 + 2] = v.z; hid[16 * blk + 4 * g4 + 3] = v.w;
         }
@@ -116,7 +140,7 @@ __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __re
         } else {
 #pragma unroll
             for (int k = 0; k < 11; ++k) {
-                const float4 v = ((const float4*)(row + 88))[k];
+                const float4 v = ((const float4*)xrow)[k];       // x[0..44)
                 xt[4 * k] = v.x; xt[4 * k + 1] = v.y; xt[4 * k + 2] = v.z; xt[4 * k + 3] = v.w;
             }
         }
@@ -164,8 +188,22 @@ int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const flo
 {
     if (n_max <= 0) return FS_OK;
     const int groups = (n_max + 31) / 32;
-    hipLaunchKernelGGL(ptf_gru_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, cat, tables, fused);
+    hipLaunchKernelGGL(ptf_gru_kernel<false>, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, cat, GruGather{}, tables,
+                       fused);
     FS_CHECK_LAUNCH("ptf_gru_forward");
+    return FS_OK;
+}
+
+int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fuse_idx, const long long* fuse_pix,
+                          const float* G, const float* R, const float* O, const float* g_i, const float* rho_i,
+                          const float* om_i, const float* tables, float* fused, hipStream_t st)
+{
+    if (n_max <= 0) return FS_OK;
+    const int groups = (n_max + 31) / 32;
+    const GruGather ga{fuse_idx, fuse_pix, G, R, O, g_i, rho_i, om_i};
+    hipLaunchKernelGGL(ptf_gru_kernel<true>, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, (const float*)nullptr, ga,
+                       tables, fused);
+    FS_CHECK_LAUNCH("ptf_gru_gather");
     return FS_OK;
 }
 
