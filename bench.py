@@ -235,7 +235,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         "config": {"workload": workload, "mode": mode, "image_hw": [H, W], "gaussians": N,
                    "sh_degree": 2, "views_per_step_per_gpu": views, "raster_streams": R_NUM_STREAMS,
                    "blend_exp": "hardware v_exp_f32" if _R_FAST() else "contract polynomial",
-                   "instances_per_view": int(n_inst),
+                   "instances_per_view": int(n_inst), "instances_per_gaussian": round(n_inst / max(N, 1), 2),
                    "parallelism": f"view-sharded x{world}" + (f" + {args.grad_exchange}(gaussian grads)" if exchange else
                                                               (" + all_gather(color,depth)" if args.gather_depth else " + all_gather(color)") if gather else "")},
     }
