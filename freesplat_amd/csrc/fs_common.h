@@ -159,6 +159,17 @@ __device__ __forceinline__ f32x2 blend_exp_of_neg(f32x2 q)
         return fs_exp2_of_neg(q);
     }
 }
+// Guard band of the hardware-exp mode around the alpha threshold 1/255 (bits 0x3B808081): alpha from v_exp_f32 and
+// alpha from the contract exp differ by at most ~7 ulp (rounding of q * log2(e) at |q| <= 5.6: 2.8 ulp; the constant: 1;
+// v_exp_f32: 1; the contract exp: 1; the product with the opacity: 0.5 each), so a value outside
+// [1/255 - 16 ulp, 1/255 + 16 ulp) falls on the same side of the threshold in both modes.  A step with any value
+// inside the band is re-evaluated with the contract exp: the accept / reject decisions of the hardware-exp mode are
+// those of the exact mode, what remains is the ~4e-7 relative difference of the accepted alphas.
+constexpr uint32_t kAlphaMinBits = 0x3B808081u;  // 1.0f / 255.0f
+constexpr uint32_t kAlphaGuardUlps = 16u;
+__device__ __forceinline__ float alpha_guard_lo() { return __uint_as_float(kAlphaMinBits - kAlphaGuardUlps); }
+__device__ __forceinline__ float alpha_guard_hi() { return __uint_as_float(kAlphaMinBits + kAlphaGuardUlps); }
+
 // Skip threshold of a record (r1.z: power below it cannot reach alpha >= 1/255) as the bit pattern the unsigned compare
 // uses: -threshold for a negative threshold; 0 otherwise (opacity <= 1/255: only q == +0 passes, and fails the alpha test).
 __device__ __forceinline__ float skip_bits(float thr) { return thr < 0.0f ? -thr : 0.0f; }

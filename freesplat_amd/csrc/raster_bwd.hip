@@ -173,9 +173,20 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
             on_a = on_a & (__float_as_uint(pw.x) <= __float_as_uint(c2.z));
             on_b = on_b & (__float_as_uint(pw.y) <= __float_as_uint(c2.w));
             if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) continue;  // wave-uniform
-            const f32x2 Gr = blend_exp_of_neg<FAST_EXP>(pw);
-            const f32x2 oe = (f32x2){c3.x, c3.y} * Gr;
-            const f32x2 al_raw = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+            f32x2 Gr = blend_exp_of_neg<FAST_EXP>(pw);
+            f32x2 oe = (f32x2){c3.x, c3.y} * Gr;
+            f32x2 al_raw = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+            if constexpr (FAST_EXP) {
+                // an alpha inside the guard band of the 1/255 threshold (fs_common.h): the pair is re-evaluated with the
+                // contract exp, so the accept / reject decisions are those of the exact mode (and of the forward)
+                const float glo = alpha_guard_lo(), ghi = alpha_guard_hi();
+                const bool nb = (on_a & (al_raw.x >= glo) & !(al_raw.x >= ghi)) | (on_b & (al_raw.y >= glo) & !(al_raw.y >= ghi));
+                if (__builtin_amdgcn_ballot_w64(nb) != 0) {  // wave-uniform, rare
+                    Gr = blend_exp_of_neg<false>(pw);
+                    oe = (f32x2){c3.x, c3.y} * Gr;
+                    al_raw = (f32x2){fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+                }
+            }
             on_a = on_a & (al_raw.x >= 1.0f / 255.0f);
             on_b = on_b & (al_raw.y >= 1.0f / 255.0f);
             if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) continue;

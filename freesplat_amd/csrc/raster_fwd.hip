@@ -1024,10 +1024,10 @@ __global__ __launch_bounds__(64) void render_kernel(
         // Two slots (four survivors) per step: the two packed exponent/exp chains are independent, so the
         // scheduler interleaves them (no dependent-issue bubbles); the blend itself stays strictly in list order.
         const int nslots = (cnt + 1) >> 1;
-#define FS_BLEND_ONE(COND, AL, OM, KR, POS)                                                         \
+#define FS_BLEND_ONE(COND, AL, OM, KR, POS, GE)                                                     \
         {                                                                                           \
             const float test_T = T_ * (OM);                                                         \
-            const bool vis = (COND) & !done & ((AL) >= 1.0f / 255.0f);                              \
+            const bool vis = (COND) & !done & (GE);            /* GE: alpha >= 1/255 */             \
             const bool ok = vis & (test_T >= 0.0001f);                                              \
             done = done | (vis ^ ok);                                                               \
             const f32x2 wgt = splat2(ok ? (AL) * T_ : 0.0f); /* weight 0: sums unchanged (finite colours) */ \
@@ -1054,15 +1054,32 @@ __global__ __launch_bounds__(64) void render_kernel(
             const bool cd = has_d & (__float_as_uint(pv.y) <= __float_as_uint(e2.w));
             if (__builtin_amdgcn_ballot_w64(((ca | cb) | (cc | cd)) & !done) == 0) continue;  // wave-uniform
             const float4 ka = q[4], kb = q[5], kc = q[10], kd = q[11];
-            const f32x2 ew = blend_exp_of_neg<FAST_EXP>(pw), ev = blend_exp_of_neg<FAST_EXP>(pv);
-            const f32x2 ow = (f32x2){c3.x, c3.y} * ew, ov = (f32x2){e3.x, e3.y} * ev;
-            const f32x2 aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
-            const f32x2 av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
+            f32x2 ew = blend_exp_of_neg<FAST_EXP>(pw), ev = blend_exp_of_neg<FAST_EXP>(pv);
+            f32x2 ow = (f32x2){c3.x, c3.y} * ew, ov = (f32x2){e3.x, e3.y} * ev;
+            f32x2 aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
+            f32x2 av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
+            bool ga, gb, gc, gd;   // alpha >= 1/255
+            if constexpr (FAST_EXP) {
+                // hardware exp; a step with an alpha inside the guard band of the 1/255 threshold (fs_common.h) is
+                // re-evaluated with the contract exp, so the accept / reject decisions are those of the exact mode
+                const float glo = alpha_guard_lo(), ghi = alpha_guard_hi();
+                ga = aw.x >= ghi; gb = aw.y >= ghi; gc = av.x >= ghi; gd = av.y >= ghi;   // nothing in [glo, ghi): same as >= 1/255
+                const bool nb = ((aw.x >= glo) & !ga) | ((aw.y >= glo) & !gb) | ((av.x >= glo) & !gc) | ((av.y >= glo) & !gd);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(nb) != 0, 0)) {  // wave-uniform, rare
+                    ew = blend_exp_of_neg<false>(pw); ev = blend_exp_of_neg<false>(pv);
+                    ow = (f32x2){c3.x, c3.y} * ew; ov = (f32x2){e3.x, e3.y} * ev;
+                    aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
+                    av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
+                    ga = aw.x >= 1.0f / 255.0f; gb = aw.y >= 1.0f / 255.0f; gc = av.x >= 1.0f / 255.0f; gd = av.y >= 1.0f / 255.0f;
+                }
+            } else {
+                ga = aw.x >= 1.0f / 255.0f; gb = aw.y >= 1.0f / 255.0f; gc = av.x >= 1.0f / 255.0f; gd = av.y >= 1.0f / 255.0f;
+            }
             const f32x2 mw = splat2(1.0f) - aw, mv = splat2(1.0f) - av;
-            FS_BLEND_ONE(ca, aw.x, mw.x, ka, c3.z)
-            FS_BLEND_ONE(cb, aw.y, mw.y, kb, c3.w)
-            FS_BLEND_ONE(cc, av.x, mv.x, kc, e3.z)
-            FS_BLEND_ONE(cd, av.y, mv.y, kd, e3.w)
+            FS_BLEND_ONE(ca, aw.x, mw.x, ka, c3.z, ga)
+            FS_BLEND_ONE(cb, aw.y, mw.y, kb, c3.w, gb)
+            FS_BLEND_ONE(cc, av.x, mv.x, kc, e3.z, gc)
+            FS_BLEND_ONE(cd, av.y, mv.y, kd, e3.w, gd)
         }
 #undef FS_BLEND_ONE
         // (the next batch's compaction overwrites the slots: DS operations of one wavefront execute in order)

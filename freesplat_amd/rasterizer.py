@@ -32,10 +32,11 @@ from . import _lib
 TILE_CULL = os.environ.get("FREESPLAT_TILE_CULL", "1") != "0"
 # Blend-loop exponential.  Default: the CPU-reproducible polynomial exp of the bit-exact contract (forward identical to
 # the oracle bit for bit).  FREESPLAT_FAST_EXP=1 (or rasterizer.FAST_EXP = True) selects the hardware v_exp_f32
-# (include/freesplat_amd.h FS_RASTER_FAST_EXP): +11 % views/s at config 3; lists / ordering / radii stay identical and
-# the image stays within ~1e-6 of the contract everywhere EXCEPT at a handful of pixels per view where the few-ulp
-# difference flips an alpha >= 1/255 or T >= 1e-4 decision (up to 4e-3 there; counted in tests and in bench.py's
-# `fast_exp` block) -- which is why it is opt-in.
+# (include/freesplat_amd.h FS_RASTER_FAST_EXP): +7 % views/s at config 3; lists / ordering / radii stay identical, the
+# alpha >= 1/255 decisions are those of the exact mode (guard band: a step with an alpha within 16 ulp of the threshold
+# is re-evaluated with the contract exp) and the image stays within ~1e-6 of the contract.  What is left is the
+# T >= 1e-4 termination: a flipped one changes a pixel by less than its remaining transmittance, 1e-4 x colour (about one
+# pixel per 2 M; counted in tests and in bench.py's `fast_exp` block).  Opt-in because it is not BIT-exact.
 FAST_EXP = os.environ.get("FREESPLAT_FAST_EXP", "0") == "1"
 # Views of one render_views call are spread round-robin over this many HIP streams so that the short
 # latency-bound launches of one view (tile scan, kernel tails) overlap the VALU-bound blend of another.

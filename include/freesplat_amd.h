@@ -84,11 +84,12 @@ typedef struct fs_raster_dims {
 #define FS_RASTER_SH_CHANNEL_MAJOR 4
 #define FS_RASTER_COV_FULL 8
 /* Hardware exponential (v_exp_f32, <= 1 ulp) in the blend loops of the forward AND the backward instead of the
- * CPU-reproducible polynomial exp of the bit-exact contract: 11 instead of 31 VALU cycles per (Gaussian, pixel) pair
- * on gfx950.  Tile ranges, list order and radii are unaffected; colours / depth / alpha move by ~1e-6, except at the few
- * pixels per view where the few-ulp difference flips an alpha >= 1/255 or T >= 1e-4 decision (up to 4e-3 there; counted
- * by tests/test_raster_hip.py and bench.py).  Off by default in the Python layer.  A forward and its backward must use
- * the same setting. */
+ * CPU-reproducible polynomial exp of the bit-exact contract: 11 instead of 26 VALU cycles per (Gaussian, pixel) pair
+ * on gfx950.  Tile ranges, list order and radii are unaffected, and so are the alpha >= 1/255 accept / reject decisions:
+ * a blend step with an alpha within 16 ulp of the threshold is re-evaluated with the contract exp.  Colours / depth /
+ * alpha move by ~1e-6; the remaining discontinuity is the T >= 1e-4 termination, whose flip changes a pixel by less
+ * than 1e-4 x colour (counted by tests/test_raster_hip.py and bench.py).  Off by default in the Python layer (not
+ * bit-exact).  A forward and its backward must use the same setting. */
 #define FS_RASTER_FAST_EXP 16
 
 /* Byte sizes of the four caller-owned device buffers for (N, H, W, instance capacity):
