@@ -945,7 +945,7 @@ constexpr int kPairQuads = 6;  // float4 per slot of two survivors
 __device__ unsigned long long g_render_trace[4 * 8192];
 #endif
 template <bool FAST_EXP>
-__global__ __launch_bounds__(64) void render_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void render_kernel(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
     const float* __restrict__ bg, const uint32_t* __restrict__ counters,

@@ -111,7 +111,9 @@ class AsyncViewGather:
     def wait(self) -> Optional[Tensor]:
         out, self.pending = self.pending, None
         if out is not None and self.cuda:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.stream)
+            out.record_stream(cur)   # allocated on the side stream, consumed on this one
         return out
 
 
