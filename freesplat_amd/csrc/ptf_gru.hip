@@ -23,11 +23,39 @@ namespace fs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// table layout (floats, each row = 64 lanes):
-//   [r1: 2*88][z1: 2*88][r2: 2*32][z2: 2*32][n1: 2*76][n2: 2*32] rows of A operands, then bias rows
-//   [b_r1: 2*16][b_z1: 2*16][b_r2: 2*16][b_z2: 2*16][b_n1: 2*16][b_n2: 2*16]
-constexpr int kR1 = 0, kZ1 = kR1 + 2 * 88, kR2 = kZ1 + 2 * 88, kZ2 = kR2 + 2 * 32, kN1 = kZ2 + 2 * 32,
-              kN2 = kN1 + 2 * 76, kBias = kN2 + 2 * 32, kRows = kBias + 6 * 32;
+// table layout (floats, each row = 64 lanes): the A-operand rows of the six matrices IN THE ORDER THE KERNEL CONSUMES
+// THEM (one row per MFMA), then the bias rows:
+//   [r1/z1: 88 steps x (r block 0, r block 1, z block 0, z block 1)][r2/z2: 32 x 4][n1: 76 x 2][n2: 32 x 2]   696 rows
+//   [pad to whole LDS chunks: 704][b_r1: 2*16][b_z1][b_r2][b_z2][b_n1][b_n2]                                   896 rows
+// All four wavefronts of a workgroup consume the same rows in the same order, so they reach the matrix pipe through a
+// two-chunk LDS ring: every wavefront fetches a quarter of the NEXT chunk (kCh rows) from L2 into kCh/4 registers while
+// the current chunk is being multiplied -- a prefetch distance of kCh MFMAs (2 k cycles), one barrier per chunk, a
+// quarter of the L2 traffic.  (With each wavefront streaming its own rows from L2 -- one 256-byte load per MFMA, issued
+// a few MFMAs ahead -- the matrix pipe waited half of the time or more: backward 749 -> 324 us per 157 k pairs.)
+constexpr int kCh = 32;
+constexpr int kP0 = 0, kP1 = kP0 + 4 * 88, kP2 = kP1 + 4 * 32, kP3 = kP2 + 2 * 76, kFwdUsed = kP3 + 2 * 32,
+              kFwdChunks = (kFwdUsed + kCh - 1) / kCh;
+constexpr int kBias = kFwdChunks * kCh, kRows = kBias + 6 * 32;
+static_assert(kFwdUsed == 696 && kBias == 704, "operand table layout");
+
+// The ring: G = this wavefront's rows of the chunk after the current one.  FS_AOP(pos) = operand row `pos` of the stream
+// (pos a compile-time constant after unrolling; the switch to a new chunk folds away everywhere else).
+#define FS_RING_SETUP(STREAM, NCHUNKS)                                                                                   \
+    __shared__ float s_ring[2 * kCh * 64];                                                                               \
+    float G[kCh / 4];                                                                                                    \
+    auto load_chunk = [&](int c) {                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < kCh / 4; ++j)                                                              \
+            G[j] = (STREAM)[(size_t)(c * kCh + wave * (kCh / 4) + j) * 64 + lane];                                       \
+    };                                                                                                                   \
+    auto switch_chunk = [&](int c) {   /* before the first operand of chunk c is read; G holds this wavefront's rows of it */ \
+        _Pragma("unroll") for (int j = 0; j < kCh / 4; ++j)                                                              \
+            s_ring[((c & 1) * kCh + wave * (kCh / 4) + j) * 64 + lane] = G[j];                                           \
+        if (c + 1 < (NCHUNKS)) load_chunk(c + 1);                                                                        \
+        __syncthreads();                                                                                                 \
+    };                                                                                                                   \
+    load_chunk(0);
+#define FS_AOP(pos) (((pos) % kCh == 0 ? switch_chunk((pos) / kCh) : (void)0), \
+                     s_ring[((((pos) / kCh) & 1) * kCh + (pos) % kCh) * 64 + lane])
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -41,19 +69,21 @@ struct GruGather {
     const long long *fuse_idx, *fuse_pix;
     const float *G, *R, *O, *g_i, *rho_i, *om_i;
 };
+// (two workgroups per CU: at one -- 407 registers if the compiler is left alone -- the fold is 7 % slower)
 template <bool GATHER>
-__global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __restrict__ counts,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ptf_gru_kernel(int n, const int32_t* __restrict__ counts,
                                                       const float* __restrict__ cat, GruGather ga,
                                                       const float* __restrict__ tab, float* __restrict__ fused)
 {
     if (counts) n = counts[1];  // (device-resident pair count: fs_ptf_fold_step)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = blockIdx.x * 4 + wave;
-    if (grp * 32 >= n) return;
+    if (blockIdx.x * 128 >= n) return;   // whole workgroup beyond n (a single wavefront beyond n stays for the barriers)
     const int p = lane & 31, hf = lane >> 5;
     const int t = grp * 32 + p;
     const bool live = t < n;
-    const float* T = tab + lane;  // T[r * 64] = row r of the tables for this lane
+    const float* T = tab + lane;  // T[r * 64] = row r of the tables for this lane (biases)
+    FS_RING_SETUP(tab, kFwdChunks)
     // sources of this pair: `row` = a materialised row, or (GATHER) the state latent / the view latent
     const float* row = GATHER ? nullptr : cat + (size_t)(live ? t : 0) * 176;
     const long long gm = GATHER ? ga.fuse_idx[live ? t : 0] : 0, gp = GATHER ? ga.fuse_pix[live ? t : 0] : 0;
@@ -98,10 +128,10 @@ __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __re
 #pragma unroll
     for (int s = 0; s < 88; ++s) {
         const float b = xh[s];
-        r0 = FS_MFMA(T[(kR1 + s) * 64], b, r0);
-        r1 = FS_MFMA(T[(kR1 + 88 + s) * 64], b, r1);
-        z0 = FS_MFMA(T[(kZ1 + s) * 64], b, z0);
-        z1 = FS_MFMA(T[(kZ1 + 88 + s) * 64], b, z1);
+        r0 = FS_MFMA(FS_AOP(kP0 + 4 * s), b, r0);
+        r1 = FS_MFMA(FS_AOP(kP0 + 4 * s + 1), b, r1);
+        z0 = FS_MFMA(FS_AOP(kP0 + 4 * s + 2), b, z0);
+        z1 = FS_MFMA(FS_AOP(kP0 + 4 * s + 3), b, z1);
     }
     // ---- layer 2 of r and z: k-step s <-> hidden unit held as register (s & 15) of block (s >> 4) ----
     f32x16 R0, R1, Z0, Z1;
@@ -114,10 +144,10 @@ __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __re
     for (int s = 0; s < 32; ++s) {
         const float br = fmaxf(s < 16 ? r0[s & 15] : r1[s & 15], 0.0f);
         const float bz = fmaxf(s < 16 ? z0[s & 15] : z1[s & 15], 0.0f);
-        R0 = FS_MFMA(T[(kR2 + s) * 64], br, R0);
-        R1 = FS_MFMA(T[(kR2 + 32 + s) * 64], br, R1);
-        Z0 = FS_MFMA(T[(kZ2 + s) * 64], bz, Z0);
-        Z1 = FS_MFMA(T[(kZ2 + 32 + s) * 64], bz, Z1);
+        R0 = FS_MFMA(FS_AOP(kP1 + 4 * s), br, R0);
+        R1 = FS_MFMA(FS_AOP(kP1 + 4 * s + 1), br, R1);
+        Z0 = FS_MFMA(FS_AOP(kP1 + 4 * s + 2), bz, Z0);
+        Z1 = FS_MFMA(FS_AOP(kP1 + 4 * s + 3), bz, Z1);
     }
     // ---- mlp_n layer 1: [r * hid (64) | x (64) | xe (24)] = 32 + 44 k-steps ----
     f32x16 n0, n1;
@@ -129,8 +159,8 @@ __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __re
     for (int s = 0; s < 32; ++s) {
         const float rr = sigmoidf_(s < 16 ? R0[s & 15] : R1[s & 15]);
         const float b = rr * hid[s];
-        n0 = FS_MFMA(T[(kN1 + s) * 64], b, n0);
-        n1 = FS_MFMA(T[(kN1 + 76 + s) * 64], b, n1);
+        n0 = FS_MFMA(FS_AOP(kP2 + 2 * s), b, n0);
+        n1 = FS_MFMA(FS_AOP(kP2 + 2 * s + 1), b, n1);
     }
     {   // tail inputs cat[88 + s + 44*hf], s < 44: half 1 already holds them (xh[44..88)), half 0 loads them
         float xt[44];
@@ -146,8 +176,8 @@ __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __re
         }
 #pragma unroll
         for (int s = 0; s < 44; ++s) {
-            n0 = FS_MFMA(T[(kN1 + 32 + s) * 64], xt[s], n0);
-            n1 = FS_MFMA(T[(kN1 + 76 + 32 + s) * 64], xt[s], n1);
+            n0 = FS_MFMA(FS_AOP(kP2 + 64 + 2 * s), xt[s], n0);
+            n1 = FS_MFMA(FS_AOP(kP2 + 64 + 2 * s + 1), xt[s], n1);
         }
     }
     // ---- mlp_n layer 2 ----
@@ -159,8 +189,8 @@ __global__ __launch_bounds__(256) void ptf_gru_kernel(int n, const int32_t* __re
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
         const float b = fmaxf(s < 16 ? n0[s & 15] : n1[s & 15], 0.0f);
-        N0 = FS_MFMA(T[(kN2 + s) * 64], b, N0);
-        N1 = FS_MFMA(T[(kN2 + 32 + s) * 64], b, N1);
+        N0 = FS_MFMA(FS_AOP(kP3 + 2 * s), b, N0);
+        N1 = FS_MFMA(FS_AOP(kP3 + 2 * s + 1), b, N1);
     }
     // ---- gates: out = (1 - z) * hid + z * tanh(q), lane holds 32 units of its pair ----
     if (live) {
@@ -207,6 +237,286 @@ int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fus
     return FS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward of the GRU, same organisation: one wavefront owns 32 pairs, lane = (pair, half), every value of a pair
+// stays in its own lanes.  The forward is re-run from the materialised input rows (keeping r, z, q, the ReLU masks as
+// bit fields), then every linear layer runs TRANSPOSED once more -- dX^T = W^T dY^T: the A operand is the table of
+// W^T in operand order, the B operand is dY straight from registers with the k order = accumulator row map, exactly
+// the trick of the forward's second layers -- so the input gradient dcat[n,176] needs no cross-lane traffic either:
+// 696 (forward) + 768 (transposed) MFMAs per 32 pairs.  The weight gradients are sums over ALL pairs of outer products
+// dY (x) X (44 928 accumulators -- 702 registers per lane if a wavefront kept them), so the kernel writes the six
+// pre-activation gradients and the four hidden activations they pair with into `side` [n,640]
+//   [dr1 | dz1 | dR | dZ | dn1 | dN | relu(r1) | relu(z1) | relu(n1) | r*hid]            (64 floats each)
+// and the caller forms dW = dY^T X with six library GEMMs whose contraction runs over n (ptf.py:_PtfFold.backward).
+//
+// transposed tables (rows of 64 lanes; lane (p, hf) of row (rb, s) holds W[u(s, hf)][32 rb + p], u = the forward's
+// accumulator unit map; 0 outside the matrix):
+//   [n2T: 2*32][n1T, r*hid rows: 2*32][n1T in cat-feature rows, blocks 2..5: 4*32][r2T: 2*32][z2T: 2*32][r1T: 6*32][z1T: 6*32]
+constexpr int kTN2 = 0, kTN1H = kTN2 + 64, kTN1C = kTN1H + 64, kTR2 = kTN1C + 128, kTZ2 = kTR2 + 64, kTR1 = kTZ2 + 64,
+              kTZ1 = kTR1 + 192, kRowsT = kTZ1 + 192;
+constexpr int kSide = 640;
+// consumption order of the backward kernel's 1464 A-operand rows: the forward's 696 (re-run), then the transposed layers;
+// `stream` holds them in this order (the last chunk padded).  Positions of the transposed layers' first rows:
+constexpr int kP4 = kFwdUsed, kP5 = kP4 + 2 * 32, kP6 = kP5 + 6 * 32, kP7 = kP6 + 4 * 32, kStreamUsed = kP7 + 12 * 32,
+              kStreamChunks = (kStreamUsed + kCh - 1) / kCh;
+static_assert(kStreamUsed == 1464, "operand stream layout");
+
+__device__ __forceinline__ void store_acc(float* __restrict__ dst, int hf, const f32x16& a)   // units acc rows of one block
+{
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+        *(float4*)(dst + 8 * g4 + 4 * hf) = make_float4(a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]);
+}
+
+__global__ __launch_bounds__(256) void ptf_gru_bwd_kernel(int n, const float* __restrict__ cat, const float* __restrict__ tab,
+                                                          const float* __restrict__ stream, const float* __restrict__ g_fused,
+                                                          float* __restrict__ dcat, float* __restrict__ side)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = blockIdx.x * 4 + wave;
+    const int p = lane & 31, hf = lane >> 5;
+    const int t = grp * 32 + p;
+    const bool live = t < n;             // (a wavefront beyond n stays for the barriers, computes on row 0, stores nothing)
+    const size_t tr = (size_t)(live ? t : 0);
+    const float* T = tab + lane;         // biases
+    FS_RING_SETUP(stream, kStreamChunks)
+    const float* row = cat + tr * 176;
+    float* sd = side + tr * kSide;       // (dead pairs compute on row 0 and store nothing)
+
+    float hid[32];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 v = *(const float4*)(row + 32 * blk + 8 * g4 + 4 * hf);
+            hid[16 * blk + 4 * g4] = v.x; hid[16 * blk + 4 * g4 + 1] = v.y;
+            hid[16 * blk + 4 * g4 + 2] = v.z; hid[16 * blk + 4 * g4 + 3] = v.w;
+        }
+    // ================= forward, keeping what the backward needs =================
+    uint32_t mr = 0, mz = 0, mn = 0;     // ReLU masks of the three first layers, bit 16*blk + q
+    float rr[32], zz[32];
+    f32x16 n0, n1;
+    {
+        f32x16 r0, r1, z0, z1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            r0[q] = T[(kBias + 0 * 32 + q) * 64]; r1[q] = T[(kBias + 0 * 32 + 16 + q) * 64];
+            z0[q] = T[(kBias + 1 * 32 + q) * 64]; z1[q] = T[(kBias + 1 * 32 + 16 + q) * 64];
+        }
+        {
+            float xh[88];
+#pragma unroll
+            for (int k = 0; k < 22; ++k) {
+                const float4 v = ((const float4*)(row + 88 * hf))[k];
+                xh[4 * k] = v.x; xh[4 * k + 1] = v.y; xh[4 * k + 2] = v.z; xh[4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 88; ++s) {
+                const float b = xh[s];
+                r0 = FS_MFMA(FS_AOP(kP0 + 4 * s), b, r0);
+                r1 = FS_MFMA(FS_AOP(kP0 + 4 * s + 1), b, r1);
+                z0 = FS_MFMA(FS_AOP(kP0 + 4 * s + 2), b, z0);
+                z1 = FS_MFMA(FS_AOP(kP0 + 4 * s + 3), b, z1);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            mr |= (r0[q] > 0.0f ? 1u : 0u) << q;  mr |= (r1[q] > 0.0f ? 1u : 0u) << (16 + q);
+            mz |= (z0[q] > 0.0f ? 1u : 0u) << q;  mz |= (z1[q] > 0.0f ? 1u : 0u) << (16 + q);
+            r0[q] = fmaxf(r0[q], 0.0f); r1[q] = fmaxf(r1[q], 0.0f);
+            z0[q] = fmaxf(z0[q], 0.0f); z1[q] = fmaxf(z1[q], 0.0f);
+        }
+        if (live) {
+            store_acc(sd + 6 * 64, hf, r0); store_acc(sd + 6 * 64 + 32, hf, r1);
+            store_acc(sd + 7 * 64, hf, z0); store_acc(sd + 7 * 64 + 32, hf, z1);
+        }
+        f32x16 R0, R1, Z0, Z1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            R0[q] = T[(kBias + 2 * 32 + q) * 64]; R1[q] = T[(kBias + 2 * 32 + 16 + q) * 64];
+            Z0[q] = T[(kBias + 3 * 32 + q) * 64]; Z1[q] = T[(kBias + 3 * 32 + 16 + q) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float br = s < 16 ? r0[s & 15] : r1[s & 15];
+            const float bz = s < 16 ? z0[s & 15] : z1[s & 15];
+            R0 = FS_MFMA(FS_AOP(kP1 + 4 * s), br, R0);
+            R1 = FS_MFMA(FS_AOP(kP1 + 4 * s + 1), br, R1);
+            Z0 = FS_MFMA(FS_AOP(kP1 + 4 * s + 2), bz, Z0);
+            Z1 = FS_MFMA(FS_AOP(kP1 + 4 * s + 3), bz, Z1);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            rr[q] = sigmoidf_(R0[q]); rr[16 + q] = sigmoidf_(R1[q]);
+            zz[q] = sigmoidf_(Z0[q]); zz[16 + q] = sigmoidf_(Z1[q]);
+        }
+    }
+    {   // mlp_n layer 1
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            n0[q] = T[(kBias + 4 * 32 + q) * 64]; n1[q] = T[(kBias + 4 * 32 + 16 + q) * 64];
+        }
+        f32x16 h0, h1;   // r * hid, stored for the weight gradient of mlp_n layer 1
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float b = rr[s] * hid[s];
+            if (s < 16) h0[s & 15] = b; else h1[s & 15] = b;
+            n0 = FS_MFMA(FS_AOP(kP2 + 2 * s), b, n0);
+            n1 = FS_MFMA(FS_AOP(kP2 + 2 * s + 1), b, n1);
+        }
+        if (live) { store_acc(sd + 9 * 64, hf, h0); store_acc(sd + 9 * 64 + 32, hf, h1); }
+        float xt[44];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float4 v = ((const float4*)(row + 88 + 44 * hf))[k];
+            xt[4 * k] = v.x; xt[4 * k + 1] = v.y; xt[4 * k + 2] = v.z; xt[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 44; ++s) {
+            n0 = FS_MFMA(FS_AOP(kP2 + 64 + 2 * s), xt[s], n0);
+            n1 = FS_MFMA(FS_AOP(kP2 + 64 + 2 * s + 1), xt[s], n1);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            mn |= (n0[q] > 0.0f ? 1u : 0u) << q;  mn |= (n1[q] > 0.0f ? 1u : 0u) << (16 + q);
+            n0[q] = fmaxf(n0[q], 0.0f); n1[q] = fmaxf(n1[q], 0.0f);
+        }
+        if (live) { store_acc(sd + 8 * 64, hf, n0); store_acc(sd + 8 * 64 + 32, hf, n1); }
+    }
+    f32x16 dN0, dN1, dZ0, dZ1;   // pre-activation gradients of the two output layers
+    float dh[32];                // gradient of hid through the gate (1 - z) * hid
+    {
+        f32x16 N0, N1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            N0[q] = T[(kBias + 5 * 32 + q) * 64]; N1[q] = T[(kBias + 5 * 32 + 16 + q) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float b = s < 16 ? n0[s & 15] : n1[s & 15];
+            N0 = FS_MFMA(FS_AOP(kP3 + 2 * s), b, N0);
+            N1 = FS_MFMA(FS_AOP(kP3 + 2 * s + 1), b, N1);
+        }
+        const float* go = g_fused + tr * 64;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 gv = *(const float4*)(go + 32 * blk + 8 * g4 + 4 * hf);
+                const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = 4 * g4 + e;
+                    const float g = live ? gq[e] : 0.0f;
+                    const float z = zz[16 * blk + q], h = hid[16 * blk + q];
+                    const float qq = tanhf(blk ? N1[q] : N0[q]);
+                    const float dn = g * z * (1.0f - qq * qq);
+                    const float dz = g * (qq - h) * z * (1.0f - z);
+                    if (blk) { dN1[q] = dn; dZ1[q] = dz; } else { dN0[q] = dn; dZ0[q] = dz; }
+                    dh[16 * blk + q] = g * (1.0f - z);
+                }
+            }
+    }
+    if (live) {
+        store_acc(sd + 5 * 64, hf, dN0); store_acc(sd + 5 * 64 + 32, hf, dN1);
+        store_acc(sd + 3 * 64, hf, dZ0); store_acc(sd + 3 * 64 + 32, hf, dZ1);
+    }
+    // ================= transposed layers =================
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 C2 = zero16, C3 = zero16, C4 = zero16, C5 = zero16;   // dcat feature blocks 2..5 (x | xe of mlp_n first)
+    f32x16 dR0, dR1;
+    {
+        // mlp_n layer 2: d relu(n1) = Wn2^T dN, masked -> dn1
+        f32x16 a0 = zero16, a1 = zero16;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float b = s < 16 ? dN0[s & 15] : dN1[s & 15];
+            a0 = FS_MFMA(FS_AOP(kP4 + 2 * s), b, a0);
+            a1 = FS_MFMA(FS_AOP(kP4 + 2 * s + 1), b, a1);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a0[q] = (mn >> q) & 1u ? a0[q] : 0.0f;
+            a1[q] = (mn >> (16 + q)) & 1u ? a1[q] : 0.0f;
+        }
+        if (live) { store_acc(sd + 4 * 64, hf, a0); store_acc(sd + 4 * 64 + 32, hf, a1); }
+        // mlp_n layer 1: d(r*hid) (2 blocks) and the x | xe part straight into its dcat blocks
+        f32x16 H0 = zero16, H1 = zero16;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float b = s < 16 ? a0[s & 15] : a1[s & 15];
+            H0 = FS_MFMA(FS_AOP(kP5 + 6 * s), b, H0);
+            H1 = FS_MFMA(FS_AOP(kP5 + 6 * s + 1), b, H1);
+            C2 = FS_MFMA(FS_AOP(kP5 + 6 * s + 2), b, C2);
+            C3 = FS_MFMA(FS_AOP(kP5 + 6 * s + 3), b, C3);
+            C4 = FS_MFMA(FS_AOP(kP5 + 6 * s + 4), b, C4);
+            C5 = FS_MFMA(FS_AOP(kP5 + 6 * s + 5), b, C5);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float r_0 = rr[q], r_1 = rr[16 + q];
+            dR0[q] = H0[q] * hid[q] * r_0 * (1.0f - r_0);
+            dR1[q] = H1[q] * hid[16 + q] * r_1 * (1.0f - r_1);
+            dh[q] += H0[q] * r_0;
+            dh[16 + q] += H1[q] * r_1;
+        }
+    }
+    if (live) { store_acc(sd + 2 * 64, hf, dR0); store_acc(sd + 2 * 64 + 32, hf, dR1); }
+    f32x16 e0 = zero16, e1 = zero16, f0 = zero16, f1 = zero16;   // dr1, dz1 (first-layer pre-activation gradients)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const float br = s < 16 ? dR0[s & 15] : dR1[s & 15];
+        const float bz = s < 16 ? dZ0[s & 15] : dZ1[s & 15];
+        e0 = FS_MFMA(FS_AOP(kP6 + 4 * s), br, e0);
+        e1 = FS_MFMA(FS_AOP(kP6 + 4 * s + 1), br, e1);
+        f0 = FS_MFMA(FS_AOP(kP6 + 4 * s + 2), bz, f0);
+        f1 = FS_MFMA(FS_AOP(kP6 + 4 * s + 3), bz, f1);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        e0[q] = (mr >> q) & 1u ? e0[q] : 0.0f;  e1[q] = (mr >> (16 + q)) & 1u ? e1[q] : 0.0f;
+        f0[q] = (mz >> q) & 1u ? f0[q] : 0.0f;  f1[q] = (mz >> (16 + q)) & 1u ? f1[q] : 0.0f;
+    }
+    if (live) {
+        store_acc(sd + 0 * 64, hf, e0); store_acc(sd + 0 * 64 + 32, hf, e1);
+        store_acc(sd + 1 * 64, hf, f0); store_acc(sd + 1 * 64 + 32, hf, f1);
+    }
+    // first layers of r and z: all six feature blocks of dcat
+    f32x16 C0, C1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { C0[q] = dh[q]; C1[q] = dh[16 + q]; }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const float br = s < 16 ? e0[s & 15] : e1[s & 15];
+        const float bz = s < 16 ? f0[s & 15] : f1[s & 15];
+        C0 = FS_MFMA(FS_AOP(kP7 + 12 * s + 0), br, C0);  C0 = FS_MFMA(FS_AOP(kP7 + 12 * s + 1), bz, C0);
+        C1 = FS_MFMA(FS_AOP(kP7 + 12 * s + 2), br, C1);  C1 = FS_MFMA(FS_AOP(kP7 + 12 * s + 3), bz, C1);
+        C2 = FS_MFMA(FS_AOP(kP7 + 12 * s + 4), br, C2);  C2 = FS_MFMA(FS_AOP(kP7 + 12 * s + 5), bz, C2);
+        C3 = FS_MFMA(FS_AOP(kP7 + 12 * s + 6), br, C3);  C3 = FS_MFMA(FS_AOP(kP7 + 12 * s + 7), bz, C3);
+        C4 = FS_MFMA(FS_AOP(kP7 + 12 * s + 8), br, C4);  C4 = FS_MFMA(FS_AOP(kP7 + 12 * s + 9), bz, C4);
+        C5 = FS_MFMA(FS_AOP(kP7 + 12 * s + 10), br, C5);  C5 = FS_MFMA(FS_AOP(kP7 + 12 * s + 11), bz, C5);
+    }
+    if (live) {
+        float* dc = dcat + tr * 176;
+        store_acc(dc, hf, C0); store_acc(dc + 32, hf, C1); store_acc(dc + 64, hf, C2);
+        store_acc(dc + 96, hf, C3); store_acc(dc + 128, hf, C4);
+#pragma unroll
+        for (int g4 = 0; g4 < 2; ++g4)   // features 160 .. 175 of the last block
+            *(float4*)(dc + 160 + 8 * g4 + 4 * hf) = make_float4(C5[4 * g4], C5[4 * g4 + 1], C5[4 * g4 + 2], C5[4 * g4 + 3]);
+    }
+}
+
+int launch_ptf_gru_bwd(int n, const float* cat, const float* tables, const float* stream, const float* g_fused,
+                       float* dcat, float* side, hipStream_t st)
+{
+    if (n <= 0) return FS_OK;
+    const int groups = (n + 31) / 32;
+    hipLaunchKernelGGL(ptf_gru_bwd_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, tables, stream, g_fused, dcat, side);
+    FS_CHECK_LAUNCH("ptf_gru_backward");
+    return FS_OK;
+}
+
 }  // namespace fs
 
 using namespace fs;
@@ -221,4 +531,20 @@ FS_API int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, 
     hipStream_t st = (hipStream_t)stream_;
     ScopedStage prof_(kStPtf, st);
     return launch_ptf_gru(n, nullptr, cat, tables, fused, st);
+}
+
+FS_API int32_t fs_ptf_gru_table_t_rows(void) { return kRowsT; }
+FS_API int32_t fs_ptf_gru_side_cols(void) { return kSide; }
+
+FS_API int32_t fs_ptf_gru_stream_rows(void) { return kStreamChunks * kCh; }
+
+FS_API int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables, const float* operand_stream,
+                               const float* g_fused, float* dcat, float* side, void* stream_)
+{
+    if (n < 0) return FS_ERR_INVALID_ARG;
+    if (n == 0) return FS_OK;
+    if (!cat || !tables || !operand_stream || !g_fused || !dcat || !side) return FS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    ScopedStage prof_(kStPtf, st);
+    return launch_ptf_gru_bwd(n, cat, tables, operand_stream, g_fused, dcat, side, st);
 }

@@ -12,15 +12,17 @@ The fold is HIP in both modes (b = 1, the only shape the reference's indexing su
     positional encodings) -> GRU on the fp32 matrix cores -> next state, every data-dependent size device-resident;
     ONE host sync per fold (the reference: four per view);
   * backward (_PtfFold): per step, in reverse, fs_ptf_write_state_backward (density-weighted blends, keep / append
-    copies) and fs_ptf_gru_inputs_backward (gather + positional encodings) are HIP kernels; the GRU's own backward --
-    six plain linear layers, dW = dY^T X over ~10^5 pairs -- re-runs the GRU on the re-gathered input rows and lets
-    rocBLAS form the weight gradients (plain library GEMMs);
+    copies) and fs_ptf_gru_inputs_backward (gather + positional encodings) are HIP kernels, and so is the GRU's own
+    backward (fs_ptf_gru_backward: forward re-run + the six linear layers transposed, on the fp32 matrix cores, giving
+    the input-row gradients); only the weight gradients dW = dY^T X -- sums over ~10^5 pairs -- are library GEMMs on
+    the per-pair factors the kernel writes;
   * `fuse_gaussians_torch` keeps the op-by-op torch formulation (fs_ptf_match indices + autograd) for b > 1 inputs and
     as the cross-check of the HIP backward in tests/test_ptf_hip.py.
 """
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 from torch import Tensor, nn
@@ -84,18 +86,21 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
     return keep[:nk], fuse[:nf], fpix[:nf], app[:na]
 
 
-_table_cache: dict = {}
+# operand tables per GRU module, valid while the parameters keep their storage and version; weak keys: a table must not
+# outlive its module (a new module may get the same id(), the same parameter addresses and the same version counters)
+_table_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 LAST_FOLD_COUNTS = None   # device tensor [V,4] (kept, fused, appended, state rows) of the last fused fold: bench accounting
 
 
 def gru_tables(gru: "GRU") -> Tensor:
-    """The GRU's weights and biases in the MFMA operand order of csrc/ptf_gru.hip: rows of 64 lanes,
-    lane l = (p = l & 31, hf = l >> 5).  Cached per parameter version."""
+    """The GRU's weights and biases as MFMA operands of csrc/ptf_gru.hip: rows of 64 lanes, lane l = (p = l & 31,
+    hf = l >> 5), one row per MFMA in the order the kernel consumes them, then the bias rows.  Cached per parameter
+    version."""
     params = [gru.mlp_r[0].weight, gru.mlp_r[0].bias, gru.mlp_r[2].weight, gru.mlp_r[2].bias,
               gru.mlp_z[0].weight, gru.mlp_z[0].bias, gru.mlp_z[2].weight, gru.mlp_z[2].bias,
               gru.mlp_n[0].weight, gru.mlp_n[0].bias, gru.mlp_n[2].weight, gru.mlp_n[2].bias]
-    key = (id(gru), tuple((q.data_ptr(), q._version) for q in params))
-    hit = _table_cache.get(id(gru))
+    key = tuple((q.data_ptr(), q._version) for q in params)
+    hit = _table_cache.get(gru)
     if hit is not None and hit[0] == key:
         return hit[1]
     dev = params[0].device
@@ -124,12 +129,128 @@ def gru_tables(gru: "GRU") -> Tensor:
             q = torch.arange(16, device=dev)
             return torch.stack([bv[acc_row(q[:, None], hf[None, :]) + 32 * b] for b in range(2)])
 
-        tab = torch.cat([t.reshape(-1, 64) for t in (l1(Wr1), l1(Wz1), l2(Wr2), l2(Wz2), n1(Wn1), l2(Wn2),
-                                                     bias(br1), bias(bz1), bias(br2), bias(bz2), bias(bn1),
-                                                     bias(bn2))]).contiguous()
+        # one row per MFMA, in the order ptf_gru_kernel consumes them (the workgroup streams them through LDS once for
+        # its four wavefronts): per k-step the row blocks of the matrices that share the step's B operand
+        r1, z1, r2, z2, nn1, nn2 = l1(Wr1), l1(Wz1), l2(Wr2), l2(Wz2), n1(Wn1), l2(Wn2)       # [2 blocks, steps, 64]
+        il = lambda *ms: torch.stack([m[b] for m in ms for b in range(2)], dim=1).reshape(-1, 64)   # [steps * 2 * len(ms), 64]
+        ops = torch.cat([il(r1, z1), il(r2, z2), il(nn1), il(nn2)])
+        rows_b = _lib.lib().fs_ptf_gru_table_rows() - 6 * 32
+        assert ops.shape[0] == 696 <= rows_b
+        tab = torch.cat([ops, ops.new_zeros(rows_b - ops.shape[0], 64)] +
+                        [bias(bv).reshape(-1, 64) for bv in (br1, bz1, br2, bz2, bn1, bn2)]).contiguous()
     assert tab.shape[0] == _lib.lib().fs_ptf_gru_table_rows()
-    _table_cache[id(gru)] = (key, tab)
+    _table_cache[gru] = (key, tab)
     return tab
+
+
+_table_t_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def gru_tables_t(gru: "GRU") -> Tensor:
+    """The GRU's six weight matrices TRANSPOSED, in the MFMA operand order of csrc/ptf_gru.hip:ptf_gru_bwd_kernel:
+    row (rb, s) of a matrix, lane l = (p = l & 31, hf = l >> 5), holds W[u(s, hf)][32 rb + p] -- u = the forward's
+    accumulator unit map -- and 0 where 32 rb + p is not an input of that matrix.  mlp_n's first layer appears twice:
+    its r*hid columns as two row blocks of their own, its x | xe columns placed at their positions among the 176
+    features of the concatenated row (blocks 2..5), so that they accumulate straight into dcat.  Cached per parameter
+    version."""
+    params = _gru_params(gru)
+    key = tuple((q.data_ptr(), q._version) for q in params)
+    hit = _table_t_cache.get(gru)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    dev = params[0].device
+    with torch.no_grad():
+        Wr1, _, Wr2, _, Wz1, _, Wz2, _, Wn1, _, Wn2, _ = [q.detach().float() for q in params]
+        lane = torch.arange(64, device=dev)
+        pp, hf = lane & 31, lane >> 5
+        s = torch.arange(32, device=dev)
+        unit = ((s[:, None] & 15) & 3) + 8 * ((s[:, None] & 15) >> 2) + 4 * hf[None, :] + 32 * (s[:, None] >> 4)   # [32, 64]
+
+        def tr(W, blocks, col_of_feature=None):
+            """[blocks*32 rows, 64 lanes]: W[unit(s, hf), col(32 rb + p)], zero where the column does not exist."""
+            out = []
+            Wp = torch.cat([W, torch.zeros(W.shape[0], 1, device=dev)], dim=1)       # last column = 0 (the "no input" slot)
+            for rb in blocks:
+                f = 32 * rb + pp                                                     # feature of this lane's row
+                col = f if col_of_feature is None else col_of_feature(f)
+                col = torch.where((col >= 0) & (col < W.shape[1]), col, torch.full_like(col, W.shape[1]))
+                out.append(Wp[unit, col[None, :].expand_as(unit)])
+            return torch.cat(out)
+
+        n1_from_cat = lambda f: torch.where(f >= 88, f - 24, torch.full_like(f, -1))   # cat feature -> mlp_n input (x | xe)
+        tab = torch.cat([tr(Wn2, range(2)), tr(Wn1, range(2)), tr(Wn1, range(2, 6), n1_from_cat), tr(Wr2, range(2)),
+                         tr(Wz2, range(2)), tr(Wr1, range(6)), tr(Wz1, range(6))]).contiguous()
+    assert tab.shape == (_lib.lib().fs_ptf_gru_table_t_rows(), 64)
+    _table_t_cache[gru] = (key, tab)
+    return tab
+
+
+# first rows of the matrices in the transposed operand table (csrc/ptf_gru.hip)
+_KTN2, _KTN1H, _KTN1C, _KTR2, _KTZ2, _KTR1, _KTZ1 = 0, 64, 128, 256, 320, 384, 576
+_stream_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def gru_operand_stream(gru: "GRU") -> Tensor:
+    """The operand rows of ptf_gru_bwd_kernel in the order in which it consumes them: the 696 rows of the forward
+    (gru_tables, already in consumption order), then the transposed layers' rows (gru_tables_t) -- mlp_n second layer,
+    mlp_n first layer, r/z second layers, r/z first layers --, padded to whole LDS chunks."""
+    tab, tab_t = gru_tables(gru), gru_tables_t(gru)
+    hit = _stream_cache.get(gru)
+    if hit is not None and hit[0] is tab and hit[1] is tab_t:
+        return hit[2]
+    o = []
+    for s in range(32):
+        o += [_KTN2 + s, _KTN2 + 32 + s]
+    for s in range(32):
+        o += [_KTN1H + s, _KTN1H + 32 + s] + [_KTN1C + 32 * j + s for j in range(4)]
+    for s in range(32):
+        o += [_KTR2 + s, _KTR2 + 32 + s, _KTZ2 + s, _KTZ2 + 32 + s]
+    for s in range(32):
+        for rb in range(6):
+            o += [_KTR1 + 32 * rb + s, _KTZ1 + 32 * rb + s]
+    rows = _lib.lib().fs_ptf_gru_stream_rows()
+    assert 696 + len(o) == 1464 <= rows
+    stream = tab.new_zeros(rows, 64)
+    stream[:696] = tab[:696]
+    stream[696: 1464] = tab_t[torch.tensor(o, device=tab.device)]
+    _stream_cache[gru] = (tab, tab_t, stream)
+    return stream
+
+
+def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tensor, g_fused: Tensor):
+    """Backward of the GRU over n materialised input rows: fs_ptf_gru_backward (forward re-run + the six transposed
+    layers on the matrix cores) gives dcat [n,176] and the per-pair factors of the weight gradients; the weight and bias
+    gradients themselves -- sums over all pairs of outer products -- are six library GEMMs and six column sums.
+    Returns (dcat, [12 parameter gradients in the order of _gru_params])."""
+    L = _lib.lib()
+    p = _lib.ptr
+    n = cat.shape[0]
+    dev = cat.device
+    # the contraction of the weight gradients runs over the n pairs and their outputs are tiny (64 x 64 .. 128 x 176): as
+    # plain GEMMs they fill two workgroups.  Split K: rows padded with zeros to S equal chunks, one batched GEMM of S
+    # partial products per matrix, summed afterwards.
+    S = max(1, min(256, n // 256))
+    n_pad = -(-n // S) * S
+    cols = L.fs_ptf_gru_side_cols()
+    dcat = torch.empty(n, 176, dtype=torch.float32, device=dev)
+    side = torch.empty(n_pad, cols, dtype=torch.float32, device=dev)
+    if n_pad > n:
+        side[n:].zero_()
+        cat = torch.cat([cat, cat.new_zeros(n_pad - n, 176)])
+    g_fused = g_fused.contiguous()
+    _lib.check(L.fs_ptf_gru_backward(n, p(cat), p(tables), p(operand_stream), p(g_fused), p(dcat), p(side),
+                                     _lib.current_stream()), "fs_ptf_gru_backward")
+    sv, cv = side.view(S, n_pad // S, cols), cat.view(S, n_pad // S, 176)
+    blk = lambda k, m=1: sv[:, :, 64 * k: 64 * (k + m)]
+    tmm = lambda a, b: torch.bmm(a.transpose(1, 2), b).sum(dim=0)      # sum over chunks of a_chunk^T b_chunk
+    dr1, dz1, dR, dZ, dn1, dN, r1a, z1a, n1a, rh = (blk(k) for k in range(10))
+    g1 = tmm(blk(0, 2), cv)                            # [dr1 | dz1]^T cat: first layers of r and z in one product
+    gn1 = torch.cat([tmm(dn1, rh), tmm(dn1, cv[:, :, 88:])], dim=1)
+    bsum = side[:, :384].sum(dim=0)                    # the six bias gradients
+    grads = [g1[:64], bsum[0:64], tmm(dR, r1a), bsum[128:192],
+             g1[64:], bsum[64:128], tmm(dZ, z1a), bsum[192:256],
+             gn1, bsum[256:320], tmm(dN, n1a), bsum[320:384]]
+    return dcat, grads
 
 
 def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
@@ -196,7 +317,7 @@ class _PtfFold(torch.autograd.Function):
     D [n]."""
 
     @staticmethod
-    def forward(ctx, lat, xs, rho, om, dep, Es, Kn, h, w, depth_thres, tables, *params):
+    def forward(ctx, lat, xs, rho, om, dep, Es, Kn, h, w, depth_thres, tables, operand_stream, *params):
         L = _lib.lib()
         p = _lib.ptr
         V, P = lat.shape[0], lat.shape[1]
@@ -227,6 +348,7 @@ class _PtfFold(torch.autograd.Function):
         cnt[0] = [P, 0, 0, P]
         n = cnt[V - 1][3]
         ctx.cnt, ctx.hw, ctx.states, ctx.scratches = cnt, (h, w), states, scratches
+        ctx.tables, ctx.operand_stream = tables, operand_stream
         ctx.save_for_backward(lat, xs, rho, om, dep, Es, *params)
         G, X, R, O, E, D = state
         return G[:n], X[:n], E[:n], D[:n, 0]
@@ -261,18 +383,13 @@ class _PtfFold(torch.autograd.Function):
                 vp(g_out), vp(g_in), p(g_lat[i]), p(g_xs[i]), p(g_rho[i]), p(g_om[i]), p(g_dep[i]),
                 _lib.current_stream()), "fs_ptf_write_state_backward")
             if nf > 0:
-                # the GRU rows: re-gather their inputs (HIP), run the GRU's backward as plain library GEMMs
+                # the GRU rows: re-gather their inputs (HIP), GRU backward on the matrix cores (+ the weight-gradient GEMMs)
                 cat = torch.empty(nf, 176, dtype=torch.float32, device=dev)
                 _lib.check(L.fs_ptf_gru_inputs(nf, fuse, fpix, p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]), p(cat),
                                                _lib.current_stream()), "fs_ptf_gru_inputs")
                 g_fused = g_out[0][nk: nk + nf] if g_out[0] is not None else z(nf, 64)
-                with torch.enable_grad():
-                    cat_ = cat.requires_grad_(True)
-                    ps = [q.detach().requires_grad_(True) for q in params]
-                    fused = _gru_from_cat(ps, cat_)
-                    grads = torch.autograd.grad(fused, [cat_] + ps, g_fused)
-                dcat = grads[0].contiguous()
-                for k, gq in enumerate(grads[1:]):
+                dcat, grads = gru_backward(params, ctx.tables, ctx.operand_stream, cat, g_fused)
+                for k, gq in enumerate(grads):
                     g_params[k] = gq if g_params[k] is None else g_params[k] + gq
                 _lib.check(L.fs_ptf_gru_inputs_backward(nf, fuse, fpix, p(R), p(O), p(rho[i]), p(om[i]), p(dcat),
                                                         p(g_in[0]), p(g_in[2]), p(g_in[3]), p(g_lat[i]), p(g_rho[i]),
@@ -292,7 +409,7 @@ class _PtfFold(torch.autograd.Function):
         need = ctx.needs_input_grad
         pick = lambda k, t: t if need[k] else None
         return (pick(0, g_lat), pick(1, g_xs), pick(2, g_rho), pick(3, g_om), pick(4, g_dep), None, None, None, None,
-                None, None) + tuple(g if need[11 + k] else None for k, g in enumerate(g_params))
+                None, None, None) + tuple(g if need[12 + k] else None for k, g in enumerate(g_params))
 
 
 def _fuse_gaussians_train(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
@@ -311,7 +428,8 @@ def _fuse_gaussians_train(gru, gaussians, coords, densities, weight_emb, depths,
     if V == 1:
         return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
     Kn = f32(intrinsics[0].detach()).reshape(V, 9)
-    G, X, E, D = _PtfFold.apply(lat, xs, rho, om, dep, Es, Kn, h, w, float(depth_thres), gru_tables(gru), *_gru_params(gru))
+    G, X, E, D = _PtfFold.apply(lat, xs, rho, om, dep, Es, Kn, h, w, float(depth_thres), gru_tables(gru),
+                                gru_operand_stream(gru), *_gru_params(gru))
     n = G.shape[0]
     return G[None], X[None], E.view(1, n, 4, 4), D[None]
 

@@ -281,6 +281,23 @@ int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const float* 
 int32_t fs_ptf_gru_table_rows(void);
 int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, float* fused, void* stream);
 
+/* Backward of the GRU on the fp32 matrix cores (autograd of networks.py:201-214 w.r.t. its input rows): the forward
+ * is re-run from cat[n,176], then every linear layer runs transposed (dX^T = W^T dY^T).  `operand_stream` =
+ * fs_ptf_gru_stream_rows() rows of 64 floats: the forward's operand rows (`tables`) followed by the rows of the six
+ * transposed matrices (fs_ptf_gru_table_t_rows() of them), re-ordered into the order in which the kernel consumes
+ * them -- the workgroup streams them through LDS once for its four wavefronts (layout: csrc/ptf_gru.hip; builders:
+ * freesplat_amd/ptf.py:gru_tables_t, gru_operand_stream).  `tables` supplies the biases.
+ * g_fused[n,64] = gradient of the GRU output -> dcat[n,176] = gradient of the input rows (fed to
+ * fs_ptf_gru_inputs_backward), and side[n, fs_ptf_gru_side_cols()] =
+ *   [dr1 | dz1 | dR | dZ | dn1 | dN | relu(r1) | relu(z1) | relu(n1) | r*hid]   (64 floats each)
+ * the pre-activation gradients of the six layers and the hidden activations they pair with: the weight gradients
+ * dW = dY^T X (contraction over the n pairs) are left to the caller's GEMM library. */
+int32_t fs_ptf_gru_table_t_rows(void);
+int32_t fs_ptf_gru_stream_rows(void);
+int32_t fs_ptf_gru_side_cols(void);
+int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables, const float* operand_stream,
+                        const float* g_fused, float* dcat, float* side, void* stream);
+
 /* ------------------------------------------------------------------------------------ *
  * Gaussian adapter steps either side of PTF                                             *
  * ------------------------------------------------------------------------------------ */

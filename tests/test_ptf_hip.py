@@ -175,3 +175,31 @@ def test_fold_backward_with_tied_winners(hip_device):
         res.append([t.grad for t in ins])
     for a, b in zip(*res):
         assert (a - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-20)
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 130, 5000])
+def test_gru_backward_kernel_vs_autograd(hip_device, n):
+    """fs_ptf_gru_backward (forward re-run + the six transposed layers on the matrix cores, ragged last group of 32) and
+    the weight-gradient GEMMs on its per-pair factors, against torch autograd of the same GRU (networks.py:201-214) on
+    the same rows: input-row gradient and all 12 parameter gradients within 1e-4 of each one's max-abs."""
+    from freesplat_amd import ptf as P
+    torch.manual_seed(100 + n)
+    gru = P.GRU().to(hip_device)
+    with torch.no_grad():
+        for q in gru.parameters():
+            q.mul_(1.5)                              # push more units through the ReLU / gate non-linearities
+    cat = torch.randn(n, 176, device=hip_device)
+    cat[:, 64:88] = torch.sin(cat[:, 64:88] * 3.0)   # positional-encoding-like ranges
+    cat[:, 152:] = torch.cos(cat[:, 152:] * 3.0)
+    g = torch.randn(n, 64, device=hip_device)
+    params = P._gru_params(gru)
+    dcat, grads = P.gru_backward(params, P.gru_tables(gru), P.gru_operand_stream(gru), cat, g)
+    cat_ = cat.clone().requires_grad_(True)
+    ps = [q.detach().clone().requires_grad_(True) for q in params]
+    ref = torch.autograd.grad(P._gru_from_cat(ps, cat_), [cat_] + ps, g)
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-20))
+    worst = {"dcat": rel(dcat, ref[0])}
+    for k, (a, b) in enumerate(zip(grads, ref[1:])):
+        assert a.shape == b.shape, k
+        worst[f"param{k}"] = rel(a, b)
+    assert max(worst.values()) < 1e-4, worst
