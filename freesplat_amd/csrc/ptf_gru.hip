@@ -57,7 +57,11 @@ static_assert(kFwdUsed == 696 && kBias == 704, "operand table layout");
 #define FS_AOP(pos) (((pos) % kCh == 0 ? switch_chunk((pos) / kCh) : (void)0), \
                      s_ring[((((pos) / kCh) & 1) * kCh + (pos) % kCh) * 64 + lane])
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// gates on the hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp each; |error| of a gate ~2e-7, the fold's bar is
+// 1e-4): the libm forms are ~30 VALU instructions each, 96 per lane and 32 pairs, and fp32 VALU work does not overlap
+// fp32 MFMA on this chip (-4 % kernel time)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
 
 #define FS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int e = 0; e < 4; ++e) {
                     const int q = 4 * g4 + e;
                     const float zz = sigmoidf_(blk ? Z1[q] : Z0[q]);
-                    const float qq = tanhf(blk ? N1[q] : N0[q]);
+                    const float qq = tanhf_(blk ? N1[q] : N0[q]);
                     const float h = hid[16 * blk + q];
                     v[e] = (1.0f - zz) * h + zz * qq;
                 }
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256) void ptf_gru_bwd_kernel(int n, const float* __
                     const int q = 4 * g4 + e;
                     const float g = live ? gq[e] : 0.0f;
                     const float z = zz[16 * blk + q], h = hid[16 * blk + q];
-                    const float qq = tanhf(blk ? N1[q] : N0[q]);
+                    const float qq = tanhf_(blk ? N1[q] : N0[q]);
                     const float dn = g * z * (1.0f - qq * qq);
                     const float dz = g * (qq - h) * z * (1.0f - z);
                     if (blk) { dN1[q] = dn; dZ1[q] = dz; } else { dN0[q] = dn; dZ0[q] = dz; }
