@@ -346,7 +346,8 @@ def cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=False):
             ro.set_exp_mode(False)
         d = np.abs(g - st_libm["color"]).max(axis=0)
         mse2 = float(((g.clip(0, 1) - st_libm["color"].clip(0, 1)) ** 2).mean())
-        parity["exp_contract"] = {"what": "HIP image (contract exp) vs the oracle with libm expf in the blend loop",
+        parity["exp_contract"] = {"what": "HIP image (" + ("guarded hardware exp" if _R.FAST_EXP else "contract exp")
+                                          + ") vs the oracle with libm expf in the blend loop",
                                   "max_abs": float(d.max()), "pixels_above_1e-4": int((d > 1e-4).sum()), "pixels": H * W,
                                   "psnr_db": "inf" if mse2 == 0 else float(-10 * np.log10(mse2))}
     return {
