@@ -63,6 +63,64 @@ __global__ __launch_bounds__(256) void cv_relayout_kernel(const float* __restric
     }
 }
 
+// accumulator row held by (reg r, half hf) of a 32x32 MFMA result (guide, "Fragment layout")
+__device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+// ---- source re-layout for the forward sweep, with the feature block of the MLP's first layer applied PER TEXEL ----
+// The first layer is linear in the averaged warped features, and those are linear in the source texels:
+//   W1f (sum_k s_k sum_tap w_tap v_tap) = sum_k s_k sum_tap w_tap (W1f v_tap),
+// so U = W1f v is formed once per source texel here (48 x 32 MACs x h*w texels: nothing) instead of once per
+// (pixel, plane) on the matrix cores (25 of the sweep's 41 MFMAs), and the sweep blends U with the bilinear weights it
+// computes anyway.  Per texel and lane half hf: REC = C/2 + 16 floats -- the C/2 features of parity hf, then the 16
+// units of U that the lane half holds as layer-2 operands (accumulator rows acc_row(r, hf)) -- stored SLOT-MAJOR:
+//   dst[map][y][s][x][hf][4],  s < REC/4  (float4 slot s of the record),
+// so that the 64 lanes of ONE tap load (32 neighbouring pixels x 2 halves, the same slot) read one contiguous KB when the
+// source is sampled at about its own resolution: 8 cache lines per instruction.  (Texel-major records, 160 B per half,
+// put every lane's 16 bytes in a line of its own -- 48 lines per instruction, re-walked by each of the 10 slot loads:
+// that version of the sweep was bound by the L1 and 1.6x SLOWER at config-3 scale than the one it replaced.)
+constexpr int kCvU = 16;
+// one thread per (map, texel): its C channel values are read once (coalesced along the pixel index), the 32 hidden
+// units are C FMAs each with the weights arriving as wave-uniform scalar loads, and the record leaves as REC/2 float4
+// stores (the two halves of a slot are adjacent: every touched line ends up fully written)
+template <int C>
+__global__ __launch_bounds__(256) void cv_relayout_project_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                  const float* __restrict__ w1, int h, int w, int n_maps)
+{
+    constexpr int HC = C / 2, REC = HC + kCvU, NS = REC / 4;
+    const int hw = h * w;
+    const long long total = (long long)n_maps * hw;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int pix = (int)(e % hw);
+        const long long map = e / hw;
+        const float* sp = src + (map * C) * hw + pix;
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = sp[(size_t)c * hw];
+        const int y = pix / w, x = pix % w;
+        float* const drow = dst + (((size_t)map * h + y) * NS * w + x) * 8;   // slot s at + s * w * 8, half hf at + hf * 4
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int s4 = 0; s4 < HC / 4; ++s4)
+                *(float4*)(drow + (size_t)s4 * w * 8 + hf * 4) =
+                    make_float4(v[2 * (4 * s4) + hf], v[2 * (4 * s4 + 1) + hf], v[2 * (4 * s4 + 2) + hf], v[2 * (4 * s4 + 3) + hf]);
+#pragma unroll
+            for (int u4 = 0; u4 < kCvU / 4; ++u4) {
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* wr = w1 + (size_t)acc_row(4 * u4 + q, hf) * (C + 1);
+                    float a = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) a = fmaf(wr[c], v[c], a);
+                    o[q] = a;
+                }
+                *(float4*)(drow + (size_t)(HC / 4 + u4) * w * 8 + hf * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
 // P = (K_src @ T_src<-cur)[:3, :] per (b, k)  (geometry_utils.py:78-80): computed once per call
 __global__ void cv_proj_kernel(int n, const float* __restrict__ src_Ks, const float* __restrict__ src_extrinsics,
                                float* __restrict__ P)
@@ -78,9 +136,6 @@ __global__ void cv_proj_kernel(int n, const float* __restrict__ src_Ks, const fl
 // LeakyReLU(0.01) = 0.505 x + 0.495 |x|: two VALU operations (|x| is a free source modifier).  fmaxf(x, 0.01 x) costs four
 // here (the multiply, the max and two NaN-canonicalising v_max that IEEE mode puts in front of it).
 __device__ __forceinline__ float lrelu(float x) { return fmaf(0.495f, fabsf(x), 0.505f * x); }
-
-// accumulator row held by (reg r, half hf) of a 32x32 MFMA result (guide, "Fragment layout")
-__device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 
 template <int HC>  // HC = C/2 channels per lane
 __global__ __launch_bounds__(256) void cost_volume_kernel(
@@ -240,6 +295,197 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
 #pragma unroll
         for (int s = 0; s < 16; ++s)
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], lrelu(acc[s]), acc2, 0, 0, 0);
+        // ---- layer 3 ----
+        float o = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o += w3r[r] * lrelu(acc2[r]);
+        o += __shfl_xor(o, 32, 64);
+        if (live && hf == 0) out[((size_t)b * D + d) * hw + pix] = o + b3v;
+#ifdef FS_CV_TRACE
+        FS_CV_T(t_end, o);
+        tr_g += t_gath - t_top;
+        tr_m += t_end - t_gath;
+#endif
+    }
+#ifdef FS_CV_TRACE
+    {
+        const int wid = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+        if (lane == 0 && wid < kCvTraceWaves) {
+            g_cv_trace[4 * wid] = tr_g; g_cv_trace[4 * wid + 1] = tr_m;
+            // [3]: shader ticks (s_memtime) << 32 | 100 MHz wall ticks of this wavefront's whole sweep -> effective clock
+            const unsigned long long dc = cv_stamp(rx) - tr_c0, dw = wall_clock64() - tr_w0;
+            g_cv_trace[4 * wid + 2] = (unsigned long long)(d1 - d0); g_cv_trace[4 * wid + 3] = (dc << 32) | (dw & 0xffffffffull);
+        }
+    }
+#endif
+}
+
+
+// The sweep with the first layer's feature block folded into the source records (cv_relayout_project_kernel): 16 MFMAs
+// per (32-pixel group, plane) instead of 41, 160 instead of 96 bytes per tap and lane.  Used for K = 1 (the reference's
+// two-view configurations): with more sources per view the extra tap bytes outweigh the 25 MFMAs saved per plane
+// (config-3 scale, K = 2: on par; 10 views, K = 8: 18 % slower than the sweep above).
+template <int HC>  // HC = C/2 channels per lane
+__global__ __launch_bounds__(256) void cost_volume_proj_kernel(
+    int B, int K, int h, int w, int D, const float* __restrict__ curT, const float* __restrict__ srcT,
+    const float* __restrict__ Pmat,
+    const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
+    long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
+    const float* __restrict__ b3, float* __restrict__ out)
+{
+    constexpr int C = 2 * HC;
+    const int hw = h * w;
+    const int groups = (hw + 31) / 32;
+    const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane & 31, hf = lane >> 5;
+    const int pix = grp * 32 + p;
+    const bool live = pix < hw;
+    const int pu = live ? pix % w : 0, pv = live ? pix / w : 0;
+
+    // ---- MLP weights in registers: layer 2 in MFMA A-operand order; of layer 1 only the dot column and the bias (its
+    //      feature block is already folded into the source records, cv_relayout_project_kernel) ----
+    float a2[16], w3r[16], b2r[16], w1d[16], b1r[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        a2[s] = w2[p * 32 + acc_row(s, hf)];  // W2[i=p][k = unit held as reg s by half hf]
+        w3r[s] = w3[acc_row(s, hf)];
+        b2r[s] = b2[acc_row(s, hf)];
+        w1d[s] = w1[acc_row(s, hf) * (C + 1) + C];
+        b1r[s] = b1[acc_row(s, hf)];
+    }
+    const float b3v = b3[0];
+
+    // ---- current-view feature (this lane's parity) ----
+    float cur[HC];
+    {
+        const float4* q = (const float4*)(curT + ((size_t)b * hw + (live ? pix : 0)) * C + (size_t)hf * HC);
+#pragma unroll
+        for (int s = 0; s < HC / 4; ++s) {
+            const float4 v = q[s];
+            cur[4 * s] = v.x; cur[4 * s + 1] = v.y; cur[4 * s + 2] = v.z; cur[4 * s + 3] = v.w;
+        }
+    }
+    // ---- ray r = invK[:3,:3] (u+.5, v+.5, 1) ----
+    const float* iK = cur_invK + (size_t)b * 16;
+    const float ux = (float)pu + 0.5f, vy = (float)pv + 0.5f;
+    const float rx = iK[0] * ux + iK[1] * vy + iK[2];
+    const float ry = iK[4] * ux + iK[5] * vy + iK[6];
+    const float rz = iK[8] * ux + iK[9] * vy + iK[10];
+
+    const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
+    // planes [d0, d1) of this wavefront: gridDim.y * 4 wavefronts share the D planes of a pixel group
+    const int dchunk = (D + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4);
+    const int d0 = min(D, ((int)blockIdx.y * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
+
+    // Per plane the sweep used to pay three dependent memory round trips before its first MFMA: the plane's depth,
+    // the projection rows (scalar loads), then the taps.  The depth is now fetched one plane ahead and the projection
+    // rows of the first two sources stay in SGPRs for the whole sweep (the shipped configs have K <= 2 except the
+    // 9-nearest selection of config 4).
+    const float* pl = planes + b * ps_b + (live ? pix : 0) * ps_p;
+    float depth_next = d0 < d1 ? pl[d0 * ps_d] : 0.0f;
+    float P0[12], P1[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        P0[e] = Pmat[((size_t)b * K) * 12 + e];
+        P1[e] = K > 1 ? Pmat[((size_t)b * K + 1) * 12 + e] : 0.0f;
+    }
+#ifdef FS_CV_TRACE
+    unsigned long long tr_g = 0, tr_m = 0;
+    const unsigned long long tr_c0 = cv_stamp(rx), tr_w0 = wall_clock64();
+#endif
+    for (int d = d0; d < d1; ++d) {
+        FS_CV_T(t_top, rx);
+        const float depth = depth_next;
+        depth_next = pl[min(d + 1, d1 - 1) * ps_d];
+        float uavg[kCvU];   // sum over the valid sources of the bilinearly blended U (this half's 16 hidden units)
+#pragma unroll
+        for (int r = 0; r < kCvU; ++r) uavg[r] = 0.0f;
+        float dot_sum = 0.0f, cnt = 0.0f;
+        auto one_source = [&](int k, const float* P) __attribute__((always_inline)) {
+
+            // world point = depth * r (homogeneous 1): geometry_utils.py:56-58
+            const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+            const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+            const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+            const float qz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+            const float zz = qz + 1e-8f;                                  // :84
+            const float sc = (fabsf(qz) > 1e-8f) ? 1.0f / zz : 1.0f;       // :83,85
+            // cost_volume.py:536: uv = 2 * pix * (1/size) - 1, then grid_sample(align_corners=False)
+            // un-normalises with ((uv + 1) * size - 1) / 2 (= pix - 0.5 in exact arithmetic).  The
+            // reference's rounding sequence is mirrored op by op (no contraction): whether a tap is just
+            // inside or outside the source image decides `dot != 0`, i.e. the validity count.
+            const float uvx = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qx, sc)), inv_w), 1.0f);
+            const float uvy = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qy, sc)), inv_h), 1.0f);
+            const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvx, 1.0f), (float)w), 1.0f), 0.5f);
+            const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvy, 1.0f), (float)h), 1.0f), 0.5f);
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const float tx = ix - fx0, ty = iy - fy0;
+            // NaN/inf coordinates sample nothing (comparisons false)
+            const bool xin0 = fx0 >= 0.0f && fx0 <= (float)(w - 1), xin1 = fx0 >= -1.0f && fx0 <= (float)(w - 2);
+            const bool yin0 = fy0 >= 0.0f && fy0 <= (float)(h - 1), yin1 = fy0 >= -1.0f && fy0 <= (float)(h - 2);
+            const int x0 = xin0 || xin1 ? (int)fx0 : 0, y0 = yin0 || yin1 ? (int)fy0 : 0;
+            // wave-uniform map base (SGPR pair) + a 32-bit per-lane byte offset: one address add per tap instead of
+            // 64-bit multiply-adds (a source map is far below 4 GB)
+            // slot-major records (cv_relayout_project_kernel): float4 slot s of texel (x, y), half hf, at
+            //   ((y * NS + s) * w + x) * 32 + hf * 16 bytes: the slot term is wave-uniform (scalar base per slot)
+            constexpr int REC = HC + kCvU, NS = REC / 4;
+            const char* base = (const char*)(srcT + (((size_t)b * K + k) * hw) * (2 * REC));
+            const uint32_t off0 = (uint32_t)((y0 * NS * w + x0) * 8 + hf * 4) * 4u;
+            const uint32_t slotb = (uint32_t)w * 32u;                        // bytes between consecutive slots of a row
+            // dot_k = warped . cur = sum_tap w_tap (v_tap . cur): the warped features themselves are never formed
+            float part = 0.0f, ub[kCvU];
+#pragma unroll
+            for (int r = 0; r < kCvU; ++r) ub[r] = 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const int ox = tap & 1, oy = tap >> 1;
+                const bool ok = live && (ox ? xin1 : xin0) && (oy ? yin1 : yin0);
+                const float wt = (ox ? tx : 1.0f - tx) * (oy ? ty : 1.0f - ty);
+                if (ok) {
+                    const uint32_t offt = off0 + (uint32_t)((oy * NS * w + ox) * 8) * 4u;
+                    float td = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < HC / 4; ++s) {
+                        const float4 v = *(const float4*)(base + (size_t)s * slotb + offt);
+                        td += v.x * cur[4 * s]; td += v.y * cur[4 * s + 1];
+                        td += v.z * cur[4 * s + 2]; td += v.w * cur[4 * s + 3];
+                    }
+                    part += wt * td;
+#pragma unroll
+                    for (int s = 0; s < kCvU / 4; ++s) {
+                        const float4 u = *(const float4*)(base + (size_t)(HC / 4 + s) * slotb + offt);
+                        ub[4 * s] += wt * u.x; ub[4 * s + 1] += wt * u.y;
+                        ub[4 * s + 2] += wt * u.z; ub[4 * s + 3] += wt * u.w;
+                    }
+                }
+            }
+            float dotk = part + __shfl_xor(part, 32, 64);
+            dotk = (zz > 0.0f) ? dotk : 0.0f;                             // cost_volume.py:571-572,589-593
+            const bool valid = dotk != 0.0f;                              // :595 (exact zero test)
+            if (valid) {
+                cnt += 1.0f;
+                dot_sum += dotk;
+#pragma unroll
+                for (int r = 0; r < kCvU; ++r) uavg[r] += ub[r];
+            }
+        
+        };
+        one_source(0, P0);
+        if (K > 1) one_source(1, P1);
+        for (int k = 2; k < K; ++k) one_source(k, Pmat + ((size_t)b * K + k) * 12);
+        const float inv = 1.0f / (cnt + 1e-8f);                          // :595-598
+        FS_CV_T(t_gath, uavg[0] + uavg[kCvU - 1] + inv + dot_sum);
+        // ---- layer 1: z1 = W1f favg + w1d * dot_avg + b1 with W1f favg = blended U / cnt; this half's 16 units ----
+        const float dbar = dot_sum * inv;
+        // ---- layer 2: H2^T = W2 lrelu(H1)^T + b2, k order = accumulator row map ----
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = b2r[r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], lrelu(fmaf(uavg[s], inv, fmaf(w1d[s], dbar, b1r[s]))), acc2, 0, 0, 0);
         // ---- layer 3 ----
         float o = 0.0f;
 #pragma unroll
@@ -656,6 +902,15 @@ using namespace fs;
 
 // Number of plane slices (grid.y): enough wavefronts for ~6+ rounds over the chip's 1024 SIMDs x 2 slots,
 // but at least 4 planes per wavefront so the per-wavefront weight loads stay amortised.
+// which forward sweep: the projected one (first layer per source texel) pays for K = 1 only (see cost_volume_proj_kernel);
+// FS_CV_PROJECTED=0/1 forces either (parity tests run both)
+static bool cv_use_projected(int K)
+{
+    const char* e = getenv("FS_CV_PROJECTED");
+    if (e && *e) return atoi(e) != 0;
+    return K == 1;
+}
+
 static int cv_plane_split(int B, int groups, int D)
 {
     static const int forced = getenv("FS_CV_SPLIT") ? atoi(getenv("FS_CV_SPLIT")) : 0;   // (tuning knob)
@@ -677,7 +932,8 @@ static int cv_bwd_plane_split(int B, int groups, int D)
 FS_API size_t fs_cost_volume_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w)
 {
     if (B < 0 || K < 0 || C <= 0 || h <= 0 || w <= 0) return 0;
-    return align_up((size_t)B * (1 + (size_t)K) * C * h * w * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256);
+    // current features [B, h*w, C] + source records [B*K, h*w, C + 32] (features + the projected first-layer block) + P
+    return align_up(((size_t)B * C + (size_t)B * K * (C + 2 * kCvU)) * h * w * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256);
 }
 
 FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
@@ -697,7 +953,7 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
     const int hw = h * w;
     float* curT = (float*)workspace;
     float* srcT = curT + (size_t)B * hw * C;
-    float* Pmat = (float*)((char*)workspace + align_up((size_t)B * (1 + (size_t)K) * C * hw * sizeof(float), 256));
+    float* Pmat = (float*)((char*)workspace + align_up(((size_t)B * C + (size_t)B * K * (C + 2 * kCvU)) * hw * sizeof(float), 256));
     {
         ScopedStage prof_(kStCostVolume, st);
         hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics,
@@ -705,19 +961,34 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
         const long long tot1 = (long long)B * hw * C, tot2 = tot1 * K;
         hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot1 + 255) / 256, 65536)),
                            dim3(256), 0, st, cur_feats, curT, C, hw, B);
-        hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
-                           dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
         const int groups = (hw + 31) / 32;
-        if (C == 48)
-            hipLaunchKernelGGL(cost_volume_kernel<24>, dim3(B * groups, cv_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT,
-                               srcT, Pmat, cur_invK, planes, (long long)plane_stride_b,
-                               (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3,
-                               out);
-        else
-            hipLaunchKernelGGL(cost_volume_kernel<8>, dim3(B * groups, cv_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT,
-                               srcT, Pmat, cur_invK, planes, (long long)plane_stride_b,
-                               (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3,
-                               out);
+        const dim3 grid(B * groups, cv_plane_split(B, groups, D));
+        if (cv_use_projected(K)) {
+            // K = 1: first layer's feature block applied per source texel, 16 MFMAs per (group, plane)
+            const unsigned gproj = (unsigned)std::min<long long>(((long long)B * K * hw + 255) / 256, 65536);
+            if (C == 48) {
+                hipLaunchKernelGGL(cv_relayout_project_kernel<48>, dim3(gproj), dim3(256), 0, st, src_feats, srcT, w1, h, w, B * K);
+                hipLaunchKernelGGL(cost_volume_proj_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
+                                   planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
+                                   w1, b1, w2, b2, w3, b3, out);
+            } else {
+                hipLaunchKernelGGL(cv_relayout_project_kernel<16>, dim3(gproj), dim3(256), 0, st, src_feats, srcT, w1, h, w, B * K);
+                hipLaunchKernelGGL(cost_volume_proj_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
+                                   planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
+                                   w1, b1, w2, b2, w3, b3, out);
+            }
+        } else {
+            hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
+                               dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
+            if (C == 48)
+                hipLaunchKernelGGL(cost_volume_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
+                                   planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
+                                   w1, b1, w2, b2, w3, b3, out);
+            else
+                hipLaunchKernelGGL(cost_volume_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
+                                   planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
+                                   w1, b1, w2, b2, w3, b3, out);
+        }
     }
     FS_CHECK_LAUNCH("cost_volume");
     return FS_OK;

@@ -29,6 +29,15 @@ def _module_from_fixture(g, h4, w4, D, C, dev):
     return m.to(dev)
 
 
+@pytest.fixture(params=["by_K", "classic", "projected"])
+def sweep(request, monkeypatch):
+    """Which forward sweep the library runs: its own choice (projected first layer for K = 1, classic otherwise) or
+    either one forced (FS_CV_PROJECTED is read at every call) -- both must meet the same bar at every K."""
+    if request.param != "by_K":
+        monkeypatch.setenv("FS_CV_PROJECTED", "1" if request.param == "projected" else "0")
+    return request.param
+
+
 def _run(m, kw, dev, **extra):
     args = {k: v.to(dev) for k, v in kw.items()}
     with torch.no_grad():
@@ -36,7 +45,7 @@ def _run(m, kw, dev, **extra):
 
 
 @pytest.mark.parametrize("name", ["cv_small_k1.npz", "cv_small_k2.npz"])
-def test_matches_reference_golden(hip_device, name):
+def test_matches_reference_golden(hip_device, name, sweep):
     g = _load(name)
     kw = {k: g[k] for k in ("cur_feats", "src_feats", "src_extrinsics", "src_poses", "src_Ks", "cur_invK",
                             "min_depth", "max_depth")}
@@ -46,7 +55,7 @@ def test_matches_reference_golden(hip_device, name):
     assert (out - g["out"]).abs().max().item() <= ATOL
 
 
-def test_native_size_vs_reference_statistics_and_oracle(hip_device):
+def test_native_size_vs_reference_statistics_and_oracle(hip_device, sweep):
     import inputs
     from oracle import cost_volume_oracle as cvo
     from freesplat_amd.cost_volume import AVGFeatureVolumeManager
@@ -68,7 +77,7 @@ def test_native_size_vs_reference_statistics_and_oracle(hip_device):
 
 @pytest.mark.parametrize("V,K,h4,w4,D,behind", [(3, 2, 15, 21, 11, True), (4, 3, 30, 40, 16, False),
                                                  (2, 1, 5, 7, 3, True), (2, 1, 64, 64, 128, False)])
-def test_ragged_shapes_vs_oracle(hip_device, V, K, h4, w4, D, behind):
+def test_ragged_shapes_vs_oracle(hip_device, V, K, h4, w4, D, behind, sweep):
     import inputs
     from oracle import cost_volume_oracle as cvo
     from freesplat_amd.cost_volume import AVGFeatureVolumeManager
@@ -103,7 +112,7 @@ def test_c3_scale_border_validity_flips_are_rare(hip_device):
     assert float(err.flatten().kthvalue(err.numel() - err.numel() // 1_000_000 - 1).values) <= ATOL
 
 
-def test_zero_features_exact_zero_semantics(hip_device):
+def test_zero_features_exact_zero_semantics(hip_device, sweep):
     """All-zero source features: every dot is exactly 0 -> no valid source -> MLP of the zero vector."""
     import inputs
     from freesplat_amd.cost_volume import AVGFeatureVolumeManager
