@@ -19,6 +19,9 @@
 //     41 MFMAs (exact fp32, = fmaf chains) per 32 pixels per plane; the gather/dot VALU work of
 //     one wavefront overlaps the MFMAs of the other wavefronts of the SIMD.
 //   * bias of layer 1 rides in the padding column of the K dimension (feature 49 := 1).
+//   * K = 1 (two-view configurations): cost_volume_proj_kernel -- the first layer's feature block is applied once per
+//     SOURCE TEXEL by the re-layout (it is linear, and so is the bilinear warp) and the sweep blends the result:
+//     16 MFMAs per 32 pixels per plane instead of 41.
 #include <algorithm>
 #include <cstdlib>
 
@@ -79,45 +82,43 @@ __device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3)
 // put every lane's 16 bytes in a line of its own -- 48 lines per instruction, re-walked by each of the 10 slot loads:
 // that version of the sweep was bound by the L1 and 1.6x SLOWER at config-3 scale than the one it replaced.)
 constexpr int kCvU = 16;
-// one thread per (map, texel): its C channel values are read once (coalesced along the pixel index), the 32 hidden
-// units are C FMAs each with the weights arriving as wave-uniform scalar loads, and the record leaves as REC/2 float4
-// stores (the two halves of a slot are adjacent: every touched line ends up fully written)
+// one thread per (map, texel, half, group of 4 units): the texel's C channel values are read by its 8 threads
+// (coalesced along the pixel index, L1 hits after the first), 4 hidden units are C FMAs each with the weights
+// arriving as wave-uniform scalar loads, and the record's float4 slots are shared out over the 8 threads
 template <int C>
 __global__ __launch_bounds__(256) void cv_relayout_project_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                                   const float* __restrict__ w1, int h, int w, int n_maps)
 {
     constexpr int HC = C / 2, REC = HC + kCvU, NS = REC / 4;
     const int hw = h * w;
-    const long long total = (long long)n_maps * hw;
+    const long long total = (long long)n_maps * 8 * hw;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int pix = (int)(e % hw);
-        const long long map = e / hw;
+        const long long r0 = e / hw;
+        const int part = (int)(r0 % 8), hf = part >> 2, u4 = part & 3;     // (wave-uniform: hw is a multiple of 64 or the
+        const long long map = r0 / 8;                                      //  branchy tail below is just divergent)
         const float* sp = src + (map * C) * hw + pix;
         float v[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) v[c] = sp[(size_t)c * hw];
         const int y = pix / w, x = pix % w;
-        float* const drow = dst + (((size_t)map * h + y) * NS * w + x) * 8;   // slot s at + s * w * 8, half hf at + hf * 4
+        float* const drow = dst + (((size_t)map * h + y) * NS * w + x) * 8 + hf * 4;   // slot s at + s * w * 8
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        for (int s4 = 0; s4 < HC / 4; ++s4)
+            if ((s4 & 3) == u4)
+                *(float4*)(drow + (size_t)s4 * w * 8) =
+                    make_float4(hf ? v[8 * s4 + 1] : v[8 * s4], hf ? v[8 * s4 + 3] : v[8 * s4 + 2],
+                                hf ? v[8 * s4 + 5] : v[8 * s4 + 4], hf ? v[8 * s4 + 7] : v[8 * s4 + 6]);
+        float o[4];
 #pragma unroll
-            for (int s4 = 0; s4 < HC / 4; ++s4)
-                *(float4*)(drow + (size_t)s4 * w * 8 + hf * 4) =
-                    make_float4(v[2 * (4 * s4) + hf], v[2 * (4 * s4 + 1) + hf], v[2 * (4 * s4 + 2) + hf], v[2 * (4 * s4 + 3) + hf]);
+        for (int q = 0; q < 4; ++q) {
+            const float* wr = w1 + (size_t)acc_row(4 * u4 + q, hf) * (C + 1);
+            float a = 0.0f;
 #pragma unroll
-            for (int u4 = 0; u4 < kCvU / 4; ++u4) {
-                float o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float* wr = w1 + (size_t)acc_row(4 * u4 + q, hf) * (C + 1);
-                    float a = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) a = fmaf(wr[c], v[c], a);
-                    o[q] = a;
-                }
-                *(float4*)(drow + (size_t)(HC / 4 + u4) * w * 8 + hf * 4) = make_float4(o[0], o[1], o[2], o[3]);
-            }
+            for (int c = 0; c < C; ++c) a = fmaf(wr[c], v[c], a);
+            o[q] = a;
         }
+        *(float4*)(drow + (size_t)(HC / 4 + u4) * w * 8) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -965,7 +966,7 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
         const dim3 grid(B * groups, cv_plane_split(B, groups, D));
         if (cv_use_projected(K)) {
             // K = 1: first layer's feature block applied per source texel, 16 MFMAs per (group, plane)
-            const unsigned gproj = (unsigned)std::min<long long>(((long long)B * K * hw + 255) / 256, 65536);
+            const unsigned gproj = (unsigned)std::min<long long>(((long long)B * K * hw * 8 + 255) / 256, 65536);
             if (C == 48) {
                 hipLaunchKernelGGL(cv_relayout_project_kernel<48>, dim3(gproj), dim3(256), 0, st, src_feats, srcT, w1, h, w, B * K);
                 hipLaunchKernelGGL(cost_volume_proj_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
