@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
 // (config-3 scale, K = 2: on par; 10 views, K = 8: 18 % slower than the sweep above).
 template <int HC>  // HC = C/2 channels per lane
 __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
-    int B, int K, int h, int w, int D, const float* __restrict__ curT, const float* __restrict__ srcT,
-    const float* __restrict__ Pmat,
+    int B, int K, int h, int w, int D, const float* __restrict__ cur_feats, const float* __restrict__ srcT,
+    const float* __restrict__ src_Ks, const float* __restrict__ src_extrinsics,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
@@ -358,15 +358,13 @@ __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
     }
     const float b3v = b3[0];
 
-    // ---- current-view feature (this lane's parity) ----
+    // ---- current-view feature (this lane's parity), straight from the caller's [C, h, w] map: read once per
+    //      wavefront, the 32 pixels of a channel are one 128-byte segment -- no re-laid-out copy of the current view ----
     float cur[HC];
     {
-        const float4* q = (const float4*)(curT + ((size_t)b * hw + (live ? pix : 0)) * C + (size_t)hf * HC);
+        const float* q = cur_feats + ((size_t)b * C + hf) * hw + (live ? pix : 0);
 #pragma unroll
-        for (int s = 0; s < HC / 4; ++s) {
-            const float4 v = q[s];
-            cur[4 * s] = v.x; cur[4 * s + 1] = v.y; cur[4 * s + 2] = v.z; cur[4 * s + 3] = v.w;
-        }
+        for (int s = 0; s < HC; ++s) cur[s] = q[(size_t)(2 * s) * hw];
     }
     // ---- ray r = invK[:3,:3] (u+.5, v+.5, 1) ----
     const float* iK = cur_invK + (size_t)b * 16;
@@ -386,12 +384,20 @@ __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
     // 9-nearest selection of config 4).
     const float* pl = planes + b * ps_b + (live ? pix : 0) * ps_p;
     float depth_next = d0 < d1 ? pl[d0 * ps_d] : 0.0f;
-    float P0[12], P1[12];
+    // P = (K_src @ T_src<-cur)[:3, :] (geometry_utils.py:78-80; the expression of cv_proj_kernel) formed here: 48 FMAs
+    // per source and wavefront instead of a launch of its own
+    auto proj_row = [&](int k, float* P) __attribute__((always_inline)) {
+        const float* Ks = src_Ks + ((size_t)b * K + k) * 16;
+        const float* Tx = src_extrinsics + ((size_t)b * K + k) * 16;
 #pragma unroll
-    for (int e = 0; e < 12; ++e) {
-        P0[e] = Pmat[((size_t)b * K) * 12 + e];
-        P1[e] = K > 1 ? Pmat[((size_t)b * K + 1) * 12 + e] : 0.0f;
-    }
+        for (int e = 0; e < 12; ++e) {
+            const int i = e / 4, j = e % 4;
+            const float v = Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] + Ks[4 * i + 3] * Tx[12 + j];
+            P[e] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));   // wave-uniform: keep it in an SGPR
+        }
+    };
+    float P0[12];      // (only the first source's rows stay resident: this sweep is the K = 1 path)
+    proj_row(0, P0);
 #ifdef FS_CV_TRACE
     unsigned long long tr_g = 0, tr_m = 0;
     const unsigned long long tr_c0 = cv_stamp(rx), tr_w0 = wall_clock64();
@@ -474,8 +480,11 @@ __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
         
         };
         one_source(0, P0);
-        if (K > 1) one_source(1, P1);
-        for (int k = 2; k < K; ++k) one_source(k, Pmat + ((size_t)b * K + k) * 12);
+        for (int k = 1; k < K; ++k) {
+            float Pk[12];
+            proj_row(k, Pk);
+            one_source(k, Pk);
+        }
         const float inv = 1.0f / (cnt + 1e-8f);                          // :595-598
         FS_CV_T(t_gath, uavg[0] + uavg[kCvU - 1] + inv + dot_sum);
         // ---- layer 1: z1 = W1f favg + w1d * dot_avg + b1 with W1f favg = blended U / cnt; this half's 16 units ----
@@ -957,28 +966,29 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
     float* Pmat = (float*)((char*)workspace + align_up(((size_t)B * C + (size_t)B * K * (C + 2 * kCvU)) * hw * sizeof(float), 256));
     {
         ScopedStage prof_(kStCostVolume, st);
-        hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics,
-                           Pmat);
         const long long tot1 = (long long)B * hw * C, tot2 = tot1 * K;
-        hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot1 + 255) / 256, 65536)),
-                           dim3(256), 0, st, cur_feats, curT, C, hw, B);
         const int groups = (hw + 31) / 32;
         const dim3 grid(B * groups, cv_plane_split(B, groups, D));
         if (cv_use_projected(K)) {
-            // K = 1: first layer's feature block applied per source texel, 16 MFMAs per (group, plane)
+            // K = 1: first layer's feature block applied per source texel, 16 MFMAs per (group, plane); two launches
+            // (the sweep reads the current view from the caller's map and forms its projection rows itself)
             const unsigned gproj = (unsigned)std::min<long long>(((long long)B * K * hw * 8 + 255) / 256, 65536);
             if (C == 48) {
                 hipLaunchKernelGGL(cv_relayout_project_kernel<48>, dim3(gproj), dim3(256), 0, st, src_feats, srcT, w1, h, w, B * K);
-                hipLaunchKernelGGL(cost_volume_proj_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
-                                   planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
-                                   w1, b1, w2, b2, w3, b3, out);
+                hipLaunchKernelGGL(cost_volume_proj_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, cur_feats, srcT, src_Ks,
+                                   src_extrinsics, cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
+                                   (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out);
             } else {
                 hipLaunchKernelGGL(cv_relayout_project_kernel<16>, dim3(gproj), dim3(256), 0, st, src_feats, srcT, w1, h, w, B * K);
-                hipLaunchKernelGGL(cost_volume_proj_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
-                                   planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
-                                   w1, b1, w2, b2, w3, b3, out);
+                hipLaunchKernelGGL(cost_volume_proj_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, cur_feats, srcT, src_Ks,
+                                   src_extrinsics, cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
+                                   (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out);
             }
         } else {
+            hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics,
+                               Pmat);
+            hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot1 + 255) / 256, 65536)),
+                               dim3(256), 0, st, cur_feats, curT, C, hw, B);
             hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
                                dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
             if (C == 48)
