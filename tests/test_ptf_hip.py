@@ -203,3 +203,20 @@ def test_gru_backward_kernel_vs_autograd(hip_device, n):
         assert a.shape == b.shape, k
         worst[f"param{k}"] = rel(a, b)
     assert max(worst.values()) < 1e-4, worst
+
+
+@pytest.mark.parametrize("n", [1, 33, 4097])
+def test_gru_forward_kernel_on_materialised_rows(hip_device, n):
+    """fs_ptf_gru_forward (the GRU on caller-built rows [hid | he | x | xe]; the fold itself uses the gathering variant of
+    the same kernel) against the torch GRU (networks.py:201-214): 1e-5 abs on O(1) outputs."""
+    from freesplat_amd import _lib, ptf as P
+    torch.manual_seed(7 + n)
+    gru = P.GRU().to(hip_device)
+    cat = torch.randn(n, 176, device=hip_device)
+    fused = torch.empty(n, 64, device=hip_device)
+    tab = P.gru_tables(gru)
+    _lib.check(_lib.lib().fs_ptf_gru_forward(n, _lib.ptr(cat), _lib.ptr(tab), _lib.ptr(fused), _lib.current_stream()),
+               "fs_ptf_gru_forward")
+    with torch.no_grad():
+        ref = P._gru_from_cat(P._gru_params(gru), cat)
+    assert (fused - ref).abs().max().item() < 1e-5
