@@ -30,6 +30,7 @@ RASTER_SH_FP16 = 2
 RASTER_SH_CHANNEL_MAJOR = 4
 RASTER_COV_FULL = 8
 RASTER_FAST_EXP = 16
+RASTER_NO_BACKWARD_STATE = 32
 
 
 def build(force: bool = False) -> str:

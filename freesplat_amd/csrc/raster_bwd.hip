@@ -569,7 +569,7 @@ FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, 
 {
     if (!dims) return FS_ERR_INVALID_ARG;
     const fs_raster_dims d = *dims;
-    if (d.N < 0) return FS_ERR_INVALID_ARG;
+    if (d.N < 0 || (d.flags & FS_RASTER_NO_BACKWARD_STATE)) return FS_ERR_INVALID_ARG;   // (that forward kept no n_contrib)
     if (d.N == 0) return FS_OK;  // an empty Gaussian set has empty gradients; its arrays may be NULL (as in the forward)
     if (!means3D || !cov3D || !bg || !viewmatrix || !projmatrix || !campos || !geom ||
         !binning || !image || !dL_dcolor || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D ||
@@ -613,7 +613,7 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
         return FS_ERR_INVALID_ARG;
     if (v == 0) return FS_OK;
     const fs_raster_dims d = *dims;
-    if (d.N < 0) return FS_ERR_INVALID_ARG;
+    if (d.N < 0 || (d.flags & FS_RASTER_NO_BACKWARD_STATE)) return FS_ERR_INVALID_ARG;
     if (d.N == 0) return FS_OK;
     if (!means3D || !cov3D || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
         !dL_dcolor || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D || !dL_dcov3D || !dL_dopacities)

@@ -200,9 +200,11 @@ class _RenderViews(torch.autograd.Function):
         depth = torch.empty(v, h, w, dtype=torch.float32, device=dev)
         alpha = torch.empty(v, h, w, dtype=torch.float32, device=dev)
         s0 = GaussianRasterizationSettings(h, w, 0.0, 0.0, None, 1.0, None, None, degree, None, False, False)
+        inference = not any(ctx.needs_input_grad[:4])     # no backward will follow: the blend skips the contributor count
 
         def launch(i, cap_i):   # single-view re-render (capacity overflow)
-            dims = R.make_dims(N, shs.shape[2], s0, sh_fp16=shs.dtype == torch.float16, native_layout=True)
+            dims = R.make_dims(N, shs.shape[2], s0, sh_fp16=shs.dtype == torch.float16, native_layout=True,
+                               inference=inference)
             rs, _, _, _ = R._launch_forward(dims, means, cov6, shs, None, opac, bgs[i], views[i], fulls[i],
                                             campos[i], cap_i, tanfov=tanfov[i],
                                             scale=None if scale is None else scale[i],
@@ -212,7 +214,7 @@ class _RenderViews(torch.autograd.Function):
         # all v views in ONE library call (fs_raster_forward_views): per-view host work is a few pointer offsets
         # instead of seven allocations and a 23-argument ctypes call, the views alternate over the side streams
         # inside the library and are joined back into the current stream before the call returns
-        dims = R.make_dims(N, shs.shape[2], s0, sh_fp16=shs.dtype == torch.float16, native_layout=True)
+        dims = R.make_dims(N, shs.shape[2], s0, sh_fp16=shs.dtype == torch.float16, native_layout=True, inference=inference)
         n_streams = min(R.NUM_STREAMS, v)
         while len(st.side_streams) < n_streams:
             st.side_streams.append(torch.cuda.Stream(device=dev))

@@ -149,16 +149,18 @@ def _f32c(t: Tensor, name: str, allow_half: bool = False) -> Tensor:
     return t.contiguous()
 
 
-def make_dims(N, M, settings: GaussianRasterizationSettings, sh_fp16: bool = False, native_layout: bool = False) -> _lib.RasterDims:
+def make_dims(N, M, settings: GaussianRasterizationSettings, sh_fp16: bool = False, native_layout: bool = False,
+              inference: bool = False) -> _lib.RasterDims:
     """`native_layout`: shs is the reference's harmonics [N,3,M] and cov3D its covariances [N,3,3]
-    (FS_RASTER_SH_CHANNEL_MAJOR | FS_RASTER_COV_FULL) instead of the rasterizer API's [N,M,3] / [N,6]."""
+    (FS_RASTER_SH_CHANNEL_MAJOR | FS_RASTER_COV_FULL) instead of the rasterizer API's [N,M,3] / [N,6].
+    `inference`: no backward will follow (FS_RASTER_NO_BACKWARD_STATE: the blend skips the contributor count)."""
     d = _lib.RasterDims()
     d.N, d.M = int(N), int(M)
     d.H, d.W = int(settings.image_height), int(settings.image_width)
     d.sh_degree = int(settings.sh_degree)
     d.tanfovx, d.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
     d.flags = ((_lib.RASTER_TILE_CULL if TILE_CULL else 0) | (_lib.RASTER_SH_FP16 if sh_fp16 else 0)
-               | (_lib.RASTER_FAST_EXP if FAST_EXP else 0))
+               | (_lib.RASTER_FAST_EXP if FAST_EXP else 0) | (_lib.RASTER_NO_BACKWARD_STATE if inference else 0))
     if native_layout:
         d.flags |= _lib.RASTER_SH_CHANNEL_MAJOR | _lib.RASTER_COV_FULL
     return d
@@ -221,7 +223,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, settings):
         N = means3D.shape[0]
         M = 0 if shs is None else shs.shape[1]
-        dims = make_dims(N, M, settings, sh_fp16=shs is not None and shs.dtype == torch.float16)
+        dims = make_dims(N, M, settings, sh_fp16=shs is not None and shs.dtype == torch.float16,
+                         inference=not any(ctx.needs_input_grad[:6]))
         bg = _f32c(settings.bg, "bg")
         view = _f32c(settings.viewmatrix, "viewmatrix")
         proj = _f32c(settings.projmatrix, "projmatrix")

@@ -91,6 +91,10 @@ typedef struct fs_raster_dims {
  * than 1e-4 x colour (counted by tests/test_raster_hip.py and bench.py).  Off by default in the Python layer (not
  * bit-exact).  A forward and its backward must use the same setting. */
 #define FS_RASTER_FAST_EXP 16
+/* Inference: the caller will not run fs_raster_backward on this forward.  The blend does not track the per-pixel
+ * contributor count (n_contrib of the image buffer is left unwritten; colour / depth / alpha / final_T are the same
+ * bits); fs_raster_backward(_views) refuses dims that carry the flag. */
+#define FS_RASTER_NO_BACKWARD_STATE 32
 
 /* Byte sizes of the four caller-owned device buffers for (N, H, W, instance capacity):
  *   out[0] geom    : per-Gaussian screen-space state            (saved for backward)

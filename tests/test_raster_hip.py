@@ -673,3 +673,27 @@ def test_backward_large_gaussians_and_deep_lists(hip_device):
         got = leaves[name].grad.cpu().numpy().reshape(ref[name].shape)
         err = np.abs(got - ref[name]).max() / (np.abs(ref[name]).max() + 1e-20)
         assert err < 2e-4, f"{name}: {err}"
+
+
+def test_inference_forward_keeps_no_backward_state(hip_device):
+    """A forward without any input requiring grad runs the blend without the contributor count
+    (FS_RASTER_NO_BACKWARD_STATE): same image bits as the tracking kernel, and the C ABI refuses a backward on it."""
+    from freesplat_amd import _lib, rasterizer as R
+    scene, cams = small_scene(N=3000, H=80, W=96, seed=12)
+    vi = view_inputs(scene, cams, 0, 80, 96, bg=(0.2, 0.3, 0.1))
+    (c_inf, _, d_inf, a_inf), _ = hip_forward(vi, hip_device)                       # no grad: inference kernel
+    (c_trk, _, d_trk, a_trk), _ = hip_forward(vi, hip_device, requires_grad=True)   # tracking kernel
+    assert c_inf.grad_fn is None and c_trk.grad_fn is not None
+    assert not (c_trk.grad_fn.rs.dims.flags & _lib.RASTER_NO_BACKWARD_STATE)
+    assert torch.equal(c_inf, c_trk.detach()) and torch.equal(d_inf, d_trk.detach()) and torch.equal(a_inf, a_trk.detach())
+    # the same forward launched by hand with the flag, then a backward on its state
+    d = lambda t: t.to(hip_device)
+    s = R.GaussianRasterizationSettings(vi["H"], vi["W"], vi["tanfovx"], vi["tanfovy"], d(vi["bg"]), 1.0, d(vi["viewmatrix"]),
+                                        d(vi["projmatrix"]), vi["sh_degree"], d(vi["campos"]), False, False)
+    dims = R.make_dims(vi["means3D"].shape[0], vi["shs"].shape[1], s, inference=True)
+    assert dims.flags & _lib.RASTER_NO_BACKWARD_STATE
+    rs, color, _, _ = R.rasterize_forward_checked(dims, d(vi["means3D"]), d(vi["cov3D"]), d(vi["shs"]), None, d(vi["opacities"]),
+                                                  d(vi["bg"]), d(vi["viewmatrix"]), d(vi["projmatrix"]), d(vi["campos"]))
+    assert torch.equal(color, c_inf)
+    with pytest.raises(_lib.FreeSplatHipError):
+        R.rasterize_backward(rs, d(vi["means3D"]), d(vi["cov3D"]), d(vi["shs"]), None, torch.ones_like(color), None)
