@@ -247,7 +247,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         per = ms / max(cnt, 1) * 1e-3
         alg = alg_bwd if train else alg_fwd
         ach = alg / per / 1e9 if per > 0 else 0.0
-        traffic, traffic_src = (committed_traffic("fs::" + dominant + "_kernel<" + ("true" if _R_FAST() else "false") + ">")
+        traffic, traffic_src = (committed_traffic("fs::" + dominant + "_kernel<" + ("true" if _R_FAST() else "false"))
                                 if workload.startswith("c3") else (None, None))
         out["roofline"] = {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": ach, "peak": 8000.0,
                            "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
@@ -283,7 +283,10 @@ def committed_traffic(kernel: str):
         return None, None
     for f in reversed(files):   # newest summary that has this kernel (forward and backward are separate files)
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
+            ks = json.load(open(f))["kernels"]
+            # `kernel` is a prefix up to the first template argument (e.g. "fs::render_kernel<false"): the forward
+            # blend has a second one (contributor-count tracking) that differs between inference and training runs
+            k = next((v for name, v in ks.items() if name == kernel or name.startswith(kernel + ",") or name.startswith(kernel + ">")), None)
         except Exception:
             continue
         if k:
