@@ -247,7 +247,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         per = ms / max(cnt, 1) * 1e-3
         alg = alg_bwd if train else alg_fwd
         ach = alg / per / 1e9 if per > 0 else 0.0
-        traffic, traffic_src = (committed_traffic("fs::" + dominant + "_kernel<" + ("true" if _R_FAST() else "false"))
+        traffic, traffic_src = (committed_traffic("fs::" + dominant + "_kernel<" + ("true" if _R_FAST() else "false")
+                                                  + ("" if train else ", false"))   # (forward bench = the inference blend)
                                 if workload.startswith("c3") else (None, None))
         out["roofline"] = {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": ach, "peak": 8000.0,
                            "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
