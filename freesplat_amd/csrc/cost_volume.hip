@@ -45,6 +45,9 @@ __device__ __forceinline__ unsigned long long cv_stamp(float dep)
     return t;
 }
 #define FS_CV_T(var, dep) const unsigned long long var = cv_stamp(dep)
+// backward: per wavefront the shader cycles of [0] forward recompute, [1] MLP backward, [2] weight-gradient outer
+// products (LDS transposes + 48 MFMAs), [3] feature gradients (re-gather for K > 1, scatter), [4] planes, [5] total
+__device__ unsigned long long g_cvb_trace[kCvTraceWaves * 6];
 #else
 #define FS_CV_T(var, dep) do {} while (0)
 #endif
@@ -694,8 +697,13 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
         for (int cb = 0; cb < NCB; ++cb) gW1[cb][r] = 0.0f;
     }
     SrcWarp<HC> W;
+#ifdef FS_CV_TRACE
+    unsigned long long tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;
+    const unsigned long long tb_start = cv_stamp(rx);
+#endif
 
     for (int d = d0; d < d1; ++d) {
+        FS_CV_T(tq0, rx);
         const float depth = planes[b * ps_b + d * ps_d + (live ? pix : 0) * ps_p];
         const size_t pt = ((size_t)b * D + d) * hw + (live ? pix : 0);
         const float go = live ? g_out[pt] : 0.0f;
@@ -731,6 +739,7 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
         for (int r = 0; r < 16; ++r) z2[r] = b2r[r];
 #pragma unroll
         for (int s = 0; s < 16; ++s) z2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], lrelu(z1[s]), z2, 0, 0, 0);
+        FS_CV_T(tq1, z2[0] + z2[15]);
         // ---- backward through the MLP ----
         f32x16 dz2, dh1;
 #pragma unroll
@@ -761,6 +770,7 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
             }
         }
         ddot = __shfl(ddot, p, 64);  // both parities of the pixel need it
+        FS_CV_T(tq2, ddot + dfavg[0]);
         // ---- weight gradients: transpose this plane's factors through LDS, accumulate the outer products ----
         {
             float* tz1 = s_stage + wave * kStage, *tz2 = tz1 + kTile1, *th1 = tz2 + kTile1, *tx = th1 + kTile1;
@@ -791,9 +801,11 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
             }
             wave_lds_sync();   // (the next plane overwrites the tile)
         }
+        FS_CV_T(tq3, gW2[0] + gW1[0][0]);
         // ---- back to the features ----
         for (int k = 0; k < K; ++k) {
-            warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, Pmat, inv_w, inv_h);
+            // (K = 1: W still holds this source from the forward recompute above -- no second gather)
+            if (K > 1) warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, Pmat, inv_w, inv_h);
             float part = 0.0f;
 #pragma unroll
             for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
@@ -829,15 +841,52 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
                 }
                 wave_lds_sync();
                 float* const dmap = d_srcT + (((size_t)b * K + k) * hw) * C;
-                for (int e = 0; e < 128; ++e) {                     // (pixel e >> 2, tap e & 3): wave-uniform
-                    const float wt = tW[e];
+                // the 128 (pixel, tap) weights and texel indices come back as two registers each (entry e in lane e & 63)
+                // and are handed out with v_readlane: the walk then has no LDS round trip in its control flow (as a loop
+                // over tW[e] / tO[e] every step waited for its own broadcast read before it could branch)
+                const float w_lo = tW[lane], w_hi = tW[64 + lane];
+                const uint32_t o_lo = tO[lane], o_hi = tO[64 + lane];
+                // Walked texel row by texel row in pixel order, equal texels in a row are neighbours in the walk (pixel p's
+                // right tap is pixel p+1's left one when the source is sampled at about its own resolution): runs of the
+                // same texel are summed in a register and leave as ONE atomic instruction -- ~66 instead of 128 per
+                // (group, plane, source).  All control flow is scalar (indices and weights live in SGPRs).
+                uint32_t run_idx = 0xffffffffu;
+                float run_acc = 0.0f;
+#pragma unroll
+                for (int e2 = 0; e2 < 128; ++e2) {                  // texel row e2 >> 6, pixel (e2 >> 1) & 31, column e2 & 1
+                    const int px = (e2 >> 1) & 31, e = px * 4 + (e2 >> 6) * 2 + (e2 & 1);
+                    const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e < 64 ? w_lo : w_hi), e & 63));
                     if (wt == 0.0f) continue;
-                    if (lane < C) atomicAdd(dmap + (size_t)tO[e] * C + lane, wt * tD[(e >> 2) * C + lane]);
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)(e < 64 ? o_lo : o_hi), e & 63);
+                    const float val = wt * tD[px * C + lane];
+                    if (idx == run_idx) {
+                        run_acc += val;
+                    } else {
+                        if (run_idx != 0xffffffffu && lane < C) atomicAdd(dmap + (size_t)run_idx * C + lane, run_acc);
+                        run_idx = idx;
+                        run_acc = val;
+                    }
                 }
+                if (run_idx != 0xffffffffu && lane < C) atomicAdd(dmap + (size_t)run_idx * C + lane, run_acc);
                 wave_lds_sync();
             }
         }
+#ifdef FS_CV_TRACE
+        {
+            FS_CV_T(tq4, dcur[0]);
+            tb0 += tq1 - tq0; tb1 += tq2 - tq1; tb2 += tq3 - tq2; tb3 += tq4 - tq3;
+        }
+#endif
     }
+#ifdef FS_CV_TRACE
+    {
+        const int wid = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+        if (lane == 0 && wid < kCvTraceWaves) {
+            unsigned long long* o = g_cvb_trace + 6 * (size_t)wid;
+            o[0] = tb0; o[1] = tb1; o[2] = tb2; o[3] = tb3; o[4] = (unsigned long long)(d1 - d0); o[5] = cv_stamp(rx) - tb_start;
+        }
+    }
+#endif
     {   // d cur: same transposition (one atomic instruction per pixel record instead of 24 over 64 scattered records)
         float* tD = s_stage + wave * kStage;
 #pragma unroll
@@ -905,6 +954,12 @@ extern "C" __attribute__((visibility("default"))) int fs_debug_cv_trace(unsigned
     static unsigned long long z[fs::kCvTraceWaves * 4];
     if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(fs::g_cv_trace), z, sizeof(z));
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fs::g_cv_trace), sizeof(z));
+}
+extern "C" __attribute__((visibility("default"))) int fs_debug_cvb_trace(unsigned long long* dst, int reset)
+{
+    static unsigned long long z[fs::kCvTraceWaves * 6];
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(fs::g_cvb_trace), z, sizeof(z));
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fs::g_cvb_trace), sizeof(z));
 }
 #endif
 

@@ -48,6 +48,37 @@ def main(V=2, K=1, h4=96, w4=128, D=128):
     print(json.dumps(out))
 
 
+def backward(V=2, K=1, h4=96, w4=128, D=128):
+    """The same for the backward kernel (fs_debug_cvb_trace): forward recompute / MLP backward / weight-gradient
+    outer products / feature gradients, shader cycles per (32-pixel group, plane)."""
+    dev = torch.device("cuda:0")
+    L = C.CDLL(_lib.LIB_PATH)
+    n = 16384 * 6
+    buf = (C.c_ulonglong * n)()
+    torch.manual_seed(0)
+    m = AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=48).to(dev)
+    kw = {k: v.to(dev) for k, v in inputs.cv_inputs(V, K, h4, w4, 48, seed=1).items()}
+    kw = {k: (v.clone().requires_grad_(True) if k in ("cur_feats", "src_feats") else v) for k, v in kw.items()}
+    for i in range(3):
+        if i == 2:
+            torch.cuda.synchronize()
+            L.fs_debug_cvb_trace(buf, 1)
+        o = m(**kw)
+        o.backward(torch.ones_like(o))
+    torch.cuda.synchronize()
+    L.fs_debug_cvb_trace(buf, 0)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 6).astype(np.float64)
+    a = a[a[:, 4] > 0]
+    planes = a[:, 4].sum()
+    names = ["forward_recompute", "mlp_backward", "weight_gradients", "feature_gradients"]
+    out = {"config": f"backward V={V} K={K} {h4}x{w4} D={D}", "wavefronts": int(len(a)), "planes_per_wavefront": float(a[:, 4].mean())}
+    out.update({nm + "_cycles_per_plane": float(a[:, i].sum() / planes) for i, nm in enumerate(names)})
+    out["total_cycles_per_plane"] = float(a[:, 5].sum() / planes)
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
     main()
     main(V=3, K=2, h4=242, w4=324)
+    backward()
+    backward(V=3, K=2, h4=242, w4=324, D=64)
