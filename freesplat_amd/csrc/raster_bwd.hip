@@ -296,7 +296,8 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float 
 // registers before the single write (per view only the 48-byte record, the tile rect and the 48-byte screen-space
 // gradient row are read).  view / proj [V,16], campos [V,3], tanfov [V,2] | NULL, scale [V] | NULL; geom and grad
 // hold V buffers geom_stride / grad_stride bytes apart.  `accumulate` adds to what the outputs already hold.
-__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
+// (two wavefronts per SIMD: 256 registers + 59 spilled dwords beat one wavefront at 310 registers by 13 %)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void preprocess_bwd_kernel(
     fs_raster_dims d, int V, const float* __restrict__ means3D, const float* __restrict__ cov3D,
     const float* __restrict__ shs, const float* __restrict__ view_all, const float* __restrict__ proj_all,
     const float* __restrict__ campos_all, const float* __restrict__ tanfov_dev,
