@@ -18,11 +18,18 @@ static unsigned g_profile_mask = 0;  // bit i: stage i is timed
 struct Rec { int stage, units; hipEvent_t a, b; };
 static std::vector<Rec> g_recs;
 static std::mutex g_mu;
+// at most this many launches of a stage are timed between two fs_profile_collect calls (the first ones): every timed
+// launch holds two timing events until the collect, and a few thousand outstanding ones slow the submission path down
+// (bench.py --steps 100: -8 % views/s with every launch timed); the per-launch average does not need more samples
+constexpr int kMaxTimedPerStage = 512;
+static int g_timed[kNumStages] = {};
 
 ScopedStage::ScopedStage(Stage s, hipStream_t st, int units) : slot_(-1), st_(st)
 {
     if (!((g_profile_mask >> (int)s) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_timed[(int)s] >= kMaxTimedPerStage) return;
+    ++g_timed[(int)s];
     Rec r;
     r.stage = (int)s;
     r.units = units;
@@ -68,6 +75,7 @@ FS_API int fs_profile_collect(int n, float* ms_total, int32_t* launches)
         (void)hipEventDestroy(r.b);
     }
     fs::g_recs.clear();
+    for (int i = 0; i < fs::kNumStages; ++i) fs::g_timed[i] = 0;
     return rc;
 }
 
