@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--grad-exchange", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
                     help="N>1 train mode: how the per-Gaussian gradients of the view shards are summed")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image all-gather")
+    ap.add_argument("--single-rank-collectives", action="store_true",
+                    help="N=1 under torch.distributed.run --nproc-per-node 1: initialise RCCL with one rank and take the "
+                         "N>1 code path (image all-gather on the side stream / gradient exchange, barrier, max-over-ranks "
+                         "timing) -- the RCCL branch on a one-GPU box")
     ap.add_argument("--gather-depth", action="store_true",
                     help="N>1: all-gather the depth maps too (the reference's decoder returns depth only when depth_mode is "
                          "set, decoder_splatting_cuda.py:64-70; colour alone is 15 MB per view, with depth 20 MB)")
@@ -81,8 +85,10 @@ class Ctx:
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
-        if self.world > 1:
+        self.dist_on = self.world > 1 or args.single_rank_collectives
+        if self.dist_on:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
@@ -90,7 +96,7 @@ class Ctx:
 
     def barrier(self):
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -119,8 +125,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         for t in g.values():
             t.requires_grad_(True)
         target = torch.rand(len(mine), 3, H, W, device=dev)
-    gather = AsyncViewGather(n_total_views, device=dev) if (world > 1 and not args.no_gather and not train) else None
-    exchange = GradExchange(args.grad_exchange) if (world > 1 and train) else None
+    gather = AsyncViewGather(n_total_views, device=dev) if (cx.dist_on and not args.no_gather and not train) else None
+    exchange = GradExchange(args.grad_exchange) if (cx.dist_on and train) else None
 
     def step():
         if train:
@@ -192,7 +198,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         _R.NUM_STREAMS = streams
         breakdown = _lib.profile_collect()
     graph_views_per_s = None
-    if world == 1 and not train and not args.no_graph:
+    if world == 1 and not cx.dist_on and not train and not args.no_graph:
         # the same step recorded once into a hipGraph (the C ABI never allocates or syncs: framing + 5 kernels per view
         # over two forked streams capture as they are) and replayed: what is left when the host-side launch train is
         # taken out of the loop
@@ -214,7 +220,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
             graph_views_per_s = n_total_views * steps / (time.perf_counter() - t1)
             graph_ok = bool(torch.equal(gc_color, color))
             del graph
-    if world > 1:
+    if cx.dist_on:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -404,7 +410,7 @@ def main():
             }
     if cx.rank == 0:
         print(json.dumps(out), flush=True)
-    if cx.world > 1:
+    if cx.dist_on:
         dist.destroy_process_group()
 
 

@@ -172,10 +172,9 @@ def sharded_cost_volume(manager, local_feats: Tensor, extrinsics: Tensor, intrin
         if local_feats.shape[0] != len(mine):
             raise ValueError(f"rank holds {local_feats.shape[0]} feature maps, expected {len(mine)}")
         feats = gather_features_autograd(local_feats, V, group)
-    kw = prepare_cost_volume_inputs(extrinsics, intrinsics, feats, near, far, image_hw, num_context_views)
-    rows = slice(mine.start, mine.stop)
-    local_kw = {k: (v if k in ("min_depth", "max_depth") else v[rows]) for k, v in kw.items()}
     if len(mine) == 0:
         D = getattr(manager, "num_depth_bins", 0)
         return feats.new_zeros((0, D) + tuple(feats.shape[-2:])) + 0.0 * feats.sum()
-    return manager(**local_kw)
+    # only this rank's rows of the B = V dimension are materialised (sources indexed out of the gathered maps)
+    return manager(**prepare_cost_volume_inputs(extrinsics, intrinsics, feats, near, far, image_hw, num_context_views,
+                                                rows=mine))

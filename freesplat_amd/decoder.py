@@ -19,6 +19,7 @@ from math import isqrt
 from typing import Optional
 
 import ctypes as C
+import os
 
 import torch
 from torch import Tensor, nn
@@ -374,9 +375,15 @@ class DecoderSplattingCUDA(nn.Module):
                      block, the images are all-gathered (RCCL over xGMI) so that every rank returns the full
                      [b, v, ...] output, and in backward the per-Gaussian gradients of the shards are summed over
                      the ranks in one flat bucket -- the multi-GPU run of src/main.py:98-103 without replicating
-                     the render work.  Gaussians and cameras must be identical on all ranks of the group."""
+                     the render work.  Gaussians and cameras must be identical on all ranks of the group: the first
+                     sharded call (every call with FREESPLAT_CHECK_REPLICAS=1) compares a checksum of the means and
+                     the extrinsics across the ranks and raises on a mismatch (Lightning DDP hands every rank its
+                     own scene: sharding the views of DIFFERENT scenes would silently mix them).
+      single_rank_collectives   take the sharded path (and issue its collectives) even on a one-rank group: how the
+                     RCCL branch is exercised on a one-GPU box (tests/test_rccl_world1.py)."""
 
-    def __init__(self, cfg=None, dataset_cfg=None, *, background_color=None, batched: bool = True, group=None):
+    def __init__(self, cfg=None, dataset_cfg=None, *, background_color=None, batched: bool = True, group=None,
+                 single_rank_collectives: bool = False):
         super().__init__()
         if background_color is None:
             background_color = getattr(dataset_cfg, "background_color", None) if dataset_cfg is not None else None
@@ -392,6 +399,8 @@ class DecoderSplattingCUDA(nn.Module):
                              persistent=False)
         self.batched = batched
         self.group = group
+        self.single_rank_collectives = single_rank_collectives
+        self._replicas_checked = False
 
     def _dist_group(self):
         if self.group is None or self.group is False:
@@ -400,7 +409,21 @@ class DecoderSplattingCUDA(nn.Module):
         if not dist.is_initialized():
             raise RuntimeError("DecoderSplattingCUDA(group=...) needs an initialised torch.distributed process group")
         g = None if self.group is True else self.group      # None = the default group
-        return (g, dist) if dist.get_world_size(g) > 1 else None
+        return (g, dist) if (dist.get_world_size(g) > 1 or self.single_rank_collectives) else None
+
+    def _check_replicas(self, group, dist, gaussians, extrinsics):
+        """All ranks of the group must hold the same Gaussians and cameras: compare a cheap checksum (sum and
+        sum of squares of the means and of the extrinsics) through one MIN and one MAX all-reduce of 4 doubles."""
+        from .view_sharding import _stage
+        m, e = gaussians.means.detach().double(), extrinsics.detach().double()
+        sig = torch.stack([m.sum(), (m * m).sum(), e.sum(), (e * e).sum()])
+        lo, hi = _stage(sig.clone(), group), _stage(sig.clone(), group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("DecoderSplattingCUDA(group=...): Gaussians / cameras differ between the ranks of the group "
+                               f"(checksum min {lo.tolist()} != max {hi.tolist()}); view sharding needs the SAME scene on "
+                               "every rank (shard scenes over ranks with group=None instead)")
 
     def forward(self, gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                 image_shape: tuple[int, int], depth_mode=None, no_color: bool = False) -> DecoderOutput:
@@ -413,8 +436,13 @@ class DecoderSplattingCUDA(nn.Module):
         bg = self.background_color
         sharded = self._dist_group()
         if sharded is not None:
+            if not self._replicas_checked or os.environ.get("FREESPLAT_CHECK_REPLICAS") == "1":
+                self._check_replicas(sharded[0], sharded[1], gaussians, extrinsics)
+                self._replicas_checked = True
             color, depth = self._forward_sharded(sharded[0], sharded[1], gaussians, extrinsics, intrinsics, near, far,
-                                                 image_shape)
+                                                 image_shape, with_depth=depth_mode is not None)
+            if depth is None:
+                return DecoderOutput(color, None)
         elif self.batched:
             colors, depths = [], []
             for i in range(b):
@@ -435,9 +463,10 @@ class DecoderSplattingCUDA(nn.Module):
         depth = depth / 2  # decoder_splatting_cuda.py:62
         return DecoderOutput(color, None if depth_mode is None else depth)
 
-    def _forward_sharded(self, group, dist, gaussians, extrinsics, intrinsics, near, far, image_shape):
+    def _forward_sharded(self, group, dist, gaussians, extrinsics, intrinsics, near, far, image_shape, with_depth=True):
         """View-sharded rendering of every scene of the batch: no collective on the render
-        path itself; one all-gather of colour+depth per scene, one flat-bucket gradient sum in backward."""
+        path itself; one all-gather of colour (+depth only when the caller asked for it: 15 instead of 20 MB per
+        968x1296 view) per scene, one flat-bucket gradient sum in backward."""
         from .view_sharding import gather_views_autograd, replicate_gaussians, shard_range
         b, v = extrinsics.shape[:2]
         h, w = image_shape
@@ -452,9 +481,12 @@ class DecoderSplattingCUDA(nn.Module):
             if len(mine):
                 c, d = render_views(extrinsics[i, sl], intrinsics[i, sl], near[i, sl], far[i, sl], image_shape,
                                     bg[None].expand(len(mine), 3), means, cov, sh, op)
-                local = torch.cat([c, d], dim=1)                       # [v_local, 4, h, w]
+                local = torch.cat([c, d], dim=1) if with_depth else c   # [v_local, 4 | 3, h, w]
             else:   # more ranks than views: this rank contributes nothing (but must keep the graph connected)
-                local = torch.zeros(0, 4, h, w, device=extrinsics.device) + 0.0 * (means.sum() + cov.sum() + sh.sum() + op.sum())
-            full = gather_views_autograd(local, v, group)              # [v, 4, h, w] on every rank
-            colors.append(full[:, :3]); depths.append(full[:, 3])
-        return torch.stack(colors), torch.stack(depths)
+                local = (torch.zeros(0, 4 if with_depth else 3, h, w, device=extrinsics.device)
+                         + 0.0 * (means.sum() + cov.sum() + sh.sum() + op.sum()))
+            full = gather_views_autograd(local, v, group)              # [v, 4 | 3, h, w] on every rank
+            colors.append(full[:, :3])
+            if with_depth:
+                depths.append(full[:, 3])
+        return torch.stack(colors), (torch.stack(depths) if with_depth else None)

@@ -45,9 +45,15 @@ def select_source_views(extrinsics: Tensor, num_context_views: int) -> Tensor:
 
 
 def prepare_cost_volume_inputs(extrinsics: Tensor, intrinsics: Tensor, matching_feats: Tensor, near: Tensor,
-                               far: Tensor, image_hw: tuple[int, int], num_context_views: int) -> dict:
+                               far: Tensor, image_hw: tuple[int, int], num_context_views: int,
+                               rows: range | None = None) -> dict:
     """extrinsics [b,V,4,4] c2w, intrinsics [b,V,3,3] normalised, matching_feats [(b V),C,h/4,w/4] (level-1
-    backbone features), near/far [b,V].  Returns the kwargs of cost_volume.forward (B = b*V rows)."""
+    backbone features), near/far [b,V].  Returns the kwargs of cost_volume.forward (B = b*V rows).
+
+    The reference repeats every tensor V-fold and `gather`s the source rows out of the copies
+    (encoder_freesplat.py:255-264: V*V*C*h/4*w/4 floats for the features); here the source rows are indexed
+    directly -- same values, no V-fold intermediate.  `rows` (a range of current views, b = 1): only those rows of the
+    B dimension are materialised -- what a view-sharded caller needs (cost_volume.sharded_cost_volume)."""
     b, V = extrinsics.shape[:2]
     h, w = image_hw
     dev = extrinsics.device
@@ -55,22 +61,29 @@ def prepare_cost_volume_inputs(extrinsics: Tensor, intrinsics: Tensor, matching_
     K[:, :, 0] *= (w // 4)
     K[:, :, 1] *= (h // 4)
     src_indices = select_source_views(extrinsics, num_context_views)                 # [b,V,Ks]
-    Ks = src_indices.shape[-1]
-    gather = lambda t, tail: t[:, None].repeat(1, V, *([1] * (t.dim() - 1))).gather(
-        dim=2, index=src_indices[(...,) + (None,) * len(tail)].repeat(1, 1, 1, *tail))
-    src_extr = gather(extrinsics, (4, 4))                                            # [b,V,Ks,4,4]
-    src_K3 = gather(K, (3, 3))
+    cur = slice(None)
+    if rows is not None:
+        if b != 1:
+            raise NotImplementedError("rows=...: one scene per call (b = 1)")
+        cur = slice(rows.start, rows.stop)
+        src_indices = src_indices[:, cur]
+    Vr, Ks = src_indices.shape[1:]
+    bi = torch.arange(b, device=dev)[:, None, None]
+    pick = lambda t: t[bi, src_indices]                                             # [b,V,...] -> [b,Vr,Ks,...]
+    src_extr = pick(extrinsics)                                                      # [b,Vr,Ks,4,4]
+    src_K3 = pick(K)
     inv = lambda t: torch.linalg.inv_ex(t).inverse
-    src_cam_T_cur = inv(src_extr) @ extrinsics.unsqueeze(2)
-    cur_cam_T_src = inv(extrinsics).unsqueeze(2) @ src_extr
+    cur_extr = extrinsics[:, cur]
+    src_cam_T_cur = inv(src_extr) @ cur_extr.unsqueeze(2)
+    cur_cam_T_src = inv(cur_extr).unsqueeze(2) @ src_extr
     C, h4, w4 = matching_feats.shape[-3:]
     feats = matching_feats.view(b, V, C, h4, w4)
-    src_feats = gather(feats, (C, h4, w4)).view(b * V, Ks, C, h4, w4)
-    src_K = torch.eye(4, device=dev)[None, None].repeat(b * V, Ks, 1, 1)
-    src_K[:, :, :3, :3] = src_K3.reshape(b * V, Ks, 3, 3)
-    cur_inv = torch.eye(4, device=dev)[None].repeat(b * V, 1, 1)
-    cur_inv[:, :3, :3] = inv(K.reshape(b * V, 3, 3))
-    return dict(cur_feats=matching_feats, src_feats=src_feats,
-                src_extrinsics=src_cam_T_cur.reshape(b * V, Ks, 4, 4), src_poses=cur_cam_T_src.reshape(b * V, Ks, 4, 4),
+    src_feats = pick(feats).reshape(b * Vr, Ks, C, h4, w4)
+    src_K = torch.eye(4, device=dev)[None, None].repeat(b * Vr, Ks, 1, 1)
+    src_K[:, :, :3, :3] = src_K3.reshape(b * Vr, Ks, 3, 3)
+    cur_inv = torch.eye(4, device=dev)[None].repeat(b * Vr, 1, 1)
+    cur_inv[:, :3, :3] = inv(K[:, cur].reshape(b * Vr, 3, 3))
+    return dict(cur_feats=feats[:, cur].reshape(b * Vr, C, h4, w4), src_feats=src_feats,
+                src_extrinsics=src_cam_T_cur.reshape(b * Vr, Ks, 4, 4), src_poses=cur_cam_T_src.reshape(b * Vr, Ks, 4, 4),
                 src_Ks=src_K, cur_invK=cur_inv, min_depth=near[:1, 0].type_as(src_K).view(1, 1, 1, 1),
                 max_depth=far[:1, 0].type_as(src_K).view(1, 1, 1, 1))

@@ -14,7 +14,8 @@ Exchanges:
                                                                             reduce_scatter_gaussian_grads
                          - all-reduce when every rank needs every row (replicated encoder)
                                                                             allreduce_gaussian_grads / replicate_gaussians
-  cost volume          all-gather of the 48-channel 1/4-resolution feature maps, then view i -> rank i mod G
+  cost volume          all-gather of the 48-channel 1/4-resolution feature maps, then rank r sweeps its contiguous
+                       block of current views (shard_range)
                                                                             freesplat_amd.cost_volume.sharded_cost_volume
 
 xGMI is point-to-point (7 links/GPU): one all-gather of a whole step's images per rank (tens of MB)
@@ -73,17 +74,25 @@ def gather_views(local: Tensor, n_total: int, group=None) -> Tensor:
     mx = max(counts)
     if local.shape[0] != counts[dist.get_rank(group)]:
         raise ValueError(f"rank holds {local.shape[0]} views, expected {counts[dist.get_rank(group)]}")
-    if local.shape[0] < mx:
-        pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        local = torch.cat([local, pad])
     dev = local.device
+    tail = tuple(local.shape[1:])
+    if local.shape[0] < mx:   # ragged: this rank sends one padded block (the pad rows are trimmed below, never read)
+        send = torch.empty((mx,) + tail, dtype=local.dtype, device=dev)
+        send[: local.shape[0]].copy_(local)
+        send[local.shape[0]:].zero_()
+        local = send
     local = _stage(local.contiguous(), group)
-    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out = torch.empty((world * mx,) + tail, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local, group=group)
     out = out.to(dev)
     if all(c == mx for c in counts):
         return out
-    return torch.cat([out[r * mx: r * mx + c] for r, c in enumerate(counts)])
+    # the first n_total % world ranks hold mx rows, the others mx - 1: two block copies
+    big = n_total % world
+    res = torch.empty((n_total,) + tail, dtype=out.dtype, device=dev)
+    res[: big * mx].copy_(out[: big * mx])
+    res[big * mx:].view((world - big, mx - 1) + tail).copy_(out[big * mx:].view((world - big, mx) + tail)[:, : mx - 1])
+    return res
 
 
 class AsyncViewGather:
@@ -133,12 +142,30 @@ def allreduce_gaussian_grads(grads: list[Optional[Tensor]], group=None) -> None:
         off += n
 
 
+_buckets: dict = {}
+
+
+def _bucket(numel: int, dtype, device) -> Tensor:
+    """The flat exchange bucket, allocated (zeroed) once per (device, dtype) and grown on demand: a training step reuses
+    it instead of allocating world*chunk floats every call.  Pad elements (ragged shards) may hold stale values of an
+    earlier call: they are summed into positions no receiver reads.  Reuse is safe because the collective is ordered
+    on the current stream before the next call's packing copies."""
+    key = (str(device), dtype)
+    b = _buckets.get(key)
+    if b is None or b.numel() < numel:
+        b = _buckets[key] = torch.zeros(numel, dtype=dtype, device=device)
+    return b[:numel]
+
+
 def reduce_scatter_gaussian_grads(grads: list[Optional[Tensor]], group=None) -> list[Optional[Tensor]]:
     """Sum the view-sharded gradients of the shared Gaussian set across ranks and leave every rank with the total
     for the Gaussian rows it OWNS (shard_range over dim 0 of each tensor): one reduce-scatter of one flat bucket
     laid out rank-major ([rows of rank 0 of every tensor | rows of rank 1 ...], padded to equal chunks).
     Returns the row shards [rows_r, ...] in the order of `grads` (None stays None).  Concatenating the shards of
-    all ranks reproduces allreduce_gaussian_grads."""
+    all ranks reproduces allreduce_gaussian_grads.  The returned shards are views of a fresh [chunk] tensor.
+
+    Packing: a tensor whose rows divide evenly over the ranks enters the bucket with ONE strided copy
+    ([world, rows/world * k] -> column block of the [world, chunk] bucket); ragged tensors take one copy per rank."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ts = [g for g in grads if g is not None]
     if not ts:
@@ -146,13 +173,20 @@ def reduce_scatter_gaussian_grads(grads: list[Optional[Tensor]], group=None) -> 
     rows = [[shard_range(t.shape[0], r, world) for t in ts] for r in range(world)]
     per = [[len(rr) * (t[0].numel() if t.shape[0] else 0) for rr, t in zip(rows[r], ts)] for r in range(world)]
     chunk = max(sum(p) for p in per)
-    flat = torch.zeros(world * chunk, dtype=ts[0].dtype, device=ts[0].device)
-    for r in range(world):
-        off = r * chunk
-        for rr, t, n in zip(rows[r], ts, per[r]):
-            if n:
-                flat[off: off + n] = t[rr.start: rr.stop].reshape(-1)
-            off += n
+    flat = _bucket(world * chunk, ts[0].dtype, ts[0].device)
+    flat2 = flat.view(world, chunk)
+    offs = [[sum(per[r][:j]) for j in range(len(ts))] for r in range(world)]
+    for j, t in enumerate(ts):
+        if t.shape[0] == 0:
+            continue
+        n0 = per[0][j]
+        if t.shape[0] % world == 0 and all(offs[r][j] == offs[0][j] for r in range(world)):
+            flat2[:, offs[0][j]: offs[0][j] + n0].copy_(t.reshape(world, n0))
+        else:
+            for r in range(world):
+                rr, n = rows[r][j], per[r][j]
+                if n:
+                    flat2[r, offs[r][j]: offs[r][j] + n].copy_(t[rr.start: rr.stop].reshape(-1))
     mine = _reduce_scatter_sum(flat, chunk, group)
     out, off, it = [], 0, iter(zip(rows[rank], ts, per[rank]))
     for g in grads:
@@ -240,11 +274,15 @@ class _GatherFeatsFn(torch.autograd.Function):
         per = 1
         for d in ctx.tail:
             per *= d
-        flat = torch.zeros(world * mx * per, dtype=g.dtype, device=g.device)
-        lo = 0
-        for r, c in enumerate(counts):
-            flat[r * mx * per: (r * mx + c) * per] = g[lo: lo + c].reshape(-1)
-            lo += c
+        g = g.contiguous()
+        flat = _bucket(world * mx * per, g.dtype, g.device)
+        if all(c == mx for c in counts):
+            flat.copy_(g.reshape(-1))
+        else:
+            lo = 0
+            for r, c in enumerate(counts):
+                flat[r * mx * per: (r * mx + c) * per].copy_(g[lo: lo + c].reshape(-1))
+                lo += c
         mine = _reduce_scatter_sum(flat, mx * per, ctx.group)
         return mine[: counts[rank] * per].view((counts[rank],) + ctx.tail), None, None
 
