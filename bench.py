@@ -112,6 +112,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
     H, W, N = synthetic.WORKLOADS[workload]
     from freesplat_amd.rasterizer import _state as _rstate
     _rstate(dev).last_instances = 0      # (capacity history of a previous workload in this process)
+    _rstate(dev).retry_cap = 0
     scene = synthetic.make_scene(N)
     n_total_views = views * world
     cams_all = synthetic.target_cameras(n_total_views)

@@ -31,7 +31,7 @@ void set_last_error(const char* what, hipError_t e);
 
 // ---- optional per-kernel event timing (fs_profile_*; off by default, zero cost when off) ------
 enum Stage {
-    kStPreprocess = 0, kStTileScan, kStEmit, kStTileSort, kStRender, kStRenderBwd, kStPreprocessBwd,
+    kStPreprocess = 0, kStTileScan, kStRender, kStRenderBwd, kStPreprocessBwd,
     kStCostVolume, kStPtf, kNumStages
 };
 struct ScopedStage {
@@ -270,21 +270,19 @@ __device__ __forceinline__ Cov2D project_cov(const float* __restrict__ V, float3
 }
 
 // ---- rasterizer buffer layouts (opaque to the caller; see fs_raster_buffer_sizes) ------------
-// geom: [N] x 3 float4 screen-space records, [N] ushort4 tile rects, [N] u8 clamp bits, [N] u64
-// packed quadrant masks (valid for rects of <= 16 tiles; larger rects recompute them), [N] f32 depths.
+// geom: [N] x 3 float4 screen-space records, [N] ushort4 tile rects, [N] u8 clamp bits.
 //   r0 = {px, py, -A/2, -C/2}   r1 = {-B, opacity, power_skip_threshold, view_z}
 //   r2 = {r, g, b, 0}           (A,B,C) = conic (inverse dilated 2D covariance)
+// (round 2 also kept packed quadrant masks and a dense depth array for the separate emit pass: 12 B per Gaussian
+//  written and re-read per view; the binning now happens in the projection launch, on registers)
 struct GeomView {
     float4* rec;
     ushort4* rect;
     uint8_t* clamp;
-    unsigned long long* qmask;  // 4 quadrant bits per tile of the rect (row-major), rects <= 16 tiles
-    float* depth;               // view-space z again, densely packed: all the emit pass needs of a record for small rects
 };
 __host__ __device__ inline size_t geom_bytes(int N)
 {
-    return align_up((size_t)N * 48, 256) + 2 * align_up((size_t)N * 8, 256) + align_up((size_t)N, 256) +
-           align_up((size_t)N * 4, 256);
+    return align_up((size_t)N * 48, 256) + align_up((size_t)N * 8, 256) + align_up((size_t)N, 256);
 }
 __host__ __device__ inline GeomView geom_view(void* base, int N)
 {
@@ -295,10 +293,6 @@ __host__ __device__ inline GeomView geom_view(void* base, int N)
     g.rect = (ushort4*)p;
     p += align_up((size_t)N * 8, 256);
     g.clamp = (uint8_t*)p;
-    p += align_up((size_t)N, 256);
-    g.qmask = (unsigned long long*)p;
-    p += align_up((size_t)N * 8, 256);
-    g.depth = (float*)p;
     return g;
 }
 // Tile -> workgroup order of the per-tile kernels (tile_sort, render, render_bwd).  Workgroup b runs on XCD b % 8
@@ -330,6 +324,16 @@ __host__ __device__ inline size_t binning_offsets_bytes(int H, int W)
     return align_up((size_t)(num_tiles(H, W) + 1) * 4, 256);
 }
 // image: [P] f32 final_T, [P] i32 n_contrib
-// scratch: [T] u32 counts, [T] u32 cursors, [cap] u64 keys
+// scratch: [T] u32 tile counts (= the binning pass' slot cursors), [T x tile_capacity] u64 keys -- a FIXED number of key
+// slots per tile, so that the projection pass can bin in the same launch (no count -> scan -> second pass over the
+// Gaussians): 4x the mean list length at the instance capacity, a power of two >= 2048 (HBM is 288 GB; config 3:
+// 8192 slots x 4941 tiles x 8 B = 324 MB of address space per stream, of which the 46 MB of real keys are touched).
+__host__ __device__ inline uint32_t tile_capacity(long long cap, int T)
+{
+    const unsigned long long want = (4ull * (unsigned long long)(cap > 0 ? cap : 1) + (unsigned long long)T - 1ull) / (unsigned long long)(T > 0 ? T : 1);
+    unsigned long long c = 2048;
+    while (c < want && c < (1ull << 26)) c <<= 1;
+    return (uint32_t)c;
+}
 
 }  // namespace fs

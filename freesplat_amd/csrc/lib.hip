@@ -44,7 +44,7 @@ ScopedStage::~ScopedStage()
     std::lock_guard<std::mutex> lk(g_mu);
     (void)hipEventRecord(g_recs[slot_].b, st_);
 }
-static const char* kStageNames[kNumStages] = {"preprocess", "tile_scan", "emit", "tile_sort", "render",
+static const char* kStageNames[kNumStages] = {"preprocess", "tile_scan", "render",
                                               "render_bwd", "preprocess_bwd", "cost_volume", "ptf"};
 }  // namespace fs
 

@@ -3,15 +3,21 @@
 // Replaces the CUDA extension FreeSplat calls at src/model/decoder/cuda_splatting.py:114-127
 // (semantics: SURVEY.md Appendix A.1-A.4).  Pipeline, all on one stream, no host sync:
 //
-//   preprocess   1 thread / Gaussian    project, cull, EWA conic, SH->RGB, tile rect, 8x8-quadrant masks of the
-//                                       alpha >= 1/255 ellipse, per-tile instance counts (LDS-privatised per workgroup)
-//   tile_scan    1 workgroup            exclusive scan of the T tile counts -> tile ranges, overflow flag
-//   emit         1 thread / Gaussian    scatter (depth_bits<<32 | id<<4 | quadrant mask) keys into the tile ranges
-//   tile_sort    1 workgroup / tile     LDS bucket sort by depth (O(n); bitonic network for lists > 2048 keys and
-//                                       degenerate tiles) -> list words (id<<4 | mask) in (depth, id) order
-//   render       1 single-wavefront workgroup per 8x8 QUADRANT of a tile, no barrier anywhere: survivors of 64 list
-//                                       entries compacted pairwise into wavefront-private LDS, packed-fp32 exponent /
-//                                       exp / alpha over pairs of Gaussians, front-to-back alpha compositing
+//   project_bin  1 thread / Gaussian    project, cull, EWA conic, SH->RGB, tile rect, 8x8-quadrant masks of the
+//                                       alpha >= 1/255 ellipse, AND the binning in the same launch: per-tile instance
+//                                       counts in LDS (privatised per workgroup), one returning global atomic per touched
+//                                       tile reserves the workgroup's slots in the tile's FIXED-capacity key area, keys
+//                                       (depth_bits<<32 | id<<4 | quadrant mask) written there
+//   tile_scan    1 workgroup            exclusive scan of the T tile counts -> compact ranges of the saved lists,
+//                                       instance total, overflow flag
+//   sort_blend   1 workgroup / tile     LDS bucket sort of the tile's keys by depth (O(n); bitonic network for lists
+//                                       > 2048 keys and degenerate tiles) -> list words (id<<4 | mask) in (depth, id)
+//                                       order, kept IN LDS (written to the saved list only when a backward follows);
+//                                       then each of the 4 wavefronts blends its own 8x8 QUADRANT front to back with no
+//                                       further barrier: survivors of 64 list entries compacted pairwise into
+//                                       wavefront-private LDS, packed-fp32 exponent / exp / alpha over pairs of Gaussians
+// (round 2 ran five kernels: preprocess -> tile_scan -> emit -> tile_sort -> render; the second pass over the Gaussians,
+//  the global list round trip between sort and blend and two launches per view are gone)
 //
 // Design notes (MI355X-first, not the CUDA layout):
 //   * no global 64-bit radix sort over all instances: instances are binned per tile with
@@ -23,6 +29,8 @@
 //   * tile -> workgroup mapping is XCD-aware and balanced: workgroup b runs on XCD b % 8; tiles are grouped in 4x4
 //     super-tiles (neighbours share most of their Gaussians -> one L2) and super-tile s goes to XCD s % 8
 //     (fs_common.h:tile_for_block).
+#include <type_traits>
+
 #include "fs_common.h"
 
 namespace fs {
@@ -241,7 +249,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ opacities, const float* __restrict__ view,
     const float* __restrict__ proj, const float* __restrict__ campos,
     const float* __restrict__ tanfov_dev, const float* __restrict__ scale_dev, GeomView g,
-    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_counts)
+    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_counts, unsigned long long* __restrict__ keys,
+    uint32_t tile_cap)
 {
     const float tanfovx = tanfov_dev ? tanfov_dev[0] : d.tanfovx;
     const float tanfovy = tanfov_dev ? tanfov_dev[1] : d.tanfovy;
@@ -362,15 +371,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         g.rec[3 * (size_t)i + 2] = r2;
         g.rect[i] = rect;
         g.clamp[i] = cb;
-        g.depth[i] = r1.w;
         radii[i] = rad;
     }
 
-    // ---- per-tile instance counts (the staging LDS is dead from here on) ----
+    // ---- binning (the staging LDS is dead from here on): count per tile in LDS, reserve, write the keys ----
     __syncthreads();
     FS_PT(0, 3);  // records written
     int* s_box = (int*)lds;
-    uint32_t* s_cnt = (uint32_t*)lds + 16;
+    uint32_t* s_cnt = (uint32_t*)lds + 16;   // per tile of the workgroup's box: instance count, then the next free slot
     const bool valid = rad > 0;
     const bool cull = (d.flags & FS_RASTER_TILE_CULL) != 0;
     const int gx = (d.W + kTile - 1) / kTile;
@@ -379,7 +387,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const bool small = area <= 16;
     unsigned long long qm = 0;
     if (valid && small) qm = pack_quad_masks(qf, r0, rect);
-    if (live) g.qmask[i] = qm;
+    // key = depth bits : (gaussian id << 4 | quadrant mask); the mask is a function of (id, tile), so
+    // ordering by the key is ordering by (depth, id)
+    const unsigned long long key_hi = ((unsigned long long)__float_as_uint(r1.w) << 32) | ((uint32_t)i << 4);
     FS_PT(0, 4);  // quadrant masks
     const BinBox bb = block_bin_box(s_box, valid, rect);
     FS_PT(0, 5);  // workgroup box
@@ -402,9 +412,25 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         FS_PT(0, 6);  // counted
         for (int k = t; k < bb.w * bb.h; k += 256) {
             const uint32_t c = s_cnt[k];
-            if (c) atomicAdd(&tile_counts[(bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w], c);
+            // first slot of this workgroup in the tile's key area (one returning global atomic per touched tile)
+            s_cnt[k] = c ? atomicAdd(&tile_counts[(bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w], c) : 0u;
         }
-        FS_PT(0, 7);  // flushed
+        __syncthreads();
+        FS_PT(0, 7);  // slots reserved
+        if (valid) {
+            int k = 0;
+            for (int y = rect.y; y < rect.w; ++y) {
+                RowBands rb = {};
+                if (!small) rb = row_bands(qf, r0, y);
+                for (int x = rect.x; x < rect.z; ++x, ++k) {
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
+                    if (!cull || m) {
+                        const uint32_t slot = atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
+                        if (slot < tile_cap) keys[(size_t)(y * gx + x) * tile_cap + slot] = key_hi | m;
+                    }
+                }
+            }
+        }
     } else if (valid) {
         int k = 0;
         for (int y = rect.y; y < rect.w; ++y) {
@@ -412,7 +438,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             if (!small) rb = row_bands(qf, r0, y);
             for (int x = rect.x; x < rect.z; ++x, ++k) {
                 const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
-                if (!cull || m) atomicAdd(&tile_counts[y * gx + x], 1u);
+                if (!cull || m) {
+                    const uint32_t slot = atomicAdd(&tile_counts[y * gx + x], 1u);
+                    if (slot < tile_cap) keys[(size_t)(y * gx + x) * tile_cap + slot] = key_hi | m;
+                }
             }
         }
     }
@@ -422,22 +451,25 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 // tile_scan: exclusive scan over T tile counts (T ~ 5e3; one workgroup of 1024)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ counts,
-                                                         uint32_t* __restrict__ offsets,
-                                                         uint32_t* __restrict__ cursors, int T,
+                                                         uint32_t* __restrict__ offsets, int T,
                                                          uint32_t* __restrict__ counters,
-                                                         unsigned long long cap)
+                                                         unsigned long long cap, uint32_t tile_cap)
 {
     __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_max[16];
     __shared__ unsigned long long s_wide[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (T + 1023) / 1024;
     const int lo = min(T, t * per), hi = min(T, lo + per);
-    uint32_t s = 0;
+    uint32_t s = 0, mx = 0;
     unsigned long long wide = 0;  // the instance total in 64 bits: offsets are 32-bit, a wrapped total must not pass as small
-    for (int k = lo; k < hi; ++k) { s += counts[k]; wide += counts[k]; }
+    for (int k = lo; k < hi; ++k) { const uint32_t c = counts[k]; s += c; wide += c; mx = max(mx, c); }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wide += __shfl_xor(wide, d, 64);
-    if (lane == 0) s_wide[wave] = wide;
+    for (int d = 32; d >= 1; d >>= 1) {
+        wide += __shfl_xor(wide, d, 64);
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    }
+    if (lane == 0) { s_wide[wave] = wide; s_max[wave] = mx; }
     // inclusive scan of the 1024 partial sums: shuffles inside a wavefront, the 16 wavefront totals through LDS
     uint32_t inc = s;
 #pragma unroll
@@ -458,109 +490,18 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
     uint32_t run = inc - s;
     for (int k = lo; k < hi; ++k) {
         offsets[k] = run;
-        cursors[k] = 0;
         run += counts[k];
     }
     if (t == 1023) {
         unsigned long long total64 = 0;
+        uint32_t maxc = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) total64 += s_wide[k];
+        for (int k = 0; k < 16; ++k) { total64 += s_wide[k]; maxc = max(maxc, s_max[k]); }
         offsets[T] = total;
         counters[0] = total64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total64;  // saturates: "more than 2^32 - 1"
-        counters[1] = (total64 > cap) ? 1u : 0u;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// emit: one key per (gaussian, tile) instance
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_kernel(int N, int gx, int flags, GeomView g,
-                                                   const uint32_t* __restrict__ offsets,
-                                                   uint32_t* __restrict__ cursors,
-                                                   unsigned long long* __restrict__ keys,
-                                                   unsigned long long cap)
-{
-    __shared__ int s_box[8];
-    __shared__ uint32_t s_cnt[kBinLds];   // per tile of the workgroup's box: instance count, then the next free slot
-    FS_PT(1, 0);
-    const int t = threadIdx.x;
-    const int i = blockIdx.x * 256 + t;
-    const bool live = i < N;
-    const ushort4 rc = live ? g.rect[i] : make_ushort4(0, 0, 0, 0);
-    const bool valid = rc.z > rc.x && rc.w > rc.y;
-    const bool cull = (flags & FS_RASTER_TILE_CULL) != 0;
-    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
-    float zdepth = 0.0f;
-    if (valid) {
-        // small rects (the common case) carry their masks precomputed: only the 4-byte depth is read, not the
-        // 48-byte record (whose lines the dense depth array spares: 65 -> ~25 MB of reads per view at config 3)
-        zdepth = g.depth[i];
-        if ((rc.z - rc.x) * (rc.w - rc.y) > 16) { r0 = g.rec[3 * (size_t)i]; r1 = g.rec[3 * (size_t)i + 1]; }
-    }
-    // key = depth bits : (gaussian id << 4 | quadrant mask); the mask is a function of (id, tile), so
-    // ordering by the key is ordering by (depth, id)
-    const unsigned long long key_hi = ((unsigned long long)__float_as_uint(zdepth) << 32) | ((uint32_t)i << 4);
-    const int area = (rc.z - rc.x) * (rc.w - rc.y);
-    const bool small = area <= 16;
-    const unsigned long long qm = (valid && small) ? g.qmask[i] : 0ull;
-    QuadForm qf = {};
-    if (valid && !small) qf = quad_form(r0, r1);
-    const BinBox bb = block_bin_box(s_box, valid, rc);
-    FS_PT(1, 1);  // loaded + workgroup box
-    if (bb.w * bb.h == 0) return;
-    if (bb.lds) {
-        for (int k = t; k < bb.w * bb.h; k += 256) s_cnt[k] = 0;
-        __syncthreads();
-        FS_PT(1, 2);  // zeroed
-        if (valid) {
-            int k = 0;
-            for (int y = rc.y; y < rc.w; ++y) {
-                RowBands rb = {};
-                if (!small) rb = row_bands(qf, r0, y);
-                for (int x = rc.x; x < rc.z; ++x, ++k) {
-                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
-                    if (!cull || m) atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        FS_PT(1, 3);  // counted
-        for (int k = t; k < bb.w * bb.h; k += 256) {
-            const uint32_t c = s_cnt[k];
-            const int tile = (bb.y0 + k / bb.w) * gx + bb.x0 + k % bb.w;
-            s_cnt[k] = c ? offsets[tile] + atomicAdd(&cursors[tile], c) : 0u;  // first slot of this workgroup in the tile's range
-        }
-        __syncthreads();
-        FS_PT(1, 4);  // slots reserved
-        if (valid) {
-            int k = 0;
-            for (int y = rc.y; y < rc.w; ++y) {
-                RowBands rb = {};
-                if (!small) rb = row_bands(qf, r0, y);
-                for (int x = rc.x; x < rc.z; ++x, ++k) {
-                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
-                    if (!cull || m) {
-                        const unsigned long long slot = atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
-                        if (slot < cap) keys[slot] = key_hi | m;
-                    }
-                }
-            }
-        }
-        FS_PT(1, 5);  // keys written
-    } else if (valid) {
-        int k = 0;
-        for (int y = rc.y; y < rc.w; ++y) {
-            RowBands rb = {};
-            if (!small) rb = row_bands(qf, r0, y);
-            for (int x = rc.x; x < rc.z; ++x, ++k) {
-                const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
-                if (!cull || m) {
-                    const int tl = y * gx + x;
-                    const unsigned long long slot = (unsigned long long)offsets[tl] + atomicAdd(&cursors[tl], 1u);
-                    if (slot < cap) keys[slot] = key_hi | m;
-                }
-            }
-        }
+        // overflow: the saved lists need `total` entries, every tile's key area `count` slots.  Non-zero = the largest
+        // tile count (>= 1), from which the caller sizes its retry.
+        counters[1] = (total64 > cap || maxc > tile_cap) ? max(maxc, 1u) : 0u;
     }
 }
 
@@ -793,11 +734,15 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
 // than kMaxBucket keys: many identical depths) fall back to the register bitonic network on the keys already loaded.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kMaxBucket = 24;
+// The sorted list words are left in LDS (`list`, which ALIASES `cnt`: positions are formed in registers, written after a
+// barrier) for the blend that follows in the same workgroup; `gout` != nullptr also writes them to the saved list
+// (training: the backward walks it).
 template <int EPT>
-__device__ __forceinline__ void sort_tile_buckets(const unsigned long long* __restrict__ keys, uint32_t* __restrict__ out,
+__device__ __forceinline__ void sort_tile_buckets(const unsigned long long* __restrict__ keys, uint32_t* __restrict__ gout,
                                                   uint32_t n, unsigned long long* sk, uint32_t* cnt, uint32_t* s_red)
 {
     constexpr int CAP = 256 * EPT;  // capacity == number of buckets
+    uint32_t* const list = cnt;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     unsigned long long k[EPT];
     uint32_t zmin = 0xFFFFFFFFu, zmax = 0u;
@@ -855,135 +800,94 @@ __device__ __forceinline__ void sort_tile_buckets(const unsigned long long* __re
     uint32_t run = inc - sum;
 #pragma unroll
     for (int w = 0; w < 3; ++w) run += w < wave ? s_red[8 + w] : 0u;
+    if (degenerate) {
+        Stages<EPT, CAP>::run(k, t, sk);  // (its exchanges synchronise the workgroup themselves)
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const uint32_t i = (uint32_t)t * EPT + e;
+            if (i < n) {
+                list[i] = (uint32_t)k[e];
+                if (gout) gout[i] = (uint32_t)k[e];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         cnt[t * EPT + j] = run;
         run += c[j];
     }
     if (t == 255) cnt[CAP] = run;  // == n
-    if (degenerate) {
-        Stages<EPT, CAP>::run(k, t, sk);  // (its exchanges synchronise the workgroup themselves)
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const uint32_t i = (uint32_t)t * EPT + e;
-            if (i < n) out[i] = (uint32_t)k[e];
-        }
-        return;
-    }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < EPT; ++e)
         if ((uint32_t)(e * 256 + t) < n) sk[cnt[bs[e] >> 8] + (bs[e] & 255u)] = k[e];
     __syncthreads();
+    uint32_t pos[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
+        pos[e] = 0u;
         if ((uint32_t)(e * 256 + t) < n) {
             const uint32_t b = bs[e] >> 8;
             const uint32_t lo = cnt[b], hi = cnt[b + 1];
             uint32_t r = 0u;
             for (uint32_t j = lo; j < hi; ++j) r += sk[j] < k[e] ? 1u : 0u;
-            out[lo + r] = (uint32_t)k[e];
+            pos[e] = lo + r;
+        }
+    }
+    __syncthreads();  // every read of the bucket offsets is done: the list may overwrite them
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if ((uint32_t)(e * 256 + t) < n) {
+            list[pos[e]] = (uint32_t)k[e];
+            if (gout) gout[pos[e]] = (uint32_t)k[e];
         }
     }
 }
 
-// (6 wavefronts per SIMD = the 6 workgroups per CU its 24.9 KB of LDS allow: 76 VGPRs without a spill; left alone the
-// compiler takes 98 and the kernel is 11 % slower)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void tile_sort_kernel(int gx, int gy, const uint32_t* __restrict__ offsets,
-                                                        unsigned long long* __restrict__ keys,
-                                                        uint32_t* __restrict__ point_list,
-                                                        const uint32_t* __restrict__ counters)
-{
-    __shared__ unsigned long long sk[kSortLds];
-    __shared__ uint32_t s_cnt[kSortLds + 1];
-    __shared__ uint32_t s_red[16];
-    if (counters[1]) return;  // overflowed capacity: ranges are not backed by memory
-    const int tile = tile_for_block(blockIdx.x, gx, gy);  // XCD-aware, balanced (fs_common.h)
-    if (tile < 0) return;
-    const uint32_t a = offsets[tile], b = offsets[tile + 1];
-    const uint32_t n = b - a;
-    if (n == 0) return;
-    if (n <= 256u) {
-        sort_tile_buckets<1>(keys + a, point_list + a, n, sk, s_cnt, s_red);
-    } else if (n <= 512u) {
-        sort_tile_buckets<2>(keys + a, point_list + a, n, sk, s_cnt, s_red);
-    } else if (n <= 1024u) {
-        sort_tile_buckets<4>(keys + a, point_list + a, n, sk, s_cnt, s_red);
-    } else if (n <= 2048u) {
-        sort_tile_buckets<8>(keys + a, point_list + a, n, sk, s_cnt, s_red);
-    } else if (n <= 2560u) {
-        sort_tile_two_runs<8, 2>(keys + a, point_list + a, n, sk);
-    } else if (n <= 3072u) {
-        sort_tile_two_runs<8, 4>(keys + a, point_list + a, n, sk);
-    } else if (n <= 4096u) {
-        sort_tile_in_registers<16>(keys + a, point_list + a, n, sk);
-    } else {
-        // rare: very long tile lists sort in place in global memory (same network)
-        __syncthreads();
-        bitonic_sort_any(keys + a, n);
-        for (uint32_t k = threadIdx.x; k < n; k += 256) point_list[a + k] = (uint32_t)keys[a + k];
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// render: front-to-back alpha compositing, one 16x16 tile per workgroup.
-// Each of the 4 wavefronts owns one 8x8 quadrant.  The list entries carry a 4-bit quadrant mask
-// (computed once at emit time), so a wavefront ballots 64 entries at a time against its own bit
-// and walks only the survivors (s_ff1 over the ballot): entries that cannot touch the quadrant
-// cost 1/64 of a VALU test instead of a full per-pixel evaluation.
-// ------------------------------------------------------------------------------------------
-// Blend loop.  Each wavefront owns one 8x8 quadrant of the tile and is fully independent of the
-// other three (no workgroup barrier anywhere):
-//   * it walks the tile's sorted list 64 entries at a time, reading the 32-bit list words itself (two batches
-//     ahead) and the 48-byte records of the entries whose quadrant bit is set (one batch ahead), so the global
-//     latency of batch i+1 / i+2 is covered by the blending of batch i;
+// Blend loop of one wavefront = one 8x8 quadrant of the tile, fully independent of the other three (no workgroup
+// barrier): front-to-back alpha compositing over the tile's sorted list.
+//   * the list words carry a 4-bit quadrant mask (computed once at binning time): the wavefront ballots 64 entries at a
+//     time against its own bit and gathers the 48-byte records of the entries that have it one batch ahead, so the global
+//     latency of batch i+1 is covered by the blending of batch i; entries that cannot touch the quadrant cost 1/64 of a
+//     VALU test instead of a full per-pixel evaluation;
 //   * the survivors of a batch are COMPACTED into a wavefront-private LDS area, two per slot with their fields
 //     interleaved ([x_a x_b y_a y_b] ...), so that the walk reads register PAIRS straight from LDS
-//     (6 ds_read_b128 per two survivors, the next slot prefetched) and the exponent, the exp and alpha of both
-//     run on packed fp32 (v_pk_{add,mul,fma}_f32): ~50 VALU per two survivors instead of ~90 with scalar fp32 and broadcast reads.
-// Arithmetic per pixel is the same sequence of IEEE operations as v1 / the oracle => same bits.
-constexpr int kPairQuads = 6;  // float4 per slot of two survivors
-#ifdef FS_RENDER_TRACE
-__device__ unsigned long long g_render_trace[4 * 8192];
-#endif
+//     (6 ds_read_b128 per two survivors) and the exponent, the exp and alpha of both run on packed fp32
+//     (v_pk_{add,mul,fma}_f32): ~50 VALU per two survivors instead of ~90 with scalar fp32 and broadcast reads;
+//   * four survivors per step (the two packed exponent / exp chains are independent, the scheduler interleaves them); the
+//     full steps of a batch carry no "does this half exist" logic, only the batch's last, partial step does.
+// Arithmetic per pixel is the same sequence of IEEE operations as the oracle => same bits.
+// LDS_LIST: `pl` points into LDS (the list the workgroup has just sorted) or to the saved list in global memory (lists
+// longer than the LDS sort's capacity): two instantiations, so that each uses its own address space's instructions.
 // TRACK: keep the per-pixel contributor count (n_contrib, the backward's starting point); off with
 // FS_RASTER_NO_BACKWARD_STATE (inference: 4 fewer selects per 4 survivors)
-template <bool FAST_EXP, bool TRACK = true>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void render_kernel(
-    int H, int W, int T, const uint32_t* __restrict__ offsets,
-    const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-    const float* __restrict__ bg, const uint32_t* __restrict__ counters,
-    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-    float* __restrict__ final_T, int32_t* __restrict__ n_contrib)
+// ------------------------------------------------------------------------------------------
+constexpr int kPairQuads = 6;  // float4 per slot of two survivors
+constexpr int kPairArea = 33 * kPairQuads;  // float4 per wavefront (+1 slot: the read of a step's second slot may run one past)
+template <bool FAST_EXP, bool TRACK, bool LDS_LIST>
+__device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const float4* __restrict__ rec, float4* const cp,
+                                               int H, int W, int tx, int ty, int wave, const float* __restrict__ bg,
+                                               float* __restrict__ out_color, float* __restrict__ out_depth,
+                                               float* __restrict__ out_alpha, float* __restrict__ final_T,
+                                               int32_t* __restrict__ n_contrib)
 {
-    __shared__ float4 s_pair[33 * kPairQuads];  // (+1 slot: the prefetch of "the next slot" may run one past)
-    if (counters[1]) return;
-    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
-    // one single-wavefront workgroup per 8x8 quadrant; the four quadrants of a tile are consecutive workgroups of
-    // the same XCD (workgroup id -> XCD id % 8), tiles in the XCD-aware, balanced order of fs_common.h
-    const int wave = (blockIdx.x >> 3) & 3;
-    const int tile = tile_for_block((int)(blockIdx.x >> 5) * 8 + (int)(blockIdx.x & 7), gx, gy);
-    if (tile < 0) return;
-    const int tx = tile % gx, ty = tile / gx;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const f32x2 pfx = splat2((float)px), pfy = splat2((float)py);
     const uint32_t qbit = 1u << wave;
-    float4* const cp = s_pair;
-
-    const uint32_t a = offsets[tile];
-    const int n = (int)(offsets[tile + 1] - a);
-    const uint32_t* const pl = point_list + a;
-#ifdef FS_RENDER_TRACE
-    const unsigned long long t_begin = wall_clock64();
-#endif
 
     float T_ = 1.0f;
     f32x2 C01 = splat2(0.0f), C2D = splat2(0.0f);
     int last = 0;
-    bool done = !inside;
+    // Per-pixel predicates live as explicit 64-bit WAVE MASKS in SGPRs (ballot in, inverse_ballot out): the compiler
+    // keeps a loop-carried `bool done` as a 0/1 byte in a VGPR and re-materialises the mask for every use (v_and +
+    // v_cmp + s_xor per survivor, v_cndmask + v_or to update it: ~4 of ~30 VALU per survivor in round 2's loop).
+    unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);
 
     // software pipeline: list words two batches ahead, records one batch ahead
     uint32_t w_cur = lane < n ? pl[lane] : 0u;
@@ -994,16 +898,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         r0 = q[0]; r1 = q[1]; r2 = q[2];
     }
     for (int c = 0; c < n; c += 64) {
-        if (__all(done)) break;  // wave-uniform
+        if (done_m == ~0ull) break;  // every pixel of the quadrant is saturated (or outside the image)
         const bool hit = (w_cur & qbit) != 0;
         const unsigned long long hits = __ballot(hit);
         const float4 a0 = r0, a1 = r1, a2 = r2;
         w_cur = w_nxt;
+        w_nxt = c + 128 + lane < n ? pl[c + 128 + lane] : 0u;
         if (w_cur & qbit) {
             const float4* q = rec + 3 * (size_t)(w_cur >> 4);
             r0 = q[0]; r1 = q[1]; r2 = q[2];
         }
-        w_nxt = c + 128 + lane < n ? pl[c + 128 + lane] : 0u;
         if (!hits) continue;
         const int cnt = __popcll(hits);
         if (hit) {
@@ -1016,7 +920,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             d[8] = -a1.x; d[10] = skip_bits(a1.z);      // [B_a B_b thr_a thr_b] (B = b; thr = bits of -threshold)
             d[12] = a1.y; d[14] = __int_as_float(c + lane + 1);  // [op_a op_b pos_a pos_b]
             cp[(k >> 1) * kPairQuads + 4 + (k & 1)] = make_float4(a2.x, a2.y, a2.z, a1.w);  // [r g b depth]
-            // odd count: the unused half of the last slot gets weight 0; its colour must still be finite
+            // the batch's last step may be partial: its unused entries enter with weight 0, their colours must still be finite
             if (k == cnt - 1) {
                 const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 const int s = k >> 1;
@@ -1025,26 +929,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             }
         }
         wave_lds_sync();
-        // Two slots (four survivors) per step: the two packed exponent/exp chains are independent, so the
-        // scheduler interleaves them (no dependent-issue bubbles); the blend itself stays strictly in list order.
-        const int nslots = (cnt + 1) >> 1;
-#define FS_BLEND_ONE(COND, AL, OM, KR, POS, GE)                                                     \
+        // VM: mask of the pixels this survivor can reach (power in range, alpha >= 1/255, pixel not yet saturated)
+#define FS_BLEND_ONE(VM, AL, OM, KR, POS)                                                           \
         {                                                                                           \
             const float test_T = T_ * (OM);                                                         \
-            const bool vis = (COND) & !done & (GE);            /* GE: alpha >= 1/255 */             \
-            const bool ok = vis & (test_T >= 0.0001f);                                              \
-            done = done | (vis ^ ok);                                                               \
+            const unsigned long long vis = (VM) & ~done_m;                                          \
+            const unsigned long long okc = __builtin_amdgcn_ballot_w64(test_T >= 0.0001f);          \
+            done_m |= vis & ~okc;                     /* T would fall below 1e-4: the pixel is done, this one not applied */ \
+            const bool ok = __builtin_amdgcn_inverse_ballot_w64(vis & okc);                         \
             const f32x2 wgt = splat2(ok ? (AL) * T_ : 0.0f); /* weight 0: sums unchanged (finite colours) */ \
             C01 = fma2((f32x2){(KR).x, (KR).y}, wgt, C01);                                          \
             C2D = fma2((f32x2){(KR).z, (KR).w}, wgt, C2D);                                          \
             T_ = ok ? test_T : T_;                                                                  \
             if constexpr (TRACK) last = ok ? __float_as_int(POS) : last;                            \
         }
-        for (int p = 0; p < nslots; p += 2) {
-            const float4* q = cp + p * kPairQuads;
+        // One step = two slots = four survivors a, b | c, d, blended strictly in list order.  PARTIAL: the batch's last
+        // step when cnt is not a multiple of 4 (entries beyond cnt are masked out); full steps carry no such logic.
+        auto step = [&](const float4* q, auto partial, int left) __attribute__((always_inline)) {
+            constexpr bool PARTIAL = decltype(partial)::value;
             const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
             const float4 e0 = q[6], e1 = q[7], e2 = q[8], e3 = q[9];
-            const bool has_b = 2 * p + 1 < cnt, has_c = 2 * p + 2 < cnt, has_d = 2 * p + 3 < cnt;
             const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
             const f32x2 ex = (f32x2){e0.x, e0.y} - pfx, ey = (f32x2){e0.z, e0.w} - pfy;
             const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx,
@@ -1052,39 +956,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             const f32x2 pv = fma2((f32x2){e1.x, e1.y} * ex, ex,
                                   fma2((f32x2){e1.z, e1.w} * ey, ey, ((f32x2){e2.x, e2.y} * ex) * ey));
             // +0 <= q <= -threshold  <=>  bits(q) <= bits(-threshold) as unsigned (negative q and NaN compare above)
-            const bool ca = __float_as_uint(pw.x) <= __float_as_uint(c2.z);
-            const bool cb = has_b & (__float_as_uint(pw.y) <= __float_as_uint(c2.w));
-            const bool cc = has_c & (__float_as_uint(pv.x) <= __float_as_uint(e2.z));
-            const bool cd = has_d & (__float_as_uint(pv.y) <= __float_as_uint(e2.w));
-            if (__builtin_amdgcn_ballot_w64(((ca | cb) | (cc | cd)) & !done) == 0) continue;  // wave-uniform
+            unsigned long long ma = __builtin_amdgcn_ballot_w64(__float_as_uint(pw.x) <= __float_as_uint(c2.z));
+            unsigned long long mb = __builtin_amdgcn_ballot_w64(__float_as_uint(pw.y) <= __float_as_uint(c2.w));
+            unsigned long long mc = __builtin_amdgcn_ballot_w64(__float_as_uint(pv.x) <= __float_as_uint(e2.z));
+            unsigned long long md = __builtin_amdgcn_ballot_w64(__float_as_uint(pv.y) <= __float_as_uint(e2.w));
+            if constexpr (PARTIAL) { mb = left > 1 ? mb : 0ull; mc = left > 2 ? mc : 0ull; md = 0ull; }
+            if ((((ma | mb) | (mc | md)) & ~done_m) == 0ull) return;  // wave-uniform: nobody in range
             const float4 ka = q[4], kb = q[5], kc = q[10], kd = q[11];
             f32x2 ew = blend_exp_of_neg<FAST_EXP>(pw), ev = blend_exp_of_neg<FAST_EXP>(pv);
             f32x2 ow = (f32x2){c3.x, c3.y} * ew, ov = (f32x2){e3.x, e3.y} * ev;
             f32x2 aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
             f32x2 av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
-            bool ga, gb, gc, gd;   // alpha >= 1/255
+            unsigned long long ga, gb, gc, gd;   // alpha >= 1/255
             if constexpr (FAST_EXP) {
                 // hardware exp; a step with an alpha inside the guard band of the 1/255 threshold (fs_common.h) is
                 // re-evaluated with the contract exp, so the accept / reject decisions are those of the exact mode
                 const float glo = alpha_guard_lo(), ghi = alpha_guard_hi();
-                ga = aw.x >= ghi; gb = aw.y >= ghi; gc = av.x >= ghi; gd = av.y >= ghi;   // nothing in [glo, ghi): same as >= 1/255
-                const bool nb = ((aw.x >= glo) & !ga) | ((aw.y >= glo) & !gb) | ((av.x >= glo) & !gc) | ((av.y >= glo) & !gd);
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(nb) != 0, 0)) {  // wave-uniform, rare
+                ga = __builtin_amdgcn_ballot_w64(aw.x >= ghi); gb = __builtin_amdgcn_ballot_w64(aw.y >= ghi);
+                gc = __builtin_amdgcn_ballot_w64(av.x >= ghi); gd = __builtin_amdgcn_ballot_w64(av.y >= ghi);   // nothing in [glo, ghi): same as >= 1/255
+                const unsigned long long nb = (__builtin_amdgcn_ballot_w64(aw.x >= glo) & ~ga) | (__builtin_amdgcn_ballot_w64(aw.y >= glo) & ~gb)
+                                            | (__builtin_amdgcn_ballot_w64(av.x >= glo) & ~gc) | (__builtin_amdgcn_ballot_w64(av.y >= glo) & ~gd);
+                if (__builtin_expect(nb != 0ull, 0)) {  // wave-uniform, rare
                     ew = blend_exp_of_neg<false>(pw); ev = blend_exp_of_neg<false>(pv);
                     ow = (f32x2){c3.x, c3.y} * ew; ov = (f32x2){e3.x, e3.y} * ev;
                     aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
                     av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
-                    ga = aw.x >= 1.0f / 255.0f; gb = aw.y >= 1.0f / 255.0f; gc = av.x >= 1.0f / 255.0f; gd = av.y >= 1.0f / 255.0f;
+                    ga = __builtin_amdgcn_ballot_w64(aw.x >= 1.0f / 255.0f); gb = __builtin_amdgcn_ballot_w64(aw.y >= 1.0f / 255.0f);
+                    gc = __builtin_amdgcn_ballot_w64(av.x >= 1.0f / 255.0f); gd = __builtin_amdgcn_ballot_w64(av.y >= 1.0f / 255.0f);
                 }
             } else {
-                ga = aw.x >= 1.0f / 255.0f; gb = aw.y >= 1.0f / 255.0f; gc = av.x >= 1.0f / 255.0f; gd = av.y >= 1.0f / 255.0f;
+                ga = __builtin_amdgcn_ballot_w64(aw.x >= 1.0f / 255.0f); gb = __builtin_amdgcn_ballot_w64(aw.y >= 1.0f / 255.0f);
+                gc = __builtin_amdgcn_ballot_w64(av.x >= 1.0f / 255.0f); gd = __builtin_amdgcn_ballot_w64(av.y >= 1.0f / 255.0f);
             }
             const f32x2 mw = splat2(1.0f) - aw, mv = splat2(1.0f) - av;
-            FS_BLEND_ONE(ca, aw.x, mw.x, ka, c3.z, ga)
-            FS_BLEND_ONE(cb, aw.y, mw.y, kb, c3.w, gb)
-            FS_BLEND_ONE(cc, av.x, mv.x, kc, e3.z, gc)
-            FS_BLEND_ONE(cd, av.y, mv.y, kd, e3.w, gd)
-        }
+            FS_BLEND_ONE(ma & ga, aw.x, mw.x, ka, c3.z)
+            FS_BLEND_ONE(mb & gb, aw.y, mw.y, kb, c3.w)
+            FS_BLEND_ONE(mc & gc, av.x, mv.x, kc, e3.z)
+            if constexpr (!PARTIAL) FS_BLEND_ONE(md & gd, av.y, mv.y, kd, e3.w)
+        };
+        const int nfull = cnt >> 2;
+        for (int p = 0; p < nfull; ++p) step(cp + 2 * p * kPairQuads, std::false_type{}, 4);
+        if (cnt & 3) step(cp + 2 * nfull * kPairQuads, std::true_type{}, cnt & 3);
 #undef FS_BLEND_ONE
         // (the next batch's compaction overwrites the slots: DS operations of one wavefront execute in order)
         wave_lds_sync();
@@ -1099,26 +1011,69 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         out_depth[pix] = C2D.y;
         out_alpha[pix] = 1.0f - T_;
     }
-#ifdef FS_RENDER_TRACE
-    if (lane == 0 && tile < 8192) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (wave == 0) { g_render_trace[4 * tile] = t_begin; g_render_trace[4 * tile + 2] = ((unsigned long long)n << 32) | hwid; }
-        const unsigned long long t_end = wall_clock64();
-        atomicMax(&g_render_trace[4 * tile + 1], t_end);
-        atomicMax(&g_render_trace[4 * tile + 3], ~t_end);
-    }
-#endif
 }
-#ifdef FS_RENDER_TRACE
-}
-extern "C" __attribute__((visibility("default"))) int fs_debug_render_trace(unsigned long long* dst, int reset)
+
+// ------------------------------------------------------------------------------------------
+// sort_blend: one workgroup per tile.  All four wavefronts sort the tile's keys in LDS (bucket sort above), the sorted
+// list words stay in LDS, then each wavefront blends its own quadrant from them without another workgroup barrier.
+// LDS: 16 KiB key staging (reused as the four wavefronts' compaction areas once the sort is done) + 8 KiB bucket
+// offsets (reused as the sorted list) = 24.2 KiB -> 6 workgroups per CU, 6 wavefronts per SIMD.
+// Lists longer than the LDS sort's 2048 keys (none in the BASELINE configs) are sorted into the saved list in global
+// memory by the register / global bitonic networks and blended from there.
+// ------------------------------------------------------------------------------------------
+static_assert(4 * kPairArea * sizeof(float4) <= kSortLds * sizeof(unsigned long long), "compaction areas must fit the key staging");
+template <bool FAST_EXP, bool TRACK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void sort_blend_kernel(
+    int H, int W, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t tile_cap,
+    unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+    const float* __restrict__ bg, const uint32_t* __restrict__ counters,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, int32_t* __restrict__ n_contrib)
 {
-    if (reset) { static unsigned long long z[4 * 8192]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(fs::g_render_trace), z, sizeof(z)); }
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fs::g_render_trace), sizeof(unsigned long long) * 4 * 8192);
+    __shared__ __attribute__((aligned(16))) unsigned long long sk[kSortLds];
+    __shared__ uint32_t s_cnt[kSortLds + 1];
+    __shared__ uint32_t s_red[16];
+    if (counters[1]) return;  // overflowed capacity: key areas / saved lists are not backed by memory
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const int tile = tile_for_block(blockIdx.x, gx, gy);  // XCD-aware, balanced (fs_common.h)
+    if (tile < 0) return;
+    const uint32_t n = counts[tile];
+    unsigned long long* const kt = keys + (size_t)tile * tile_cap;
+    uint32_t* const gl = point_list + offsets[tile];   // this tile's range of the saved (compact) list
+    const bool in_lds = n <= (uint32_t)kSortLds;
+    if (n == 0) {
+    } else if (n <= 256u) {
+        sort_tile_buckets<1>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
+    } else if (n <= 512u) {
+        sort_tile_buckets<2>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
+    } else if (n <= 1024u) {
+        sort_tile_buckets<4>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
+    } else if (n <= 2048u) {
+        sort_tile_buckets<8>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
+    } else if (n <= 2560u) {
+        sort_tile_two_runs<8, 2>(kt, gl, n, sk);
+    } else if (n <= 3072u) {
+        sort_tile_two_runs<8, 4>(kt, gl, n, sk);
+    } else if (n <= 4096u) {
+        sort_tile_in_registers<16>(kt, gl, n, sk);
+    } else {
+        // rare: very long tile lists sort in place in global memory (same network)
+        __syncthreads();
+        bitonic_sort_any(kt, n);
+        for (uint32_t k = threadIdx.x; k < n; k += 256) gl[k] = (uint32_t)kt[k];
+    }
+    if (!in_lds) __threadfence_block();
+    __syncthreads();  // list complete (LDS or global); the key staging is free for the compaction areas
+    const int wave = threadIdx.x >> 6;
+    float4* const cp = (float4*)sk + wave * kPairArea;
+    const int tx = tile % gx, ty = tile / gx;
+    if (in_lds)
+        blend_quadrant<FAST_EXP, TRACK, true>(s_cnt, (int)n, rec, cp, H, W, tx, ty, wave, bg, out_color, out_depth, out_alpha,
+                                              final_T, n_contrib);
+    else
+        blend_quadrant<FAST_EXP, TRACK, false>(gl, (int)n, rec, cp, H, W, tx, ty, wave, bg, out_color, out_depth, out_alpha,
+                                               final_T, n_contrib);
 }
-namespace fs {
-#endif
 
 }  // namespace fs
 
@@ -1134,7 +1089,7 @@ FS_API int fs_raster_buffer_sizes(int32_t N, int32_t H, int32_t W, int64_t cap, 
     out[0] = geom_bytes(N > 0 ? N : 1);
     out[1] = binning_offsets_bytes(H, W) + align_up((size_t)(cap > 0 ? cap : 1) * 4, 256);
     out[2] = align_up(P * 4, 256) * 2;
-    out[3] = align_up(T * 4, 256) * 2 + align_up((size_t)(cap > 0 ? cap : 1) * 8, 256);
+    out[3] = align_up(T * 4, 256) + align_up(T * (size_t)tile_capacity(cap, (int)T) * 8, 256);
     return FS_OK;
 }
 
@@ -1185,8 +1140,8 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     float* final_T = (float*)image;
     int32_t* n_contrib = (int32_t*)((char*)image + align_up(P * 4, 256));
     uint32_t* counts = (uint32_t*)scratch;
-    uint32_t* cursors = (uint32_t*)((char*)scratch + align_up((size_t)T * 4, 256));
-    unsigned long long* keys = (unsigned long long*)((char*)scratch + 2 * align_up((size_t)T * 4, 256));
+    unsigned long long* keys = (unsigned long long*)((char*)scratch + align_up((size_t)T * 4, 256));
+    const uint32_t tile_cap = tile_capacity(cap, T);
 
     if (hipMemsetAsync(counts, 0, (size_t)T * 4, st) != hipSuccess) {
         set_last_error("memset tile counts", hipGetLastError());
@@ -1200,42 +1155,28 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
             ScopedStage prof_(kStPreprocess, st);
             hipLaunchKernelGGL(preprocess_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, means3D,
                                cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos,
-                               tanfov_dev, scale_dev, g, radii, counts);
+                               tanfov_dev, scale_dev, g, radii, counts, keys, tile_cap);
         }
         FS_CHECK_LAUNCH("preprocess");
     }
     {
         ScopedStage prof_(kStTileScan, st);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, cursors, T,
-                           counters, (unsigned long long)cap);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, T,
+                           counters, (unsigned long long)cap, tile_cap);
     }
     FS_CHECK_LAUNCH("tile_scan");
-    if (d.N > 0) {
-        {
-            ScopedStage prof_(kStEmit, st);
-            hipLaunchKernelGGL(emit_kernel, dim3((d.N + 255) / 256), dim3(256), 0, st, d.N, gx, d.flags, g, offsets,
-                               cursors, keys, (unsigned long long)cap);
-        }
-        FS_CHECK_LAUNCH("emit");
-    }
     const int nblk = tile_grid_blocks(gx, (d.H + kTile - 1) / kTile);
-    {
-        ScopedStage prof_(kStTileSort, st);
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(nblk), dim3(256), 0, st, gx, (d.H + kTile - 1) / kTile, offsets, keys,
-                           point_list, counters);
-    }
-    FS_CHECK_LAUNCH("tile_sort");
     {
         ScopedStage prof_(kStRender, st);
 #define FS_LAUNCH_RENDER(F, TR)                                                                                     \
-        hipLaunchKernelGGL((render_kernel<F, TR>), dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets, point_list,  \
-                           g.rec, bg, counters, out_color, out_depth, out_alpha, final_T, n_contrib)
+        hipLaunchKernelGGL((sort_blend_kernel<F, TR>), dim3(nblk), dim3(256), 0, st, d.H, d.W, counts, offsets, tile_cap, \
+                           keys, point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T, n_contrib)
         const bool track = !(d.flags & FS_RASTER_NO_BACKWARD_STATE);
         if (d.flags & FS_RASTER_FAST_EXP) { if (track) FS_LAUNCH_RENDER(true, true); else FS_LAUNCH_RENDER(true, false); }
         else { if (track) FS_LAUNCH_RENDER(false, true); else FS_LAUNCH_RENDER(false, false); }
 #undef FS_LAUNCH_RENDER
     }
-    FS_CHECK_LAUNCH("render");
+    FS_CHECK_LAUNCH("sort_blend");
     return FS_OK;
 }
 

@@ -160,7 +160,7 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
 # ---------------------------------------------------------------------------------------------
 # Batched multi-view path: one shared Gaussian set, v views, one sync.
 # ---------------------------------------------------------------------------------------------
-_pending_checks: list = []  # (counters [v,2], states | None, device) of render_views(..., check="deferred") calls
+_pending_checks: list = []  # (counters [v,2], states | None, device, (H, W)) of render_views(..., check="deferred") calls
 
 
 def check_deferred() -> None:
@@ -170,9 +170,9 @@ def check_deferred() -> None:
     pend, _pending_checks = _pending_checks, []
     if not pend:
         return
-    counters = torch.cat([c for c, _, _ in pend]).tolist()
+    counters = torch.cat([c for c, _, _, _ in pend]).tolist()
     bad, k = 0, 0
-    for c, states, dev in pend:
+    for c, states, dev, hw in pend:
         st = R._state(dev)
         for i in range(c.shape[0]):
             n_inst, overflow = counters[k]
@@ -181,7 +181,9 @@ def check_deferred() -> None:
             if states is not None:
                 states[i].num_rendered = n_inst
             st.last_instances = max(st.last_instances, n_inst)
-            bad += 1 if overflow else 0
+            if overflow:    # (non-zero = the largest tile list: sizes the next call's capacity)
+                bad += 1
+                st.retry_cap = max(st.retry_cap, R.retry_capacity(n_inst, overflow & 0xFFFFFFFF, *hw))
     if bad:
         raise R._lib.FreeSplatHipError(f"{bad} deferred view(s) overflowed their instance capacity; "
                                        "re-render them (capacity history has been updated)")
@@ -249,14 +251,15 @@ class _RenderViews(torch.autograd.Function):
                      campos=campos, tanfov=tanfov, scale=scale)
         if deferred:
             # without a backward to come only the 8-byte counter pairs stay alive until the check, not the buffers
-            _pending_checks.append((counters, states if any(ctx.needs_input_grad) else None, dev))
+            _pending_checks.append((counters, states if any(ctx.needs_input_grad) else None, dev, (h, w)))
         else:
             counters = torch.stack([rs.counters for rs in states]).tolist()  # the single sync
             worst = 0
             for i, (n_inst, overflow) in enumerate(counters):
                 n_inst &= 0xFFFFFFFF
                 if overflow:
-                    states[i] = launch(i, n_inst + 1024)
+                    st.retry_cap = max(st.retry_cap, R.retry_capacity(n_inst, overflow & 0xFFFFFFFF, h, w))
+                    states[i] = launch(i, st.retry_cap)
                     batch = None        # that view now lives in its own buffers: backward goes view by view
                 states[i].num_rendered = n_inst
                 worst = max(worst, n_inst)

@@ -67,6 +67,7 @@ class _DeviceState:
     def __init__(self):
         self.scratch: dict[int, Tensor] = {}   # one reusable scratch per HIP stream
         self.last_instances = 0
+        self.retry_cap = 0                     # capacity a past overflow asked for (retry_capacity)
         self.side_streams: list = []
 
 
@@ -89,7 +90,15 @@ def _buffer_sizes(N: int, H: int, W: int, cap: int):
 
 def default_capacity(N: int, st: _DeviceState) -> int:
     """Instance capacity: generous (HBM is 288 GB) so the overflow retry is the rare path."""
-    return max(1 << 20, 8 * N, int(st.last_instances * 1.25) + 1024)
+    return max(1 << 20, 8 * N, int(st.last_instances * 1.25) + 1024, st.retry_cap)
+
+
+def retry_capacity(n_inst: int, max_tile: int, H: int, W: int) -> int:
+    """Capacity for the retry after an overflow: counters = {instances, largest tile list}.  The saved lists need
+    `n_inst` entries; every tile owns a fixed key area of tile_capacity(cap, T) = pow2 >= 4*cap/T slots
+    (csrc/fs_common.h), which must hold the largest tile list."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return max(n_inst + 1024, (max_tile * T + 3) // 4 + 1)
 
 
 class RasterState:
@@ -174,8 +183,8 @@ def rasterize_forward_checked(dims, means3D, cov3D, shs, colors, opacities, bg, 
     rs, color, depth, alpha = _launch_forward(dims, means3D, cov3D, shs, colors, opacities, bg, view,
                                               proj, campos, cap)
     n_inst, overflow = (int(x) & 0xFFFFFFFF for x in rs.counters.tolist())
-    if overflow:
-        cap = n_inst + 1024
+    if overflow:   # (non-zero = the largest tile list)
+        cap = st.retry_cap = max(st.retry_cap, retry_capacity(n_inst, overflow, dims.H, dims.W))
         rs, color, depth, alpha = _launch_forward(dims, means3D, cov3D, shs, colors, opacities, bg,
                                                   view, proj, campos, cap)
         n_inst, overflow = (int(x) & 0xFFFFFFFF for x in rs.counters.tolist())
