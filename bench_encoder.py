@@ -111,15 +111,13 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True):
         dt = timed(lambda: m.fuse_gaussians(*a), steps, 0)
         _lib.profile_enable(False)
         ms, cnt = _lib.profile_collect()["ptf"]
-    # training step of the fold (forward + backward, every differentiable input and the GRU parameters): the HIP
-    # path (_PtfFold) and, beside it, the op-by-op torch formulation on the same index lists
+    # training step of the fold (forward + backward, every differentiable input and the GRU parameters): the HIP path (_PtfFold)
     def train_step(fn):
         ins = [t.detach().clone().requires_grad_(True) for t in (a[0][0], a[1][0], a[2], a[3], a[4])]
         out = fn([ins[0]], [ins[1]], ins[2], ins[3], ins[4], *a[5:])
         sum(o.sum() for o in out).backward()
     n_tr = max(2, steps // 4)
     dt_train = timed(lambda: train_step(m.fuse_gaussians), n_tr, 1)
-    dt_train_torch = timed(lambda: train_step(m.fuse_gaussians_torch), n_tr, 1)
     with torch.no_grad():
         m.fuse_gaussians(*a)            # (LAST_FOLD_COUNTS of the inference fold)
     from freesplat_amd import ptf as _ptf
@@ -151,7 +149,7 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True):
                  "dtype": "f32 / int64 indices", "data": "synthetic",
                  "config": {"workload": "ptf_native", "views": V, "gaussians_in": M_in, "gaussians_out": M_out,
                             "fused_pairs_per_step": [c[1] for c in steps_counts[1:]]},
-                 "train_fwd_bwd": {"hip_ms": dt_train * 1e3, "torch_ops_on_hip_indices_ms": dt_train_torch * 1e3,
+                 "train_fwd_bwd": {"hip_ms": dt_train * 1e3, 
                                    "what": "forward + backward of the fold w.r.t. latents, coords, densities, weights, "
                                            "depths and the GRU parameters; gradients checked against the oracle's "
                                            "autograd in tests/test_ptf_hip.py"},

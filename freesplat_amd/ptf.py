@@ -16,8 +16,8 @@ The fold is HIP in both modes (b = 1, the only shape the reference's indexing su
     backward (fs_ptf_gru_backward: forward re-run + the six linear layers transposed, on the fp32 matrix cores, giving
     the input-row gradients); only the weight gradients dW = dY^T X -- sums over ~10^5 pairs -- are library GEMMs on
     the per-pair factors the kernel writes;
-  * `fuse_gaussians_torch` keeps the op-by-op torch formulation (fs_ptf_match indices + autograd) for b > 1 inputs and
-    as the cross-check of the HIP backward in tests/test_ptf_hip.py.
+  * no torch-op formulation of the fold lives in the product: the op-by-op cross-check of the HIP backward is
+    tests/ptf_torch_ref.py.  One scene per call, as the reference's caller does (encoder_freesplat.py:355-368).
 """
 from __future__ import annotations
 
@@ -444,59 +444,13 @@ def fuse_gaussians(self, gaussians, coords, densities, weight_emb, depths, extri
     needs_grad = torch.is_grad_enabled() and (
         any(t.requires_grad for t in (gaussians[0], coords[0], densities, weight_emb, depths))
         or any(q.requires_grad for q in self.gru.parameters()))
-    if gaussians[0].shape[0] == 1:
-        fn = _fuse_gaussians_train if needs_grad else _fuse_gaussians_fused
-        return fn(self.gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
-                  depth_thres)
-    return fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
-                                depth_thres)
-
-
-def fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
-                         depth_thres=0.1):
-    """The fold step by step in torch device ops on the HIP index lists (fs_ptf_match), differentiable through
-    autograd; one host sync per view.  Used for b > 1 and as the cross-check of _PtfFold's backward."""
-    length = gaussians[0].shape[1]
-    G = gaussians[0][:, 0]
-    R = densities[:, 0]
-    O = weight_emb[:, 0]
-    X = coords[0][:, 0, :, 0, 0]
-    Ex = extrinsics[:, 0][:, None].repeat(1, G.shape[1], 1, 1)
-    depths = depths.reshape(depths.shape[0], -1)
-    Dp = depths[None, 0]
-    h, w = image_shape
-    for i in range(1, length):
-        extrinsic = extrinsics[0, i]
-        K = intrinsics[0, i].clone()
-        K[:1, :] *= w
-        K[1:2, :] *= h
-        kpix = torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
-        w2c = torch.linalg.inv_ex(extrinsic).inverse
-        keep, fuse, fpix, app = match_view(X[0], w2c, kpix, depths[i], h, w, depth_thres)
-        if fuse.numel() > 0:
-            xe = positional_encoding(torch.cat([R[:, fuse], weight_emb[:, i, fpix]], dim=-1), 6)
-            he = positional_encoding(torch.cat([densities[:, i, fpix], O[:, fuse]], dim=-1), 6)
-            fused = self.gru(gaussians[0][:, i, fpix].unsqueeze(2), G[:, fuse].unsqueeze(2), xe, he).squeeze(2)
-            w0 = R[:, fuse].repeat(1, 1, 1, 2)
-            w1 = densities[:, i, fpix].repeat(1, 1, 1, 2)
-            G = torch.cat([G[:, keep], fused], dim=1)
-            X = torch.cat([X[:, keep], (X[:, fuse] * w0[..., 1] + coords[0][:, i, fpix, 0, 0] * w1[..., 1])
-                           / (w0[..., 1] + w1[..., 1])], dim=1)
-            Ex = torch.cat([Ex[:, keep], (Ex[:, fuse] * w0[..., :1] + extrinsics[:, i, None] * w1[..., :1])
-                            / (w0[..., :1] + w1[..., :1])], dim=1)
-            Dp = torch.cat([Dp[:, keep], (Dp[:, fuse] * w0[..., 0, 0] + depths[None, i, fpix] * w1[..., 0, 0])
-                            / (w0[..., 0, 0] + w1[..., 0, 0])], dim=1)
-            R_new = R[:, fuse] + densities[:, i, fpix]
-            O_new = O[:, fuse] + weight_emb[:, i, fpix]
-            R = torch.cat([R[:, keep], R_new], dim=1)
-            O = torch.cat([O[:, keep], O_new], dim=1)
-        G = torch.cat([G, gaussians[0][:, i, app]], dim=1)
-        X = torch.cat([X, coords[0][:, i, app, 0, 0]], dim=1)
-        R = torch.cat([R, densities[:, i, app]], dim=1)
-        O = torch.cat([O, weight_emb[:, i, app]], dim=1)
-        Ex = torch.cat([Ex, extrinsics[:, i, None].repeat(1, app.numel(), 1, 1)], dim=1)
-        Dp = torch.cat([Dp, depths[None, i, app]], dim=1)
-    return G, X, Ex, Dp
+    if gaussians[0].shape[0] != 1:
+        # the reference folds one scene per call (encoder_freesplat.py:355-368 slices x[b:b+1] for every b); with b > 1
+        # its body would apply scene 0's match lists to every scene's rows -- no caller does that
+        raise NotImplementedError("fuse_gaussians folds ONE scene per call (pass x[b:b+1] slices, as "
+                                  "EncoderFreeSplat.forward does); got b = %d" % gaussians[0].shape[0])
+    fn = _fuse_gaussians_train if needs_grad else _fuse_gaussians_fused
+    return fn(self.gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape, depth_thres)
 
 
 class PixelwiseTripletFusion(nn.Module):
@@ -508,4 +462,3 @@ class PixelwiseTripletFusion(nn.Module):
         self.gru = GRU()
 
     fuse_gaussians = fuse_gaussians
-    fuse_gaussians_torch = fuse_gaussians_torch

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from ptf_torch_ref import fuse_gaussians_torch
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 pytestmark = pytest.mark.gpu
@@ -105,7 +107,7 @@ def test_fused_inference_path_equals_differentiable_path(hip_device, V, h, w):
     with torch.no_grad():
         fused = m.fuse_gaussians(*a)
     ref = m.fuse_gaussians(*a)   # GRU parameters require grad -> training path (HIP fold + HIP backward)
-    tor = m.fuse_gaussians_torch(*a)   # op-by-op torch formulation on the HIP index lists
+    tor = fuse_gaussians_torch(m, *a)   # op-by-op torch formulation on the HIP index lists (tests/ptf_torch_ref.py)
     assert ref[0].requires_grad and tor[0].requires_grad and not fused[0].requires_grad
     for x, y, t, name in zip(fused, ref, tor, ("latent", "xyz", "extrinsics", "depths")):
         assert x.shape == y.shape == t.shape, name
@@ -145,7 +147,7 @@ def test_fold_vs_oracle_and_gradients(hip_device, V, h, w):
     assert out[0].shape == ref[0].shape and out[0].shape[1] < V * h * w   # something fused
     for a, b, name in zip(out, ref, ("latent", "xyz", "extrinsics", "depths")):
         assert (a.detach().cpu() - b.detach()).abs().max().item() <= 1e-4, name
-    out_t, gin_t, gpar_t = run(m.fuse_gaussians_torch)
+    out_t, gin_t, gpar_t = run(lambda *a_: fuse_gaussians_torch(m, *a_))
     rel = lambda a, b: (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
     for a, t, c, name in zip(gin, gin_t, cpu_in, names):
         assert a is not None and a.shape == c.grad.shape, name
@@ -166,7 +168,7 @@ def test_fold_backward_with_tied_winners(hip_device):
     m = m.to(hip_device)
     d = lambda t: t.to(hip_device)
     res = []
-    for fn in (m.fuse_gaussians, m.fuse_gaussians_torch):
+    for fn in (m.fuse_gaussians, lambda *a_: fuse_gaussians_torch(m, *a_)):
         ins = [d(g[k]).clone().requires_grad_(True) for k in ("latents", "coords", "densities", "weights", "depths")]
         out = fn([ins[0]], [ins[1]], ins[2], ins[3], ins[4], d(g["extrinsics"])[None], d(g["intrinsics"])[None],
                  (int(g["h"]), int(g["w"])))

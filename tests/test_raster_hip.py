@@ -203,23 +203,27 @@ def test_capacity_overflow_retry(hip_device, monkeypatch):
 
 
 def test_tile_key_area_overflow_retry(hip_device, monkeypatch):
-    """Every tile owns a fixed key area (tile_capacity(cap, T) slots): a scene that piles more instances onto ONE tile
-    than that -- while the instance total still fits the capacity -- must be reported (counters[1] = the largest tile
-    list) and retried with a capacity whose key areas hold it; same image as the oracle."""
+    """Every tile owns a fixed key area (tile_capacity(cap, T) slots, >= 4x the mean list length): a scene that piles more
+    instances onto ONE tile than that -- while the instance total still fits the capacity -- must be reported
+    (counters[1] = the largest tile list) and retried with a capacity whose key areas hold it; same image as the oracle."""
     from freesplat_amd import rasterizer as R
-    H = W = 64
-    scene, cams = small_scene(N=60, H=H, W=W, seed=12)
+    H = W = 128                                                   # 64 tiles
+    scene, cams = small_scene(N=2, H=H, W=W, seed=12)
     for k in ("means", "covariances", "harmonics", "opacities"):
-        scene[k] = torch.cat([scene[k]] * 60)                 # 3600 Gaussians, 60 copies of each
+        scene[k] = torch.cat([scene[k]] * 1500)                   # 3000 Gaussians on the same few tiles
     vi = view_inputs(scene, cams, 0, H, W)
     st = oracle_forward(vi)                                       # (the oracle's lists are the unculled ones)
-    counts = st["ranges"][:, 1] - st["ranges"][:, 0]
-    assert counts.max() > 2048                                    # more than the minimum key area of one tile
+    counts = (st["ranges"][:, 1] - st["ranges"][:, 0]).astype(np.int64)
+    cap = int(counts.sum()) + 64
+    tile_cap = 2048
+    while tile_cap < (4 * cap + 63) // 64:
+        tile_cap *= 2
+    assert counts.max() > tile_cap                                # the total fits `cap`, the big tiles' key areas do not
     monkeypatch.setattr(R, "TILE_CULL", False)
-    monkeypatch.setattr(R, "default_capacity", lambda N, s: int(counts.sum()) + 64)   # total fits, the big tile does not
+    monkeypatch.setattr(R, "default_capacity", lambda N, s: max(cap, s.retry_cap))
     R._state(hip_device).retry_cap = 0
     (color, _, _, _), _ = hip_forward(vi, hip_device)
-    assert R._state(hip_device).retry_cap >= (int(counts.max()) * 16 + 3) // 4       # the retry path was taken
+    assert R._state(hip_device).retry_cap >= (int(counts.max()) * 64 + 3) // 4       # the retry path was taken
     np.testing.assert_array_equal(color.cpu().numpy(), st["color"])
     R._state(hip_device).retry_cap = 0
 
