@@ -50,8 +50,7 @@ __device__ __forceinline__ float fs_exp(float x)
     if (x < -80.0f) return 0.0f;
     const float t = fmaf(x, 1.44269504088896341f, 12582912.0f);
     const float n = t - 12582912.0f;
-    float r = fmaf(n, -0.693145751953125f, x);       // Cody-Waite: ln2 = hi + lo
-    r = fmaf(n, -1.42860676533018e-6f, r);
+    const float r = fmaf(n, -0.693147182464599609375f, x);   // one fma with the fp32 ln2 (exact product; see the oracle's note)
     float p = fmaf(r, kExpC5, kExpC4);
     p = fmaf(r, p, kExpC3);
     p = fmaf(r, p, kExpC2);
@@ -117,8 +116,7 @@ __device__ __forceinline__ f32x2 fs_exp2_nonpos(f32x2 x)
     const f32x2 magic = splat2(12582912.0f);
     const f32x2 t = fma2(x, splat2(1.44269504088896341f), magic);
     const f32x2 n = t - magic;
-    f32x2 r = fma2(n, splat2(-0.693145751953125f), x);
-    r = fma2(n, splat2(-1.42860676533018e-6f), r);
+    const f32x2 r = fma2(n, splat2(-0.693147182464599609375f), x);
     f32x2 q = fma2(r, splat2(kExpC5), splat2(kExpC4));
     q = fma2(r, q, splat2(kExpC3));
     q = fma2(r, q, splat2(kExpC2));
@@ -136,8 +134,7 @@ __device__ __forceinline__ f32x2 fs_exp2_of_neg(f32x2 q)
     const f32x2 magic = splat2(12582912.0f);
     const f32x2 t = fma2(q, splat2(-1.44269504088896341f), magic);   // == fma(-q, log2 e, magic)
     const f32x2 n = t - magic;
-    f32x2 r = fma2(n, splat2(-0.693145751953125f), -q);
-    r = fma2(n, splat2(-1.42860676533018e-6f), r);
+    const f32x2 r = fma2(n, splat2(-0.693147182464599609375f), -q);
     f32x2 p = fma2(r, splat2(kExpC5), splat2(kExpC4));
     p = fma2(r, p, splat2(kExpC3));
     p = fma2(r, p, splat2(kExpC2));

@@ -166,8 +166,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
             const float4* q = cp + p * kBwdQuads;
             const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
             const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
-            const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx,
-                                  fma2((f32x2){c1.z, c1.w} * dy, dy, ((f32x2){c2.x, c2.y} * dx) * dy));
+            const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx, dy * fma2((f32x2){c1.z, c1.w}, dy, (f32x2){c2.x, c2.y} * dx));
             // pw = -power; +0 <= pw <= -threshold as ONE unsigned compare of the bit patterns
             bool on_a = __float_as_int(c3.z) <= last, on_b = __float_as_int(c3.w) <= last;
             on_a = on_a & (__float_as_uint(pw.x) <= __float_as_uint(c2.z));

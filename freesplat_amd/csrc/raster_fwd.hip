@@ -951,10 +951,9 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
             const float4 e0 = q[6], e1 = q[7], e2 = q[8], e3 = q[9];
             const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
             const f32x2 ex = (f32x2){e0.x, e0.y} - pfx, ey = (f32x2){e0.z, e0.w} - pfy;
-            const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx,
-                                  fma2((f32x2){c1.z, c1.w} * dy, dy, ((f32x2){c2.x, c2.y} * dx) * dy));   // = -power
-            const f32x2 pv = fma2((f32x2){e1.x, e1.y} * ex, ex,
-                                  fma2((f32x2){e1.z, e1.w} * ey, ey, ((f32x2){e2.x, e2.y} * ex) * ey));
+            // -power = A dx^2 + dy (C dy + B dx): 3 multiplications + 2 fmas (the oracle's own association)
+            const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx, dy * fma2((f32x2){c1.z, c1.w}, dy, (f32x2){c2.x, c2.y} * dx));
+            const f32x2 pv = fma2((f32x2){e1.x, e1.y} * ex, ex, ey * fma2((f32x2){e1.z, e1.w}, ey, (f32x2){e2.x, e2.y} * ex));
             // +0 <= q <= -threshold  <=>  bits(q) <= bits(-threshold) as unsigned (negative q and NaN compare above)
             unsigned long long ma = __builtin_amdgcn_ballot_w64(__float_as_uint(pw.x) <= __float_as_uint(c2.z));
             unsigned long long mb = __builtin_amdgcn_ballot_w64(__float_as_uint(pw.y) <= __float_as_uint(c2.w));

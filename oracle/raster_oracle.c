@@ -43,17 +43,18 @@ typedef struct {
 } fso_params;
 
 /* ---- deterministic exp, x <= 0 in practice -------------------------------------------
- * n = round(x log2 e) through the magic-number addition (ONE fused rounding: fmaf), Cody-Waite reduction
- * r = x - n ln2 in two fmas, degree-5 minimax polynomial in Horner form (max relative error 1.5e-7 = 2.5 ulp over the
- * reduced range, measured in fp32), scaling by 2^n.  Every operation is an IEEE fma / add / ldexp: the HIP kernels
+ * n = round(x log2 e) through the magic-number addition (ONE fused rounding: fmaf), reduction r = x - n ln2 in ONE fma
+ * with the fp32 ln2 (the product n * fl(ln2) is exact inside the fma; fl(ln2) - ln2 = 1.9e-9, so for the |n| <= 8 of
+ * every alpha that can reach 1/255 the reduced argument is off by <= 1.5e-8 = 0.25 ulp of the result -- the hi/lo split
+ * of round 2 bought nothing there), degree-5 minimax polynomial in Horner form (max relative error 1.7e-7 = 2.8 ulp on
+ * [-6, 0], measured in fp32; 3.7e-7 on [-80, 0]), scaling by 2^n.  Every operation is an IEEE fma / add / ldexp: the HIP kernels
  * evaluate exactly this sequence (fs_common.h: fs_exp, fs_exp2_of_neg). */
 static inline float fso_exp(float x)
 {
     if (x < -80.0f) return 0.0f;
     const float t = fmaf(x, 1.44269504088896341f, 12582912.0f);   /* 1.5 * 2^23: the sum's low bits are round(x log2 e) */
     const float n = t - 12582912.0f;
-    float r = fmaf(n, -0.693145751953125f, x);       /* Cody-Waite: ln2 = hi + lo */
-    r = fmaf(n, -1.42860676533018e-6f, r);
+    const float r = fmaf(n, -0.693147182464599609375f, x);
     float p = fmaf(r, 0.008290314115583897f, 0.04189793020486832f);
     p = fmaf(r, p, 0.1666763573884964f);
     p = fmaf(r, p, 0.4999915063381195f);
@@ -309,7 +310,7 @@ FSO_API void fso_render(const fso_params* P, const unsigned* ranges, const unsig
                     const float dx = means2D[2 * g] - pfx, dy = means2D[2 * g + 1] - pfy;
                     const float* co = conic_opacity + 4 * g;
                     const float hA = -0.5f * co[0], hC = -0.5f * co[2], nB = -co[1];
-                    const float power = fmaf(hA * dx, dx, fmaf(hC * dy, dy, (nB * dx) * dy));
+                    const float power = fmaf(hA * dx, dx, dy * fmaf(hC, dy, nB * dx));
                     if (power > 0.0f) continue;
                     const float alpha = fminf(0.99f, co[3] * fso_blend_exp(power));
                     if (alpha < 1.0f / 255.0f) continue;
@@ -383,7 +384,7 @@ FSO_API void fso_render_backward(const fso_params* P, const unsigned* ranges,
                     const float dx = means2D[2 * g] - pfx, dy = means2D[2 * g + 1] - pfy;
                     const float* co = conic_opacity + 4 * g;
                     const float hA = -0.5f * co[0], hC = -0.5f * co[2], nB = -co[1];
-                    const float power = fmaf(hA * dx, dx, fmaf(hC * dy, dy, (nB * dx) * dy));
+                    const float power = fmaf(hA * dx, dx, dy * fmaf(hC, dy, nB * dx));
                     if (power > 0.0f) continue;
                     const float G = fso_blend_exp(power);
                     const float alpha = fminf(0.99f, co[3] * G);
