@@ -29,6 +29,16 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / max(steps, 1)
 
 
+def _traffic(workload):
+    """(bytes per call / fold, source) from the newest committed profiles/*_traffic.json (profiles/tools/fwd_traffic.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    try:
+        import fwd_traffic
+        return fwd_traffic.lookup(workload)
+    except Exception:
+        return None, None
+
+
 def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, cpu=True, cpu_views=None):
     """`cpu_views`: how many of the V current views the CPU baseline sweeps (bounded sample; default all)."""
     import inputs
@@ -53,6 +63,7 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
         _lib.profile_enable(False)
         ms, cnt = _lib.profile_collect()["cost_volume"]
     flops = V * h4 * w4 * D * (480 * K + 5248)
+    wl_name = {(2, 1, 96): "cv_native_K1", (3, 2, 242): "cv_c3scale_K2", (10, 8, 96): "cv_fvt10_K8"}.get((V, K, h4), "")
     kern = ms / max(cnt, 1) * 1e-3
     # training step of the volume: forward + backward w.r.t. both feature maps and the six MLP tensors
     ga = {k: (v.clone().requires_grad_(True) if k in ("cur_feats", "src_feats") else v) for k, v in args.items()}
@@ -88,10 +99,13 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
             "roofline": {"bound": "mfma", "kernel": "cost_volume (relayout + sweep)", "achieved": flops / kern / 1e12,
                          "peak": 157.3, "unit": "TFLOP/s", "frac": flops / kern / 1e12 / 157.3,
                          "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern * 1e3, "launches": cnt,
-                         "traffic": None}}, **extra)
+                         "traffic": _traffic(wl_name)[0], "traffic_source": _traffic(wl_name)[1],
+                         "traffic_unit": "HBM bytes per call (all current views)"}}, **extra)
 
 
-def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True):
+def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
+    """`cpu_steps`: bound the CPU baseline to the fold of the first cpu_steps + 1 views (the later steps of a long fold
+    are larger -- the state grows -- so scaling that time to all V - 1 steps UNDER-estimates the CPU time)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_ptf_hip import _scene
     from freesplat_amd import _lib
@@ -127,23 +141,32 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True):
     P, REC = h * w, 344
     alg, M = 0, P
     for i in range(1, V):
-        k, f, a, m_out = steps_counts[i]
-        alg += M * 12 + P * 4 + (k + 2 * f + a) * REC + (k + f + a) * REC
+        k, f, n_app, m_out = steps_counts[i]
+        alg += M * 12 + P * 4 + (k + 2 * f + n_app) * REC + (k + f + n_app) * REC
         M = m_out
     kern_ms = ms / steps   # every launch of the library's ptf stage (event-bracketed), per fold call
     extra = {}
     if cpu:
         torch.set_num_threads(os.cpu_count() or 1)
+        nv = V if cpu_steps is None else min(V, cpu_steps + 1)
         with torch.no_grad():
             t0 = time.perf_counter()
-            ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w))
+            ref = po.fuse_gaussians(params, lat[:, :nv], coords[:, :nv], dens[:, :nv], wts[:, :nv], depths[:nv], E[None, :nv],
+                                    Kn[None, :nv], (h, w))
             t_cpu = time.perf_counter() - t0
+            got = out if nv == V else [x.cpu() for x in m.fuse_gaussians([a[0][0][:, :nv]], [a[1][0][:, :nv]], a[2][:, :nv], a[3][:, :nv],
+                                                                         a[4][:nv], a[5][:, :nv], a[6][:, :nv], (h, w))]
         torch.set_num_threads(8)
-        err = max(float((x - y).abs().max()) for x, y in zip(out, ref))
-        extra = {"cpu_baseline": {"value": 1.0 / t_cpu, "unit": "folds/s", "cores": os.cpu_count(), "kind": "port",
-                                  "sample": f"1 fold of {V} views through oracle/ptf_oracle.py (numpy match + torch CPU GRU; "
-                                            "pinned by the reference's golden folds)"},
-                 "parity": {"max_abs_err_vs_oracle": err, "same_count_and_order": bool(out[0].shape == ref[0].shape)}}
+        err = max(float((x - y).abs().max()) for x, y in zip(got, ref))
+        scale = (V - 1) / (nv - 1)
+        extra = {"cpu_baseline": {"value": 1.0 / (t_cpu * scale), "unit": "folds/s", "cores": os.cpu_count(), "kind": "port",
+                                  "sample": (f"1 fold of {V} views" if nv == V else
+                                             f"the fold of the first {nv} of {V} views ({nv - 1} of {V - 1} steps, time scaled by "
+                                             f"{scale:.1f}: an under-estimate, later steps fold into a larger state)")
+                                            + " through oracle/ptf_oracle.py (numpy match + torch CPU GRU; pinned by the "
+                                              "reference's golden folds)"},
+                 "parity": {"max_abs_err_vs_oracle": err, "same_count_and_order": bool(got[0].shape == ref[0].shape),
+                            "views_compared": nv}}
     M_in, M_out = V * h * w, out[0].shape[1]
     return dict({"metric": f"PTF folds/sec, {V} views @ {h}x{w}", "value": 1.0 / dt, "unit": "folds/s", "ms_per_call": dt * 1e3,
                  "dtype": "f32 / int64 indices", "data": "synthetic",
@@ -156,7 +179,8 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True):
                  "roofline": {"bound": "hbm", "kernel": "ptf fold (match + gru_inputs + gru + write_state, all steps)",
                               "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                               "frac": alg / (kern_ms * 1e-3) / 8e12, "algorithmic_bytes_per_fold": alg,
-                              "kernel_ms_per_fold": kern_ms, "launches": cnt // max(steps, 1), "traffic": None}}, **extra)
+                              "kernel_ms_per_fold": kern_ms, "launches": cnt // max(steps, 1),
+                              "traffic": _traffic(f"ptf_{V}_views")[0], "traffic_source": _traffic(f"ptf_{V}_views")[1]}}, **extra)
 
 
 def bench_depth_tail(dev, steps, warmup, V=2, D=128, h2=192, w2=256):

@@ -62,7 +62,7 @@ __device__ __forceinline__ float fs_exp(float x)
 // ---- phase timestamps inside kernels (debug builds: make EXTRA=-DFS_PHASE_TRACE; profiles/phase_trace.py) ----
 // FS_PT(kernel, k): thread 0 of the first 4096 workgroups stamps wall_clock64() (100 MHz) into slot k (< 8).
 #ifdef FS_PHASE_TRACE
-constexpr int kPtKernels = 4, kPtBlocks = 4096, kPtSlots = 8;
+constexpr int kPtKernels = 4, kPtBlocks = 4096, kPtSlots = 10;
 static __device__ unsigned long long g_phase_trace[kPtKernels * kPtBlocks * kPtSlots];  // one per translation unit
 #define FS_PT(kern, k)                                                                                  \
     do {                                                                                                \
@@ -330,6 +330,7 @@ __host__ __device__ inline uint32_t tile_capacity(long long cap, int T)
     const unsigned long long want = (4ull * (unsigned long long)(cap > 0 ? cap : 1) + (unsigned long long)T - 1ull) / (unsigned long long)(T > 0 ? T : 1);
     unsigned long long c = 2048;
     while (c < want && c < (1ull << 26)) c <<= 1;
+    while (c > 1 && c * (unsigned long long)(T > 0 ? T : 1) > 0xFFFFFFFFull) c >>= 1;   // key slots are indexed in 32 bits
     return (uint32_t)c;
 }
 

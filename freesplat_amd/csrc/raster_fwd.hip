@@ -426,11 +426,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                     const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
                     if (!cull || m) {
                         const uint32_t slot = atomicAdd(&s_cnt[(y - bb.y0) * bb.w + (x - bb.x0)], 1u);
-                        if (slot < tile_cap) keys[(size_t)(y * gx + x) * tile_cap + slot] = key_hi | m;
+                        // (tile * tile_cap + slot < 2^32: tile_capacity() bounds the product)
+                        if (slot < tile_cap) keys[(uint32_t)(y * gx + x) * tile_cap + slot] = key_hi | m;
                     }
                 }
             }
         }
+        FS_PT(0, 8);  // keys written
     } else if (valid) {
         int k = 0;
         for (int y = rect.y; y < rect.w; ++y) {
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
                 if (!cull || m) {
                     const uint32_t slot = atomicAdd(&tile_counts[y * gx + x], 1u);
-                    if (slot < tile_cap) keys[(size_t)(y * gx + x) * tile_cap + slot] = key_hi | m;
+                    if (slot < tile_cap) keys[(uint32_t)(y * gx + x) * tile_cap + slot] = key_hi | m;
                 }
             }
         }
@@ -668,7 +670,6 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
     constexpr int E = 2 * EA, NA = 256 * EA, NB = 256 * EB;
     const int t = threadIdx.x;
     unsigned long long ka[EA], kb[EB];
-    FS_PT(2, 0);
 #pragma unroll
     for (int e = 0; e < EA; ++e) ka[e] = keys[t * EA + e];  // n > NA
 #pragma unroll
@@ -676,11 +677,8 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
         const uint32_t i = (uint32_t)(NA + t * EB + e);
         kb[e] = i < n ? keys[i] : ~0ull;
     }
-    FS_PT(2, 1);  // (loads issued)
     Stages<EA, NA>::run(ka, t, lds);
-    FS_PT(2, 2);  // first run sorted
     Stages<EB, NB>::run(kb, t, lds);
-    FS_PT(2, 3);  // second run sorted
     unsigned long long k[E];
 #pragma unroll
     for (int c0 = 0; c0 < NA + NB; c0 += kSortLds) {  // through the exchange buffer, kSortLds keys at a time
@@ -705,16 +703,13 @@ __device__ __forceinline__ void sort_tile_two_runs(const unsigned long long* __r
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if (t * E + e >= NA + NB) k[e] = ~0ull;
-    FS_PT(2, 4);  // re-laid out
     thread_exchange<E, 255, true>(k, t, lds);  // flip step of the last stage: i <-> i ^ (512*EA - 1)
     Clean<E, 256 * E / 4>::run(k, t, lds);
-    FS_PT(2, 5);  // merged
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)t * E + e;
         if (i < n) out[i] = (uint32_t)k[e];
     }
-    FS_PT(2, 6);  // stored
 }
 
 
@@ -1036,6 +1031,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     const int tile = tile_for_block(blockIdx.x, gx, gy);  // XCD-aware, balanced (fs_common.h)
     if (tile < 0) return;
+    FS_PT(2, 0);
     const uint32_t n = counts[tile];
     unsigned long long* const kt = keys + (size_t)tile * tile_cap;
     uint32_t* const gl = point_list + offsets[tile];   // this tile's range of the saved (compact) list
@@ -1062,7 +1058,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         for (uint32_t k = threadIdx.x; k < n; k += 256) gl[k] = (uint32_t)kt[k];
     }
     if (!in_lds) __threadfence_block();
+    FS_PT(2, 1);  // this wavefront's part of the sort done
     __syncthreads();  // list complete (LDS or global); the key staging is free for the compaction areas
+    FS_PT(2, 2);  // list complete
     const int wave = threadIdx.x >> 6;
     float4* const cp = (float4*)sk + wave * kPairArea;
     const int tx = tile % gx, ty = tile / gx;
@@ -1072,6 +1070,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     else
         blend_quadrant<FAST_EXP, TRACK, false>(gl, (int)n, rec, cp, H, W, tx, ty, wave, bg, out_color, out_depth, out_alpha,
                                                final_T, n_contrib);
+    FS_PT(2, 3);  // quadrant 0 blended
 }
 
 }  // namespace fs

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Where the time of a workgroup goes inside preprocess / emit / tile_sort (debug build only):
-    make -C freesplat_amd/csrc clean && make -C freesplat_amd/csrc EXTRA=-DFS_PHASE_TRACE
-    python profiles/phase_trace.py
+"""Where the time of a workgroup goes inside preprocess (projection + binning) / sort_blend (debug build only):
+    make -C freesplat_amd/csrc VARIANT=trace EXTRA=-DFS_PHASE_TRACE
+    FREESPLAT_LIB=$PWD/freesplat_amd/libfreesplat_hip_trace.so python profiles/phase_trace.py
 FS_PT(kernel, k) stamps wall_clock64() (100 MHz) at phase boundaries for thread 0 of the first 4096 workgroups;
 this renders one C3 view and prints the mean / median duration of every phase."""
 import ctypes as C
@@ -17,10 +17,10 @@ from freesplat_amd import _lib, synthetic  # noqa: E402
 from freesplat_amd.decoder import render_views  # noqa: E402
 
 PHASES = {
-    0: ("preprocess", ["stage inputs + sync", "project / conic / SH", "write records + sync", "quadrant masks",
-                       "workgroup box", "zero + count (LDS atomics)", "flush (global atomics)"]),
-    1: ("emit", ["load + workgroup box", "zero", "count (LDS atomics)", "reserve slots (global atomics)", "rank + write keys"]),
-    2: ("tile_sort (two-run path)", ["issue loads", "sort first run", "sort second run", "re-layout via LDS", "merge", "store"]),
+    0: ("preprocess (projection + binning)", ["stage inputs + sync", "project / conic / SH", "write records + sync", "quadrant masks",
+                       "workgroup box", "zero + count (LDS atomics)", "reserve slots (returning global atomics)",
+                       "rank + write keys"]),
+    2: ("sort_blend (wavefront 0)", ["load keys + LDS bucket sort", "wait for the other wavefronts", "blend quadrant 0"]),
 }
 
 
@@ -32,14 +32,14 @@ def main():
     g = {k: scene[k].to(dev) for k in ("means", "covariances", "harmonics", "opacities")}
     L = _lib.lib()
     L.fs_debug_phase_trace.restype = C.c_int
-    buf = np.zeros(4 * 4096 * 8, np.uint64)
+    buf = np.zeros(4 * 4096 * 10, np.uint64)
     with torch.no_grad():
         for it in range(4):
             render_views(cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"], (H, W), torch.zeros(1, 3, device=dev),
                          g["means"], g["covariances"], g["harmonics"], g["opacities"])
             torch.cuda.synchronize()
             L.fs_debug_phase_trace(buf.ctypes.data_as(C.c_void_p))     # (copies out and clears)
-    t = buf.reshape(4, 4096, 8).astype(np.float64) / 100.0
+    t = buf.reshape(4, 4096, 10).astype(np.float64) / 100.0
     for kern, (name, phases) in PHASES.items():
         n = len(phases) + 1
         x = t[kern][:, :n]
