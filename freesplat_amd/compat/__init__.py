@@ -3,6 +3,10 @@
     import freesplat_amd.compat as compat
     compat.install()            # before `import src.main`: provides `diff_gaussian_rasterization_depth`
     compat.patch_reference()    # after `src` is importable: swaps the hot-path classes for the HIP ones
+
+or, as ONE command from the root of the FreeSplat checkout (freesplat_amd on PYTHONPATH):
+
+    python -m freesplat_amd.compat.run src.main +experiment=scannet/2views ...     (freesplat_amd/compat/run.py)
 """
 import importlib
 import sys
@@ -22,10 +26,14 @@ def patch_reference(decoder: bool = True) -> dict:
       src.model.encoder.modules.cost_volume.AVGFeatureVolumeManager   (cost_volume.py:384)
       src.model.encoder.encoder_freesplat.{AVGFeatureVolumeManager, GaussianAdapter, GRU}
       src.model.encoder.encoder_freesplat.EncoderFreeSplat.fuse_gaussians       (:431)
+      src.model.encoder.encoder_freesplat.EncoderFreeSplat.forward              (:190-429; encoder_forward.py: the
+                                                                                 reference's sub-modules in the reference's
+                                                                                 order, the repeat + gather glue of :216-288
+                                                                                 replaced by direct indexing)
       src.model.encoder.modules.networks.DepthDecoder.forward                   (networks.py:108-154)
       src.model.decoder.DECODERS["splatting_cuda"]                              (decoder/__init__.py:5-13)
     Returns {dotted name: replacement} for logging."""
-    from .. import cost_volume, depth_tail, gaussian_adapter, ptf
+    from .. import cost_volume, depth_tail, encoder_forward, gaussian_adapter, ptf
     from ..decoder import DecoderSplattingCUDA
     done = {}
     cvm = importlib.import_module("src.model.encoder.modules.cost_volume")
@@ -36,6 +44,8 @@ def patch_reference(decoder: bool = True) -> dict:
     enc.GaussianAdapter = gaussian_adapter.GaussianAdapter
     enc.GRU = ptf.GRU
     enc.EncoderFreeSplat.fuse_gaussians = ptf.fuse_gaussians
+    enc.EncoderFreeSplat.forward = encoder_forward.encoder_forward
+    done["src.model.encoder.encoder_freesplat.EncoderFreeSplat.forward"] = encoder_forward.encoder_forward
     for n in ("AVGFeatureVolumeManager", "GaussianAdapter", "GRU"):
         done[f"src.model.encoder.encoder_freesplat.{n}"] = getattr(enc, n)
     done["src.model.encoder.encoder_freesplat.EncoderFreeSplat.fuse_gaussians"] = ptf.fuse_gaussians
