@@ -137,13 +137,47 @@ __global__ void cv_proj_kernel(int n, const float* __restrict__ src_Ks, const fl
     P[e] = Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] + Ks[4 * i + 3] * Tx[12 + j];
 }
 
+// Workgroup -> (batch row, 32-pixel group, plane slice), XCD-aware.  Workgroup i runs on XCD i % 8 (hardware round
+// robin), and every XCD has its own 4 MB L2: with the plain (row * groups + group, slice) grid, neighbouring pixel groups
+// -- which sample the SAME rows of the source maps -- landed on eight different XCDs, every L2 had to hold all K source
+// maps of a view (10 views, K = 8: 19 MB) and the sweep re-fetched them from memory over and over: 16.7 GB of fetches per
+// call against 0.27 GB of algorithmic bytes (profiles/r3_traffic.json, cv_fvt10_K8).  Here XCD x owns the x-th horizontal
+// BAND of pixel groups of every view and walks it in row-major order, plane slice by plane slice: the workgroups in
+// flight on an XCD share a few source rows per map.
+struct CvBlock { int b, grp, slice; bool ok; };
+__device__ __forceinline__ CvBlock cv_block(int B, int groups, int slices)
+{
+#ifdef FS_CV_LINEAR_GRID   // (A/B builds: round 2's order -- group fastest, then batch row, then slice)
+    {
+        CvBlock o;
+        const int id = (int)blockIdx.x, per = B * groups;
+        o.slice = id / per;
+        o.b = (id - o.slice * per) / groups;
+        o.grp = id - o.slice * per - o.b * groups;
+        o.ok = o.slice < slices;
+        return o;
+    }
+#endif
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+    const int gb = (groups + 7) >> 3;          // pixel groups per band
+    const int per_b = slices * gb;
+    CvBlock o;
+    o.b = j / per_b;
+    const int r = j - o.b * per_b;
+    o.slice = r / gb;
+    o.grp = xcd * gb + (r - o.slice * gb);
+    o.ok = o.b < B && o.grp < groups;
+    return o;
+}
+static inline unsigned cv_grid(int B, int groups, int slices) { return 8u * (unsigned)B * (unsigned)slices * (unsigned)((groups + 7) >> 3); }
+
 // LeakyReLU(0.01) = 0.505 x + 0.495 |x|: two VALU operations (|x| is a free source modifier).  fmaxf(x, 0.01 x) costs four
 // here (the multiply, the max and two NaN-canonicalising v_max that IEEE mode puts in front of it).
 __device__ __forceinline__ float lrelu(float x) { return fmaf(0.495f, fabsf(x), 0.505f * x); }
 
 template <int HC>  // HC = C/2 channels per lane
 __global__ __launch_bounds__(256) void cost_volume_kernel(
-    int B, int K, int h, int w, int D, const float* __restrict__ curT, const float* __restrict__ srcT,
+    int B, int K, int h, int w, int D, int slices, const float* __restrict__ curT, const float* __restrict__ srcT,
     const float* __restrict__ Pmat,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -153,7 +187,9 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
     constexpr int C = 2 * HC;
     const int hw = h * w;
     const int groups = (hw + 31) / 32;
-    const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const CvBlock blk_ = cv_block(B, groups, slices);
+    if (!blk_.ok) return;   // (workgroup-uniform)
+    const int b = blk_.b, grp = blk_.grp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, hf = lane >> 5;
     const int pix = grp * 32 + p;
@@ -192,9 +228,9 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
     const float rz = iK[8] * ux + iK[9] * vy + iK[10];
 
     const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
-    // planes [d0, d1) of this wavefront: gridDim.y * 4 wavefronts share the D planes of a pixel group
-    const int dchunk = (D + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4);
-    const int d0 = min(D, ((int)blockIdx.y * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
+    // planes [d0, d1) of this wavefront: slices * 4 wavefronts share the D planes of a pixel group
+    const int dchunk = (D + slices * 4 - 1) / (slices * 4);
+    const int d0 = min(D, (blk_.slice * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
 
     // Per plane the sweep used to pay three dependent memory round trips before its first MFMA: the plane's depth,
     // the projection rows (scalar loads), then the taps.  The depth is now fetched one plane ahead and the projection
@@ -313,7 +349,7 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
     }
 #ifdef FS_CV_TRACE
     {
-        const int wid = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+        const int wid = (int)blockIdx.x * 4 + wave;
         if (lane == 0 && wid < kCvTraceWaves) {
             g_cv_trace[4 * wid] = tr_g; g_cv_trace[4 * wid + 1] = tr_m;
             // [3]: shader ticks (s_memtime) << 32 | 100 MHz wall ticks of this wavefront's whole sweep -> effective clock
@@ -331,7 +367,7 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
 // (config-3 scale, K = 2: on par; 10 views, K = 8: 18 % slower than the sweep above).
 template <int HC>  // HC = C/2 channels per lane
 __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
-    int B, int K, int h, int w, int D, const float* __restrict__ cur_feats, const float* __restrict__ srcT,
+    int B, int K, int h, int w, int D, int slices, const float* __restrict__ cur_feats, const float* __restrict__ srcT,
     const float* __restrict__ src_Ks, const float* __restrict__ src_extrinsics,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -341,7 +377,9 @@ __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
     constexpr int C = 2 * HC;
     const int hw = h * w;
     const int groups = (hw + 31) / 32;
-    const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const CvBlock blk_ = cv_block(B, groups, slices);
+    if (!blk_.ok) return;   // (workgroup-uniform)
+    const int b = blk_.b, grp = blk_.grp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, hf = lane >> 5;
     const int pix = grp * 32 + p;
@@ -377,9 +415,9 @@ __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
     const float rz = iK[8] * ux + iK[9] * vy + iK[10];
 
     const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
-    // planes [d0, d1) of this wavefront: gridDim.y * 4 wavefronts share the D planes of a pixel group
-    const int dchunk = (D + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4);
-    const int d0 = min(D, ((int)blockIdx.y * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
+    // planes [d0, d1) of this wavefront: slices * 4 wavefronts share the D planes of a pixel group
+    const int dchunk = (D + slices * 4 - 1) / (slices * 4);
+    const int d0 = min(D, (blk_.slice * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
 
     // Per plane the sweep used to pay three dependent memory round trips before its first MFMA: the plane's depth,
     // the projection rows (scalar loads), then the taps.  The depth is now fetched one plane ahead and the projection
@@ -513,7 +551,7 @@ __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
     }
 #ifdef FS_CV_TRACE
     {
-        const int wid = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+        const int wid = (int)blockIdx.x * 4 + wave;
         if (lane == 0 && wid < kCvTraceWaves) {
             g_cv_trace[4 * wid] = tr_g; g_cv_trace[4 * wid + 1] = tr_m;
             // [3]: shader ticks (s_memtime) << 32 | 100 MHz wall ticks of this wavefront's whole sweep -> effective clock
@@ -617,7 +655,7 @@ __device__ __forceinline__ constexpr int row_half(int i) { return (i >> 2) & 1; 
 
 template <int HC>
 __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
-    int B, int K, int h, int w, int D, const float* __restrict__ curT, const float* __restrict__ srcT,
+    int B, int K, int h, int w, int D, int slices, const float* __restrict__ curT, const float* __restrict__ srcT,
     const float* __restrict__ Pmat,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -635,7 +673,9 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     __shared__ float s_stage[4 * kStage];
     const int hw = h * w;
     const int groups = (hw + 31) / 32;
-    const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const CvBlock blk_ = cv_block(B, groups, slices);
+    if (!blk_.ok) return;   // (workgroup-uniform)
+    const int b = blk_.b, grp = blk_.grp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, hf = lane >> 5;
     const int pix = grp * 32 + p;
@@ -683,8 +723,8 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     const float ry = iK[4] * ux + iK[5] * vy + iK[6];
     const float rz = iK[8] * ux + iK[9] * vy + iK[10];
     const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
-    const int dchunk = (D + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4);
-    const int d0 = min(D, ((int)blockIdx.y * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
+    const int dchunk = (D + slices * 4 - 1) / (slices * 4);
+    const int d0 = min(D, (blk_.slice * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
     float gw3r[16], gb2r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { gw3r[r] = 0.0f; gb2r[r] = 0.0f; }
@@ -880,7 +920,7 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     }
 #ifdef FS_CV_TRACE
     {
-        const int wid = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+        const int wid = (int)blockIdx.x * 4 + wave;
         if (lane == 0 && wid < kCvTraceWaves) {
             unsigned long long* o = g_cvb_trace + 6 * (size_t)wid;
             o[0] = tb0; o[1] = tb1; o[2] = tb2; o[3] = tb3; o[4] = (unsigned long long)(d1 - d0); o[5] = cv_stamp(rx) - tb_start;
@@ -1023,19 +1063,20 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
         ScopedStage prof_(kStCostVolume, st);
         const long long tot1 = (long long)B * hw * C, tot2 = tot1 * K;
         const int groups = (hw + 31) / 32;
-        const dim3 grid(B * groups, cv_plane_split(B, groups, D));
+        const int slices = cv_plane_split(B, groups, D);
+        const dim3 grid(cv_grid(B, groups, slices));
         if (cv_use_projected(K)) {
             // K = 1: first layer's feature block applied per source texel, 16 MFMAs per (group, plane); two launches
             // (the sweep reads the current view from the caller's map and forms its projection rows itself)
             const unsigned gproj = (unsigned)std::min<long long>(((long long)B * K * hw * 8 + 255) / 256, 65536);
             if (C == 48) {
                 hipLaunchKernelGGL(cv_relayout_project_kernel<48>, dim3(gproj), dim3(256), 0, st, src_feats, srcT, w1, h, w, B * K);
-                hipLaunchKernelGGL(cost_volume_proj_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, cur_feats, srcT, src_Ks,
+                hipLaunchKernelGGL(cost_volume_proj_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, slices, cur_feats, srcT, src_Ks,
                                    src_extrinsics, cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
                                    (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out);
             } else {
                 hipLaunchKernelGGL(cv_relayout_project_kernel<16>, dim3(gproj), dim3(256), 0, st, src_feats, srcT, w1, h, w, B * K);
-                hipLaunchKernelGGL(cost_volume_proj_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, cur_feats, srcT, src_Ks,
+                hipLaunchKernelGGL(cost_volume_proj_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, slices, cur_feats, srcT, src_Ks,
                                    src_extrinsics, cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
                                    (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out);
             }
@@ -1047,11 +1088,11 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
             hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
                                dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
             if (C == 48)
-                hipLaunchKernelGGL(cost_volume_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
+                hipLaunchKernelGGL(cost_volume_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, slices, curT, srcT, Pmat, cur_invK,
                                    planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
                                    w1, b1, w2, b2, w3, b3, out);
             else
-                hipLaunchKernelGGL(cost_volume_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, curT, srcT, Pmat, cur_invK,
+                hipLaunchKernelGGL(cost_volume_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, slices, curT, srcT, Pmat, cur_invK,
                                    planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
                                    w1, b1, w2, b2, w3, b3, out);
         }
@@ -1109,13 +1150,14 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
     hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_cur), dim3(256), 0, st, cur_feats, curT, C, hw, B);
     hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_src), dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
     const int groups = (hw + 31) / 32;
+    const int bslices = cv_bwd_plane_split(B, groups, D);
     if (C == 48)
-        hipLaunchKernelGGL(cost_volume_bwd_kernel<24>, dim3(B * groups, cv_bwd_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
+        hipLaunchKernelGGL(cost_volume_bwd_kernel<24>, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
                            d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3);
     else
-        hipLaunchKernelGGL(cost_volume_bwd_kernel<8>, dim3(B * groups, cv_bwd_plane_split(B, groups, D)), dim3(256), 0, st, B, K, h, w, D, curT, srcT,
+        hipLaunchKernelGGL(cost_volume_bwd_kernel<8>, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
                            d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3);

@@ -80,5 +80,6 @@ def backward(V=2, K=1, h4=96, w4=128, D=128):
 if __name__ == "__main__":
     main()
     main(V=3, K=2, h4=242, w4=324)
+    main(V=10, K=8)
     backward()
     backward(V=3, K=2, h4=242, w4=324, D=64)

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-size parity cases whose CPU oracle needs minutes (still part of `-m gpu`)")
     config.addinivalue_line("markers", "fast_exp: run the rasterizer with the opt-in hardware exp (FS_RASTER_FAST_EXP); "
                                        "every other test uses the default, bit-exact contract exp")
 

@@ -54,6 +54,61 @@ def test_config4_5_long_sequence_fold(hip_device, V, h, w):
         assert (a.cpu() - b.detach()).abs().max().item() <= 1e-4, name
 
 
+@pytest.mark.slow
+def test_config4_cost_volume_at_its_real_size(hip_device):
+    """BASELINE config 4 at the size bench.py times it (`fvt10_96x128_K8`: 10 context views at the native 96x128
+    matching resolution, D = 128 planes, the 9 pose-nearest views as sources -> K = 8): the whole HIP call, ONE of its
+    current views checked against the reference-pinned oracle (a 256-thread host needs ~10 s per view)."""
+    import inputs
+    from oracle import cost_volume_oracle as cvo
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    V, K, h4, w4, D, C = 10, 8, 96, 128, 128, 48
+    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=1)             # (bench_encoder.bench_cost_volume's inputs)
+    torch.manual_seed(0)
+    m = AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    sd = {k.replace(".", "__"): v for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out = m.to(hip_device)(**{k: v.to(hip_device) for k, v in kw.items()}).cpu()
+    assert out.shape == (V, D, h4, w4)
+    torch.set_num_threads(os.cpu_count() or 1)
+    for v in (3,):
+        one = slice(v, v + 1)
+        ref = cvo.cost_volume(kw["cur_feats"][one], kw["src_feats"][one], kw["src_extrinsics"][one], kw["src_Ks"][one],
+                              kw["cur_invK"][one], kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
+        err = (out[one] - ref).abs()
+        # cells above 1e-4 are validity flips of bilinear taps on the image border (tests/test_cost_volume_hip.py)
+        assert int((err > 1e-4).sum()) <= max(2, err.numel() // 100000) and float(err.median()) < 1e-5, (
+            int((err > 1e-4).sum()), float(err.max()), float(err.median()))
+
+
+@pytest.mark.slow
+def test_config4_fold_at_its_real_size(hip_device):
+    """BASELINE config 4's fold at the size bench.py times it (`fold_10_views`: 10 views at 384x512 = 1.97 M raw
+    Gaussians): same count, same ORDER (the appended / kept / fused layout of every step) and values within 1e-4 of the
+    reference-pinned oracle.  Minutes of host time: the oracle folds step by step in numpy / torch CPU."""
+    from oracle import ptf_oracle as po
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    from test_ptf_hip import _scene
+    V, h, w = 10, 384, 512
+    E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=5)          # (bench_encoder.bench_ptf's scene)
+    torch.manual_seed(1)
+    m = PixelwiseTripletFusion()
+    params = {k: v.detach().clone() for k, v in m.gru.state_dict().items()}
+    mg = PixelwiseTripletFusion()
+    mg.load_state_dict(m.state_dict())
+    mg = mg.to(hip_device)
+    d = lambda t: t.to(hip_device)
+    with torch.no_grad():
+        out = [x.cpu() for x in mg.fuse_gaussians([d(lat)], [d(coords)], d(dens), d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))]
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w))
+    assert out[0].shape == ref[0].shape and out[0].shape[1] < V * h * w        # same count; something fused
+    for a, b, name in zip(out, ref, ("latent", "xyz", "extrinsics", "depths")):
+        assert a.shape == b.shape, name
+        assert (a - b).abs().max().item() <= 1e-4, name          # row i of ours is row i of the reference: same order
+
+
 def test_config5_fp16_sh_storage(hip_device):
     """fp16 SH = storage only (BASELINE config 5): against the ORACLE fed the fp16-rounded coefficients the image is
     bit-exact and the gradients are within the backward's bar; and the fp32 HIP path on those coefficients gives
