@@ -164,6 +164,8 @@ __device__ __forceinline__ CvBlock cv_block(int B, int groups, int slices)
     CvBlock o;
     o.b = j / per_b;
     const int r = j - o.b * per_b;
+    // (plane slice fastest instead -- the slices of one pixel group side by side, ~0.6 MB of source rows in flight per XCD
+    //  instead of ~3.3 MB at K = 8 -- measured the same: the sweep is not bound by L2 misses)
     o.slice = r / gb;
     o.grp = xcd * gb + (r - o.slice * gb);
     o.ok = o.b < B && o.grp < groups;
