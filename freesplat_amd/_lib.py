@@ -25,6 +25,8 @@ class RasterDims(C.Structure):
                 ("flags", C.c_int32)]
 
 
+ABI_VERSION = 3          # include/freesplat_amd.h FS_ABI_VERSION
+
 RASTER_TILE_CULL = 1
 RASTER_SH_FP16 = 2
 RASTER_SH_CHANNEL_MAJOR = 4
@@ -48,6 +50,7 @@ _VP = C.c_void_p
 # name -> (restype, argtypes); must list every symbol include/freesplat_amd.h declares
 SIGNATURES = {
     "fs_version": (C.c_char_p, []),
+    "fs_abi_version": (C.c_int, []),
     "fs_last_error": (C.c_char_p, []),
     "fs_profile_enable": (C.c_int, [C.c_int]),
     "fs_profile_collect": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
@@ -107,6 +110,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if L.fs_abi_version() != ABI_VERSION:
+            raise FreeSplatHipError(f"{LIB_PATH} has ABI revision {L.fs_abi_version()}, this binding expects {ABI_VERSION} "
+                                    "(include/freesplat_amd.h FS_ABI_VERSION): rebuild the library")
         _lib = L
     return _lib
 

@@ -73,16 +73,32 @@ static __device__ unsigned long long g_phase_trace[kPtKernels * kPtBlocks * kPtS
 #define FS_PT(kern, k) do {} while (0)
 #endif
 
-// positional encoding of two scalars, 6 octaves each, (sin, cos) interleaved (encoder_freesplat.py:62-77): 24 floats
+// positional encoding of two scalars, 6 octaves each, (sin, cos) interleaved (encoder_freesplat.py:62-77): 24 floats.
+// Hardware v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS and are accurate to ~1e-6 on the fraction; the
+// libm forms cost ~40 VALU each, 48 of them per fused pair.  The arguments are accumulated densities and weights times
+// 2^k, k <= 5 -- they grow with every fused view and reach the hundreds in a long fold --, so the revolutions are formed
+// in two pieces: rev = fl(x / 2 pi) and its exact residual (one fma with the hi part of 1 / 2 pi, one with the lo part);
+// 2^k rev is exact, its integer part is removed exactly, and the residual is added to the small remaining fraction.
+// The phase then carries ~1e-8 revolutions of error whatever |x| is (a plain fp32 x / 2 pi: up to 3.6e-5 revolutions =
+// 2e-4 rad at x = 1234, k = 5 -- the bound the round-2 comment got wrong).
+__device__ __forceinline__ void rev2pi(float x, float& rev, float& res)
+{
+    constexpr float kInv2PiHi = 0.15915494f, kInv2PiLo = 6.4206382e-9f;    // 1 / (2 pi) = hi + lo
+    rev = x * kInv2PiHi;
+    res = fmaf(x, kInv2PiLo, fmaf(x, kInv2PiHi, -rev));
+}
 __device__ __forceinline__ void pos_enc2(float a, float b, float* __restrict__ out)  // 24 floats
 {
+    float ra, ea, rb, eb;
+    rev2pi(a, ra, ea);
+    rev2pi(b, rb, eb);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const float f = (float)(1 << k);
-        // hardware v_sin_f32 / v_cos_f32 (arguments are densities and weights times <= 32: |error| ~1e-6, far inside the
-        // fold's 1e-4 bar; the libm forms cost ~40 VALU each, 48 of them per fused pair)
-        out[2 * k] = __sinf(a * f); out[2 * k + 1] = __cosf(a * f);
-        out[12 + 2 * k] = __sinf(b * f); out[12 + 2 * k + 1] = __cosf(b * f);
+        const float ta = ra * f, tb = rb * f;                       // (exact)
+        const float pa = (ta - rintf(ta)) + ea * f, pb = (tb - rintf(tb)) + eb * f;
+        out[2 * k] = __builtin_amdgcn_sinf(pa); out[2 * k + 1] = __builtin_amdgcn_cosf(pa);
+        out[12 + 2 * k] = __builtin_amdgcn_sinf(pb); out[12 + 2 * k + 1] = __builtin_amdgcn_cosf(pb);
     }
 }
 

@@ -40,6 +40,12 @@ extern "C" {
 
 /* Library / build identification: "freesplat_amd <ver> gfx950". */
 const char* fs_version(void);
+/* Integer ABI revision: bumped whenever a signature, a flag or the layout of an opaque buffer changes.  A binding checks
+ * it right after loading the library (freesplat_amd/_lib.py does): a stale build would otherwise accept calls with
+ * shifted pointers.  3 = round 3 (single-pass binning: scratch = per-tile key areas, counters[1] = largest tile list on
+ * overflow, geom without the mask / depth arrays; fused sort + blend). */
+#define FS_ABI_VERSION 3
+int fs_abi_version(void);
 /* Last HIP error string observed by a failing call on this thread (never NULL). */
 const char* fs_last_error(void);
 
