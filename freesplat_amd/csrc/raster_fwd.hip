@@ -861,7 +861,7 @@ __device__ __forceinline__ void sort_tile_buckets(const unsigned long long* __re
 // FS_RASTER_NO_BACKWARD_STATE (inference: 4 fewer selects per 4 survivors)
 // ------------------------------------------------------------------------------------------
 constexpr int kPairQuads = 6;  // float4 per slot of two survivors
-constexpr int kPairArea = 33 * kPairQuads;  // float4 per wavefront (+1 slot: the read of a step's second slot may run one past)
+constexpr int kPairArea = 34 * kPairQuads;  // float4 per wavefront: up to 3 carried + 64 new survivors = 67 entries, two per slot
 template <bool FAST_EXP, bool TRACK, bool LDS_LIST>
 __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const float4* __restrict__ rec, float4* const cp,
                                                int H, int W, int tx, int ty, int wave, const float* __restrict__ bg,
@@ -884,6 +884,71 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
     // v_cmp + s_xor per survivor, v_cndmask + v_or to update it: ~4 of ~30 VALU per survivor in round 2's loop).
     unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);
 
+    // VM: mask of the pixels this survivor can reach (power in range, alpha >= 1/255, pixel not yet saturated)
+#define FS_BLEND_ONE(VM, AL, OM, KR, POS)                                                           \
+    {                                                                                               \
+        const float test_T = T_ * (OM);                                                             \
+        const unsigned long long vis = (VM) & ~done_m;                                              \
+        const unsigned long long okc = __builtin_amdgcn_ballot_w64(test_T >= 0.0001f);              \
+        done_m |= vis & ~okc;                     /* T would fall below 1e-4: the pixel is done, this one not applied */ \
+        const bool ok = __builtin_amdgcn_inverse_ballot_w64(vis & okc);                             \
+        const f32x2 wgt = splat2(ok ? (AL) * T_ : 0.0f); /* weight 0: sums unchanged (finite colours) */ \
+        C01 = fma2((f32x2){(KR).x, (KR).y}, wgt, C01);                                              \
+        C2D = fma2((f32x2){(KR).z, (KR).w}, wgt, C2D);                                              \
+        T_ = ok ? test_T : T_;                                                                      \
+        if constexpr (TRACK) last = ok ? __float_as_int(POS) : last;                                \
+    }
+    // One step = two slots = four survivors a, b | c, d, blended strictly in list order.  PARTIAL: the quadrant's very
+    // last step, `left` (1..3) entries; full steps carry no "does this entry exist" logic.
+    auto step = [&](const float4* q, auto partial, int left) __attribute__((always_inline)) {
+        constexpr bool PARTIAL = decltype(partial)::value;
+        const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+        const float4 e0 = q[6], e1 = q[7], e2 = q[8], e3 = q[9];
+        const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
+        const f32x2 ex = (f32x2){e0.x, e0.y} - pfx, ey = (f32x2){e0.z, e0.w} - pfy;
+        // -power = A dx^2 + dy (C dy + B dx): 3 multiplications + 2 fmas (the oracle's own association)
+        const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx, dy * fma2((f32x2){c1.z, c1.w}, dy, (f32x2){c2.x, c2.y} * dx));
+        const f32x2 pv = fma2((f32x2){e1.x, e1.y} * ex, ex, ey * fma2((f32x2){e1.z, e1.w}, ey, (f32x2){e2.x, e2.y} * ex));
+        // +0 <= q <= -threshold  <=>  bits(q) <= bits(-threshold) as unsigned (negative q and NaN compare above)
+        unsigned long long ma = __builtin_amdgcn_ballot_w64(__float_as_uint(pw.x) <= __float_as_uint(c2.z));
+        unsigned long long mb = __builtin_amdgcn_ballot_w64(__float_as_uint(pw.y) <= __float_as_uint(c2.w));
+        unsigned long long mc = __builtin_amdgcn_ballot_w64(__float_as_uint(pv.x) <= __float_as_uint(e2.z));
+        unsigned long long md = __builtin_amdgcn_ballot_w64(__float_as_uint(pv.y) <= __float_as_uint(e2.w));
+        if constexpr (PARTIAL) { mb = left > 1 ? mb : 0ull; mc = left > 2 ? mc : 0ull; md = 0ull; }
+        if ((((ma | mb) | (mc | md)) & ~done_m) == 0ull) return;  // wave-uniform: nobody in range
+        const float4 ka = q[4], kb = q[5], kc = q[10], kd = q[11];
+        f32x2 ew = blend_exp_of_neg<FAST_EXP>(pw), ev = blend_exp_of_neg<FAST_EXP>(pv);
+        f32x2 ow = (f32x2){c3.x, c3.y} * ew, ov = (f32x2){e3.x, e3.y} * ev;
+        f32x2 aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
+        f32x2 av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
+        unsigned long long ga, gb, gc, gd;   // alpha >= 1/255
+        if constexpr (FAST_EXP) {
+            // hardware exp; a step with an alpha inside the guard band of the 1/255 threshold (fs_common.h) is
+            // re-evaluated with the contract exp, so the accept / reject decisions are those of the exact mode
+            const float glo = alpha_guard_lo(), ghi = alpha_guard_hi();
+            ga = __builtin_amdgcn_ballot_w64(aw.x >= ghi); gb = __builtin_amdgcn_ballot_w64(aw.y >= ghi);
+            gc = __builtin_amdgcn_ballot_w64(av.x >= ghi); gd = __builtin_amdgcn_ballot_w64(av.y >= ghi);   // nothing in [glo, ghi): same as >= 1/255
+            const unsigned long long nb = (__builtin_amdgcn_ballot_w64(aw.x >= glo) & ~ga) | (__builtin_amdgcn_ballot_w64(aw.y >= glo) & ~gb)
+                                        | (__builtin_amdgcn_ballot_w64(av.x >= glo) & ~gc) | (__builtin_amdgcn_ballot_w64(av.y >= glo) & ~gd);
+            if (__builtin_expect(nb != 0ull, 0)) {  // wave-uniform, rare
+                ew = blend_exp_of_neg<false>(pw); ev = blend_exp_of_neg<false>(pv);
+                ow = (f32x2){c3.x, c3.y} * ew; ov = (f32x2){e3.x, e3.y} * ev;
+                aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
+                av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
+                ga = __builtin_amdgcn_ballot_w64(aw.x >= 1.0f / 255.0f); gb = __builtin_amdgcn_ballot_w64(aw.y >= 1.0f / 255.0f);
+                gc = __builtin_amdgcn_ballot_w64(av.x >= 1.0f / 255.0f); gd = __builtin_amdgcn_ballot_w64(av.y >= 1.0f / 255.0f);
+            }
+        } else {
+            ga = __builtin_amdgcn_ballot_w64(aw.x >= 1.0f / 255.0f); gb = __builtin_amdgcn_ballot_w64(aw.y >= 1.0f / 255.0f);
+            gc = __builtin_amdgcn_ballot_w64(av.x >= 1.0f / 255.0f); gd = __builtin_amdgcn_ballot_w64(av.y >= 1.0f / 255.0f);
+        }
+        const f32x2 mw = splat2(1.0f) - aw, mv = splat2(1.0f) - av;
+        FS_BLEND_ONE(ma & ga, aw.x, mw.x, ka, c3.z)
+        FS_BLEND_ONE(mb & gb, aw.y, mw.y, kb, c3.w)
+        FS_BLEND_ONE(mc & gc, av.x, mv.x, kc, e3.z)
+        if constexpr (!PARTIAL) FS_BLEND_ONE(md & gd, av.y, mv.y, kd, e3.w)
+    };
+
     // software pipeline: list words two batches ahead, records one batch ahead
     uint32_t w_cur = lane < n ? pl[lane] : 0u;
     uint32_t w_nxt = 64 + lane < n ? pl[64 + lane] : 0u;
@@ -892,6 +957,10 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
         const float4* q = rec + 3 * (size_t)(w_cur >> 4);
         r0 = q[0]; r1 = q[1]; r2 = q[2];
     }
+    // Survivors that do not fill a step of four are CARRIED into the next batch (they stay at the front of the
+    // compaction area, the next batch's survivors are appended behind them): one partial step per quadrant instead of
+    // one per batch (~0.4 of a step per batch of ~9).
+    int rem = 0;
     for (int c = 0; c < n; c += 64) {
         if (done_m == ~0ull) break;  // every pixel of the quadrant is saturated (or outside the image)
         const bool hit = (w_cur & qbit) != 0;
@@ -904,9 +973,8 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
             r0 = q[0]; r1 = q[1]; r2 = q[2];
         }
         if (!hits) continue;
-        const int cnt = __popcll(hits);
         if (hit) {
-            const int k = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0));
+            const int k = rem + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0));
             float* d = (float*)(cp + (k >> 1) * kPairQuads) + (k & 1);
             // (coefficients NEGATED: the walk evaluates q = -power >= 0, bit for bit the negation of the oracle's power,
             //  so that "0 >= power >= threshold" is one unsigned compare of q's bits against skip_bits)
@@ -915,86 +983,27 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
             d[8] = -a1.x; d[10] = skip_bits(a1.z);      // [B_a B_b thr_a thr_b] (B = b; thr = bits of -threshold)
             d[12] = a1.y; d[14] = __int_as_float(c + lane + 1);  // [op_a op_b pos_a pos_b]
             cp[(k >> 1) * kPairQuads + 4 + (k & 1)] = make_float4(a2.x, a2.y, a2.z, a1.w);  // [r g b depth]
-            // the batch's last step may be partial: its unused entries enter with weight 0, their colours must still be finite
-            if (k == cnt - 1) {
-                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                const int s = k >> 1;
-                if (!(k & 1)) cp[s * kPairQuads + 5] = z;
-                if (!(s & 1)) { cp[(s + 1) * kPairQuads + 4] = z; cp[(s + 1) * kPairQuads + 5] = z; }  // unused second slot of the step
-            }
         }
         wave_lds_sync();
-        // VM: mask of the pixels this survivor can reach (power in range, alpha >= 1/255, pixel not yet saturated)
-#define FS_BLEND_ONE(VM, AL, OM, KR, POS)                                                           \
-        {                                                                                           \
-            const float test_T = T_ * (OM);                                                         \
-            const unsigned long long vis = (VM) & ~done_m;                                          \
-            const unsigned long long okc = __builtin_amdgcn_ballot_w64(test_T >= 0.0001f);          \
-            done_m |= vis & ~okc;                     /* T would fall below 1e-4: the pixel is done, this one not applied */ \
-            const bool ok = __builtin_amdgcn_inverse_ballot_w64(vis & okc);                         \
-            const f32x2 wgt = splat2(ok ? (AL) * T_ : 0.0f); /* weight 0: sums unchanged (finite colours) */ \
-            C01 = fma2((f32x2){(KR).x, (KR).y}, wgt, C01);                                          \
-            C2D = fma2((f32x2){(KR).z, (KR).w}, wgt, C2D);                                          \
-            T_ = ok ? test_T : T_;                                                                  \
-            if constexpr (TRACK) last = ok ? __float_as_int(POS) : last;                            \
-        }
-        // One step = two slots = four survivors a, b | c, d, blended strictly in list order.  PARTIAL: the batch's last
-        // step when cnt is not a multiple of 4 (entries beyond cnt are masked out); full steps carry no such logic.
-        auto step = [&](const float4* q, auto partial, int left) __attribute__((always_inline)) {
-            constexpr bool PARTIAL = decltype(partial)::value;
-            const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
-            const float4 e0 = q[6], e1 = q[7], e2 = q[8], e3 = q[9];
-            const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
-            const f32x2 ex = (f32x2){e0.x, e0.y} - pfx, ey = (f32x2){e0.z, e0.w} - pfy;
-            // -power = A dx^2 + dy (C dy + B dx): 3 multiplications + 2 fmas (the oracle's own association)
-            const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx, dy * fma2((f32x2){c1.z, c1.w}, dy, (f32x2){c2.x, c2.y} * dx));
-            const f32x2 pv = fma2((f32x2){e1.x, e1.y} * ex, ex, ey * fma2((f32x2){e1.z, e1.w}, ey, (f32x2){e2.x, e2.y} * ex));
-            // +0 <= q <= -threshold  <=>  bits(q) <= bits(-threshold) as unsigned (negative q and NaN compare above)
-            unsigned long long ma = __builtin_amdgcn_ballot_w64(__float_as_uint(pw.x) <= __float_as_uint(c2.z));
-            unsigned long long mb = __builtin_amdgcn_ballot_w64(__float_as_uint(pw.y) <= __float_as_uint(c2.w));
-            unsigned long long mc = __builtin_amdgcn_ballot_w64(__float_as_uint(pv.x) <= __float_as_uint(e2.z));
-            unsigned long long md = __builtin_amdgcn_ballot_w64(__float_as_uint(pv.y) <= __float_as_uint(e2.w));
-            if constexpr (PARTIAL) { mb = left > 1 ? mb : 0ull; mc = left > 2 ? mc : 0ull; md = 0ull; }
-            if ((((ma | mb) | (mc | md)) & ~done_m) == 0ull) return;  // wave-uniform: nobody in range
-            const float4 ka = q[4], kb = q[5], kc = q[10], kd = q[11];
-            f32x2 ew = blend_exp_of_neg<FAST_EXP>(pw), ev = blend_exp_of_neg<FAST_EXP>(pv);
-            f32x2 ow = (f32x2){c3.x, c3.y} * ew, ov = (f32x2){e3.x, e3.y} * ev;
-            f32x2 aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
-            f32x2 av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
-            unsigned long long ga, gb, gc, gd;   // alpha >= 1/255
-            if constexpr (FAST_EXP) {
-                // hardware exp; a step with an alpha inside the guard band of the 1/255 threshold (fs_common.h) is
-                // re-evaluated with the contract exp, so the accept / reject decisions are those of the exact mode
-                const float glo = alpha_guard_lo(), ghi = alpha_guard_hi();
-                ga = __builtin_amdgcn_ballot_w64(aw.x >= ghi); gb = __builtin_amdgcn_ballot_w64(aw.y >= ghi);
-                gc = __builtin_amdgcn_ballot_w64(av.x >= ghi); gd = __builtin_amdgcn_ballot_w64(av.y >= ghi);   // nothing in [glo, ghi): same as >= 1/255
-                const unsigned long long nb = (__builtin_amdgcn_ballot_w64(aw.x >= glo) & ~ga) | (__builtin_amdgcn_ballot_w64(aw.y >= glo) & ~gb)
-                                            | (__builtin_amdgcn_ballot_w64(av.x >= glo) & ~gc) | (__builtin_amdgcn_ballot_w64(av.y >= glo) & ~gd);
-                if (__builtin_expect(nb != 0ull, 0)) {  // wave-uniform, rare
-                    ew = blend_exp_of_neg<false>(pw); ev = blend_exp_of_neg<false>(pv);
-                    ow = (f32x2){c3.x, c3.y} * ew; ov = (f32x2){e3.x, e3.y} * ev;
-                    aw = (f32x2){fminf(0.99f, ow.x), fminf(0.99f, ow.y)};
-                    av = (f32x2){fminf(0.99f, ov.x), fminf(0.99f, ov.y)};
-                    ga = __builtin_amdgcn_ballot_w64(aw.x >= 1.0f / 255.0f); gb = __builtin_amdgcn_ballot_w64(aw.y >= 1.0f / 255.0f);
-                    gc = __builtin_amdgcn_ballot_w64(av.x >= 1.0f / 255.0f); gd = __builtin_amdgcn_ballot_w64(av.y >= 1.0f / 255.0f);
-                }
-            } else {
-                ga = __builtin_amdgcn_ballot_w64(aw.x >= 1.0f / 255.0f); gb = __builtin_amdgcn_ballot_w64(aw.y >= 1.0f / 255.0f);
-                gc = __builtin_amdgcn_ballot_w64(av.x >= 1.0f / 255.0f); gd = __builtin_amdgcn_ballot_w64(av.y >= 1.0f / 255.0f);
-            }
-            const f32x2 mw = splat2(1.0f) - aw, mv = splat2(1.0f) - av;
-            FS_BLEND_ONE(ma & ga, aw.x, mw.x, ka, c3.z)
-            FS_BLEND_ONE(mb & gb, aw.y, mw.y, kb, c3.w)
-            FS_BLEND_ONE(mc & gc, av.x, mv.x, kc, e3.z)
-            if constexpr (!PARTIAL) FS_BLEND_ONE(md & gd, av.y, mv.y, kd, e3.w)
-        };
-        const int nfull = cnt >> 2;
+        const int total = rem + __popcll(hits), nfull = total >> 2;
         for (int p = 0; p < nfull; ++p) step(cp + 2 * p * kPairQuads, std::false_type{}, 4);
-        if (cnt & 3) step(cp + 2 * nfull * kPairQuads, std::true_type{}, cnt & 3);
-#undef FS_BLEND_ONE
-        // (the next batch's compaction overwrites the slots: DS operations of one wavefront execute in order)
-        wave_lds_sync();
+        rem = total & 3;
+        if (rem != 0 && nfull != 0) {
+            // the leftover entries sit in the slot pair behind the last full step: move that pair to the front
+            // (DS operations of one wavefront execute in order: the steps' reads are done, the copy's read precedes its write)
+            float4 t = {};
+            if (lane < 2 * kPairQuads) t = cp[2 * nfull * kPairQuads + lane];
+            if (lane < 2 * kPairQuads) cp[lane] = t;
+        }
+        wave_lds_sync();   // (the next batch's compaction appends behind the carried entries)
     }
+    if (rem != 0 && done_m != ~0ull) {
+        // the quadrant's last, partial step: its unused entries enter with weight 0, their colours must still be finite
+        if (lane >= rem && lane < 4) cp[(lane >> 1) * kPairQuads + 4 + (lane & 1)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        wave_lds_sync();
+        step(cp, std::true_type{}, rem);
+    }
+#undef FS_BLEND_ONE
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         final_T[pix] = T_;

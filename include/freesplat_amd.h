@@ -106,8 +106,10 @@ typedef struct fs_raster_dims {
  *   out[0] geom    : per-Gaussian screen-space state            (saved for backward)
  *   out[1] binning : per-tile ranges + depth-sorted id list      (saved for backward)
  *   out[2] image   : per-pixel final transmittance + n_contrib   (saved for backward)
- *   out[3] scratch : sort keys, tile counters                    (reusable after the call)
- * `inst_capacity` bounds the number of (gaussian, tile) instances; see fs_raster_forward. */
+ *   out[3] scratch : tile counters + one FIXED key area per tile  (reusable after the call)
+ * `inst_capacity` bounds the number of (gaussian, tile) instances (the saved lists hold that many entries) and sizes
+ * the key areas: every tile owns tile_capacity = the power of two >= max(2048, 4 * inst_capacity / T) key slots (T =
+ * tiles), so that the projection kernel can bin in the same launch; see fs_raster_forward for the overflow report. */
 int fs_raster_buffer_sizes(int32_t N, int32_t H, int32_t W, int64_t inst_capacity, size_t out[4]);
 
 /*
@@ -116,9 +118,10 @@ int fs_raster_buffer_sizes(int32_t N, int32_t H, int32_t W, int64_t inst_capacit
  * projmatrix[16] (both as torch passes them: transposed, i.e. column-major), campos[3].
  * Outputs (device): out_color[3,H,W], out_depth[H,W] (sum z*alpha*T, un-normalised),
  * out_alpha[H,W] (1 - T_final), radii[N] (int32, 0 = culled),
- * counters[2] (uint32): {number of instances I, overflow flag (I > inst_capacity)}.
- * If the overflow flag is set the image outputs are undefined and the caller must retry
- * with inst_capacity >= I (the library never allocates).
+ * counters[2] (uint32): {number of instances I, overflow}.  overflow == 0: fine.  overflow != 0 (I > inst_capacity, or
+ * a tile list longer than its key area): the value is the LARGEST TILE LIST n_max (>= 1); the image outputs are
+ * undefined and the caller must retry with a capacity such that inst_capacity >= I and 4 * inst_capacity / T >= n_max
+ * (the library never allocates).
  * Optional device-resident settings (NULL = unused), so that a multi-view caller never has to
  * read a tensor back to the host:
  *   tanfov_dev[2]  overrides dims->tanfovx/tanfovy;
