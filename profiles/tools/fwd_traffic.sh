@@ -8,7 +8,7 @@ for W in $WL; do
   mkdir -p $OUT
   CALLS=$(python -c "import sys; sys.path.insert(0,'profiles/tools'); import fwd_traffic as f; print(f.WORKLOADS['$W'][1])")
   echo $CALLS > $OUT/calls.txt
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o x --output-format csv -- python profiles/tools/fwd_traffic.py run $W $CALLS > $OUT/fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o x --output-format csv -- python profiles/tools/fwd_traffic.py run $W $CALLS > $OUT/write.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o x --output-format csv -- python profiles/tools/fwd_traffic.py run $W $CALLS > $OUT/fetch.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o x --output-format csv -- python profiles/tools/fwd_traffic.py run $W $CALLS > $OUT/write.log 2>&1
 done
 python profiles/tools/fwd_traffic.py summarize $TAG

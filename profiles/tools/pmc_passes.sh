@@ -2,20 +2,19 @@
 # Generic PMC passes of one command, each counter set in its own run (kernel-trace only beside it):
 #   profiles/tools/pmc_passes.sh <outdir> <kernel-name-substring> -- <command...>
 # prints the mean per-launch value of every counter for the kernels whose name contains the substring.
+# (SQ / GRBM sets only: four TA_*_sum counters in one pass made rocprofv3 abort -- "exceeds the capabilities of the
+#  hardware" -- and then hang until killed; every pass runs under `timeout`.)
 export TMPDIR=/tmp
 OUT=$1; PAT=$2; shift 3
 mkdir -p $OUT
 SETS=(
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
  "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU"
- "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_TOTAL_CYCLES_sum"
- "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"
- "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TD_TD_BUSY_sum"
  "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES"
 )
 i=0
 for S in "${SETS[@]}"; do
-  rocprofv3 --pmc $S --kernel-trace -d $OUT/p$i -o x --output-format csv -- "$@" > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $S --kernel-trace -d $OUT/p$i -o x --output-format csv -- "$@" > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python - "$OUT" "$PAT" <<'PY'
