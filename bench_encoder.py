@@ -39,6 +39,21 @@ def _traffic(workload):
         return None, None
 
 
+def _mfma_busy(kernel_prefix):
+    """Matrix-pipe busy fraction of the sweep kernel from the newest committed PMC summary (SQ_VALU_MFMA_BUSY_CYCLES /
+    (1024 SIMDs x kernel-trace duration x 2.4 GHz); profiles/run_rocprof_encoder.sh: native 96x128 K = 1 only)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cv_sq_counters.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            for k, v in d.get("kernels", d).items():
+                if isinstance(v, dict) and k.startswith(kernel_prefix) and "mfma_busy_frac_at_2.4GHz" in v:
+                    return float(v["mfma_busy_frac_at_2.4GHz"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, cpu=True, cpu_views=None):
     """`cpu_views`: how many of the V current views the CPU baseline sweeps (bounded sample; default all)."""
     import inputs
@@ -99,6 +114,9 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
             "roofline": {"bound": "mfma", "kernel": "cost_volume (relayout + sweep)", "achieved": flops / kern / 1e12,
                          "peak": 157.3, "unit": "TFLOP/s", "frac": flops / kern / 1e12 / 157.3,
                          "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern * 1e3, "launches": cnt,
+                         "mfma_busy_counter": _mfma_busy("fs::cost_volume_proj_kernel")[0] if wl_name == "cv_native_K1" else None,
+                         "mfma_busy_note": "matrix-pipe busy fraction from SQ_VALU_MFMA_BUSY_CYCLES (native K = 1 profile); `frac` "
+                                           "prices the reference formulation's flops (41 MFMAs per cell), the K = 1 sweep issues 16",
                          "traffic": _traffic(wl_name)[0], "traffic_source": _traffic(wl_name)[1],
                          "traffic_unit": "HBM bytes per call (all current views)"}}, **extra)
 

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 TAG=$1; shift
 OUT=gpurun_out/prof_${TAG}_train
 mkdir -p $OUT
-B="python bench.py --steps 3 --warmup 1 --sections raster --no-graph --no-cpu-baseline --no-profile --mode train $*"
+B="python bench.py --steps 3 --warmup 1 --sections raster --no-graph --no-cpu-baseline --no-profile --min-time 0 --mode train $*"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o c3 --output-format csv -- $B > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o c3 --output-format csv -- $B > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o c3 --output-format csv -- $B > $OUT/write.log 2>&1
