@@ -16,7 +16,8 @@
 namespace fs {
 
 constexpr int kGradStride = 12;  // floats per Gaussian in the accumulation scratch
-// layout: 0,1 mean2D | 2,3,4 conic (x, y(half), z) | 5 opacity | 6,7,8 rgb | 9 view z | 10,11 pad
+// layout: 0,1 moments S_x, S_y | 2,3,4 moments S_xx, S_xy, S_yy (render_bwd; preprocess_bwd turns them into the mean2D and
+// conic gradients) | 5 opacity | 6,7,8 rgb | 9 view z | 10,11 pad
 
 // Wavefront sums on the gfx950 row-swap instructions: v_permlane32_swap(X, Y) leaves X+Y = (value X summed over lanes
 // l, l+32) in the lower half and (value Y ...) in the upper half -- one swap + one add per surviving value, a HALVING
@@ -104,7 +105,6 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
     const f32x2 g01 = {inside ? dL_dcolor[pix] : 0.0f, inside ? dL_dcolor[HW + pix] : 0.0f};
     const f32x2 g23 = {inside ? dL_dcolor[2 * HW + pix] : 0.0f, (inside && dL_ddepth) ? dL_ddepth[pix] : 0.0f};
     const float Tb = Tf * (bg[0] * g01.x + bg[1] * g01.y + bg[2] * g23.x);
-    const f32x2 half_wh = {0.5f * (float)W, 0.5f * (float)H};
 
     int maxlast = last;
 #pragma unroll
@@ -219,21 +219,17 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
                 const f32x2 c01 = w * g01, c23 = w * g23;
                 vb[6] = c01.x; vb[7] = c01.y; vb[8] = c23.x; vb[9] = c23.y;
             }
-            // per-Gaussian derivative terms of both survivors, packed [a, b]
+            // per-Gaussian derivative terms of both survivors, packed [a, b].  The five geometric partials leave as MOMENT
+            // sums of w = dL/dG * G over the pixels -- S_x = sum w dx, S_y = sum w dy, S_xx = sum w dx^2, S_xy = sum w dx dy,
+            // S_yy = sum w dy^2 -- and preprocess_bwd combines them per Gaussian with the conic:
+            //   dL/dmean2D = -(W/2, H/2) * (a S_x + b S_y, c S_y + b S_x),   dL/dconic = -1/2 (S_xx, S_xy, S_yy)
+            // (linear in the partials, so summing first is the same sum; 9 packed operations per pair instead of 20).
             const f32x2 dL_dG = (f32x2){c3.x, c3.y} * dLa;
             const f32x2 v_op = G * dLa;
-            const f32x2 gdx = G * dx, gdy = G * dy;
-            const f32x2 A2 = (f32x2){c1.x, c1.y} + (f32x2){c1.x, c1.y}, C2 = (f32x2){c1.z, c1.w} + (f32x2){c1.z, c1.w};
-            const f32x2 Bm = {c2.x, c2.y};
-            const f32x2 dGx = -fma2(A2, gdx, Bm * gdy);  // dG/d(delta x) = -(a gdx + b gdy),  A = a/2, B = b
-            const f32x2 dGy = -fma2(C2, gdy, Bm * gdx);
-            const f32x2 v_mx = (dL_dG * dGx) * splat2(half_wh.x);
-            const f32x2 v_my = (dL_dG * dGy) * splat2(half_wh.y);
-            const f32x2 hq = dL_dG * splat2(-0.5f);
-            const f32x2 tx2 = gdx * hq, ty2 = gdy * hq;
-            const f32x2 v_ca = tx2 * dx, v_cb = tx2 * dy, v_cc = ty2 * dy;
-            va[0] = v_mx.x; va[1] = v_my.x; va[2] = v_ca.x; va[3] = v_cb.x; va[4] = v_cc.x; va[5] = v_op.x;
-            vb[0] = v_mx.y; vb[1] = v_my.y; vb[2] = v_ca.y; vb[3] = v_cb.y; vb[4] = v_cc.y; vb[5] = v_op.y;
+            const f32x2 wdx = dL_dG * (G * dx), wdy = dL_dG * (G * dy);
+            const f32x2 sxx = wdx * dx, sxy = wdx * dy, syy = wdy * dy;
+            va[0] = wdx.x; va[1] = wdy.x; va[2] = sxx.x; va[3] = sxy.x; va[4] = syy.x; va[5] = v_op.x;
+            vb[0] = wdx.y; vb[1] = wdy.y; vb[2] = sxx.y; vb[3] = sxy.y; vb[4] = syy.y; vb[5] = v_op.y;
             float tot[5];
             wave_sum_pair(va, vb, tot);
             // row r of the wavefront: components 5*(r&1) .. +4 of survivor (r >> 1); lane (r, j < 5) flushes component j
@@ -356,8 +352,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float3 p = p0;
             if (scale_dev) { p.x = p.x * wscale; p.y = p.y * wscale; p.z = p.z * wscale; }
             aop += ga[5];
-            const float gm2x = ga[0], gm2y = ga[1];
-            am2x += gm2x; am2y += gm2y;
             const float fx = (float)d.W / (2.0f * tanfovx), fy = (float)d.H / (2.0f * tanfovy);
             float c3[6];
 #pragma unroll
@@ -371,7 +365,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float a = cv.a, b = cv.b, c = cv.c;
             const float denom = a * c - b * b;
             const float d2inv = 1.0f / (denom * denom + 0.0000001f);
-            const float gcx = ga[2], gcy = ga[3], gcz = ga[4];
+            // the blend's moment sums -> gradients of the 2-D mean (pixels) and of the conic (A, B, C) = (c, -b, a) / det
+            float gm2x = 0.0f, gm2y = 0.0f;
+            if (denom != 0.0f) {
+                const float det_inv = 1.0f / denom;
+                const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
+                gm2x = -0.5f * (float)d.W * (cA * ga[0] + cB * ga[1]);
+                gm2y = -0.5f * (float)d.H * (cC * ga[1] + cB * ga[0]);
+            }
+            am2x += gm2x; am2y += gm2y;
+            const float gcx = -0.5f * ga[2], gcy = -0.5f * ga[3], gcz = -0.5f * ga[4];
             float gt[3] = {0, 0, 0};
             if (d2inv != 0.0f) {
                 const float dL_da = d2inv * (-c * c * gcx + 2.0f * b * c * gcy + (denom - a * c) * gcz);
