@@ -105,6 +105,11 @@ def lib():
             raise FreeSplatHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). freesplat_amd has no CPU / eager fallback.")
+        # torch first: it brings its own HIP runtime (libamdhip64 of its ROCm build), and the library must resolve its HIP
+        # symbols to THAT copy -- loaded the other way round (this library first, as a bare `build(); smoke()` in one
+        # process did) the system runtime is initialised beside torch's and every launch fails with "no ROCm-capable
+        # device is detected"
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
