@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
     const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, float* __restrict__ grad)
 {
-    __shared__ float4 s_pair[32 * kBwdQuads];
+    __shared__ float4 s_pair[33 * kBwdQuads];   // up to 1 carried + 64 new survivors, two per slot
     if (counters && counters[1]) return;  // the forward overflowed its capacity: no image, no lists -> zero gradients
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     const int wave = (blockIdx.x >> 3) & 3;  // quadrant; same workgroup order as the forward
@@ -117,6 +117,85 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
     const int row = lane >> 4, col = lane & 15;
     float4* const cp = s_pair;
 
+    // One pair of survivors (a further back, b in front of it): recompute, recurrences, partials, wavefront sums, flush.
+    auto do_pair = [&](const float4* q) __attribute__((always_inline)) {
+        const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+        const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
+        const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx, dy * fma2((f32x2){c1.z, c1.w}, dy, (f32x2){c2.x, c2.y} * dx));
+        // pw = -power; +0 <= pw <= -threshold as ONE unsigned compare of the bit patterns
+        bool on_a = __float_as_int(c3.z) <= last, on_b = __float_as_int(c3.w) <= last;
+        on_a = on_a & (__float_as_uint(pw.x) <= __float_as_uint(c2.z));
+        on_b = on_b & (__float_as_uint(pw.y) <= __float_as_uint(c2.w));
+        if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) return;  // wave-uniform
+        f32x2 Gr = blend_exp_of_neg<FAST_EXP>(pw);
+        f32x2 oe = (f32x2){c3.x, c3.y} * Gr;
+        f32x2 al_raw = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+        if constexpr (FAST_EXP) {
+            // an alpha inside the guard band of the 1/255 threshold (fs_common.h): the pair is re-evaluated with the
+            // contract exp, so the accept / reject decisions are those of the exact mode (and of the forward)
+            const float glo = alpha_guard_lo(), ghi = alpha_guard_hi();
+            const bool nb = (on_a & (al_raw.x >= glo) & !(al_raw.x >= ghi)) | (on_b & (al_raw.y >= glo) & !(al_raw.y >= ghi));
+            if (__builtin_amdgcn_ballot_w64(nb) != 0) {  // wave-uniform, rare
+                Gr = blend_exp_of_neg<false>(pw);
+                oe = (f32x2){c3.x, c3.y} * Gr;
+                al_raw = (f32x2){fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+            }
+        }
+        on_a = on_a & (al_raw.x >= 1.0f / 255.0f);
+        on_b = on_b & (al_raw.y >= 1.0f / 255.0f);
+        if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) return;
+        const float4 ka = q[4], kb = q[5];
+        const f32x2 al = {on_a ? al_raw.x : 0.0f, on_b ? al_raw.y : 0.0f};
+        const f32x2 G = {on_a ? Gr.x : 0.0f, on_b ? Gr.y : 0.0f};
+        const f32x2 om = splat2(1.0f) - al;
+        // 1 - alpha >= 0.01: one reciprocal (1 ulp) serves both divisions of the reference formula
+        const f32x2 rinv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+        float va[10], vb[10];
+        f32x2 dLa;
+        {   // survivor a (the one further back)
+            T_ = T_ * rinv.x;
+            const f32x2 d01 = (f32x2){ka.x, ka.y} - R01, d23 = (f32x2){ka.z, ka.w} - R23;
+            const f32x2 s = fma2(d23, g23, d01 * g01);
+            R01 = fma2(splat2(al.x), d01, R01);
+            R23 = fma2(splat2(al.x), d23, R23);
+            dLa.x = fmaf(s.x + s.y, T_, -(Tb * rinv.x));
+            const f32x2 w = splat2(al.x * T_);
+            const f32x2 c01 = w * g01, c23 = w * g23;
+            va[6] = c01.x; va[7] = c01.y; va[8] = c23.x; va[9] = c23.y;
+        }
+        {   // survivor b (in front of a)
+            T_ = T_ * rinv.y;
+            const f32x2 d01 = (f32x2){kb.x, kb.y} - R01, d23 = (f32x2){kb.z, kb.w} - R23;
+            const f32x2 s = fma2(d23, g23, d01 * g01);
+            R01 = fma2(splat2(al.y), d01, R01);
+            R23 = fma2(splat2(al.y), d23, R23);
+            dLa.y = fmaf(s.x + s.y, T_, -(Tb * rinv.y));
+            const f32x2 w = splat2(al.y * T_);
+            const f32x2 c01 = w * g01, c23 = w * g23;
+            vb[6] = c01.x; vb[7] = c01.y; vb[8] = c23.x; vb[9] = c23.y;
+        }
+        // per-Gaussian derivative terms of both survivors, packed [a, b].  The five geometric partials leave as MOMENT
+        // sums of w = dL/dG * G over the pixels -- S_x = sum w dx, S_y = sum w dy, S_xx = sum w dx^2, S_xy = sum w dx dy,
+        // S_yy = sum w dy^2 -- and preprocess_bwd combines them per Gaussian with the conic:
+        //   dL/dmean2D = -(W/2, H/2) * (a S_x + b S_y, c S_y + b S_x),   dL/dconic = -1/2 (S_xx, S_xy, S_yy)
+        // (linear in the partials, so summing first is the same sum; 9 packed operations per pair instead of 20).
+        const f32x2 dL_dG = (f32x2){c3.x, c3.y} * dLa;
+        const f32x2 v_op = G * dLa;
+        const f32x2 wdx = dL_dG * (G * dx), wdy = dL_dG * (G * dy);
+        const f32x2 sxx = wdx * dx, sxy = wdx * dy, syy = wdy * dy;
+        va[0] = wdx.x; va[1] = wdy.x; va[2] = sxx.x; va[3] = sxy.x; va[4] = syy.x; va[5] = v_op.x;
+        vb[0] = wdx.y; vb[1] = wdy.y; vb[2] = sxx.y; vb[3] = sxy.y; vb[4] = syy.y; vb[5] = v_op.y;
+        float tot[5];
+        wave_sum_pair(va, vb, tot);
+        // row r of the wavefront: components 5*(r&1) .. +4 of survivor (r >> 1); lane (r, j < 5) flushes component j
+        const float4 ids = q[6];
+        if (col < 5) {
+            const float v = col == 0 ? tot[0] : col == 1 ? tot[1] : col == 2 ? tot[2] : col == 3 ? tot[3] : tot[4];
+            const uint32_t id = __float_as_uint(row < 2 ? ids.x : ids.y);
+            if (v != 0.0f) atomicAdd(&grad[(size_t)id * kGradStride + 5 * (row & 1) + col], v);
+        }
+    };
+
     // software pipeline over batches of 64 entries, highest batch first: list words two batches ahead, records one
     const int top = (m_end - 1) >> 6;
     auto word = [&](int bi) -> uint32_t {
@@ -129,6 +208,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
         const float4* q = rec + 3 * (size_t)(w_cur >> 4);
         r0 = q[0]; r1 = q[1]; r2 = q[2];
     }
+    int rem = 0;
     for (int bi = top; bi >= 0; --bi) {
         const bool hit = (w_cur & qbit) != 0;
         const unsigned long long hits = __ballot(hit);
@@ -143,7 +223,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
         if (!hits) continue;
         const int cnt = __popcll(hits);
         if (hit) {
-            const int k = __popcll(hits & ~((2ull << lane) - 1ull));  // survivors above this lane: back to front
+            const int k = rem + __popcll(hits & ~((2ull << lane) - 1ull));  // carried survivor + survivors above this lane: back to front
             float* d = (float*)(cp + (k >> 1) * kBwdQuads) + (k & 1);
             // (coefficients negated, threshold as unsigned-compare bits: see the forward's compaction)
             d[0] = a0.x; d[2] = a0.y;                    // [x_a x_b y_a y_b]
@@ -152,95 +232,31 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
             d[12] = a1.y; d[14] = __int_as_float((bi << 6) + lane + 1);  // [op_a op_b pos_a pos_b]
             cp[(k >> 1) * kBwdQuads + 4 + (k & 1)] = make_float4(a2.x, a2.y, a2.z, a1.w);  // [r g b depth]
             d[24] = __uint_as_float(w_this >> 4);        // [id_a id_b . .]
-            if (k == cnt - 1 && !(k & 1)) {
-                // odd count: the unused half of the last slot must hold finite numbers (it enters with weight 0)
-                d[1] = 0.0f; d[3] = 0.0f; d[5] = 0.0f; d[7] = 0.0f; d[9] = 0.0f; d[11] = 0.0f; d[13] = 0.0f;
-                d[15] = __int_as_float(0x7fffffff);
-                cp[(k >> 1) * kBwdQuads + 5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                d[25] = 0.0f;
-            }
         }
         wave_lds_sync();
-        const int nslots = (cnt + 1) >> 1;
-        for (int p = 0; p < nslots; ++p) {
-            const float4* q = cp + p * kBwdQuads;
-            const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
-            const f32x2 dx = (f32x2){c0.x, c0.y} - pfx, dy = (f32x2){c0.z, c0.w} - pfy;
-            const f32x2 pw = fma2((f32x2){c1.x, c1.y} * dx, dx, dy * fma2((f32x2){c1.z, c1.w}, dy, (f32x2){c2.x, c2.y} * dx));
-            // pw = -power; +0 <= pw <= -threshold as ONE unsigned compare of the bit patterns
-            bool on_a = __float_as_int(c3.z) <= last, on_b = __float_as_int(c3.w) <= last;
-            on_a = on_a & (__float_as_uint(pw.x) <= __float_as_uint(c2.z));
-            on_b = on_b & (__float_as_uint(pw.y) <= __float_as_uint(c2.w));
-            if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) continue;  // wave-uniform
-            f32x2 Gr = blend_exp_of_neg<FAST_EXP>(pw);
-            f32x2 oe = (f32x2){c3.x, c3.y} * Gr;
-            f32x2 al_raw = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
-            if constexpr (FAST_EXP) {
-                // an alpha inside the guard band of the 1/255 threshold (fs_common.h): the pair is re-evaluated with the
-                // contract exp, so the accept / reject decisions are those of the exact mode (and of the forward)
-                const float glo = alpha_guard_lo(), ghi = alpha_guard_hi();
-                const bool nb = (on_a & (al_raw.x >= glo) & !(al_raw.x >= ghi)) | (on_b & (al_raw.y >= glo) & !(al_raw.y >= ghi));
-                if (__builtin_amdgcn_ballot_w64(nb) != 0) {  // wave-uniform, rare
-                    Gr = blend_exp_of_neg<false>(pw);
-                    oe = (f32x2){c3.x, c3.y} * Gr;
-                    al_raw = (f32x2){fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
-                }
-            }
-            on_a = on_a & (al_raw.x >= 1.0f / 255.0f);
-            on_b = on_b & (al_raw.y >= 1.0f / 255.0f);
-            if (__builtin_amdgcn_ballot_w64(on_a | on_b) == 0) continue;
-            const float4 ka = q[4], kb = q[5];
-            const f32x2 al = {on_a ? al_raw.x : 0.0f, on_b ? al_raw.y : 0.0f};
-            const f32x2 G = {on_a ? Gr.x : 0.0f, on_b ? Gr.y : 0.0f};
-            const f32x2 om = splat2(1.0f) - al;
-            // 1 - alpha >= 0.01: one reciprocal (1 ulp) serves both divisions of the reference formula
-            const f32x2 rinv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-            float va[10], vb[10];
-            f32x2 dLa;
-            {   // survivor a (the one further back)
-                T_ = T_ * rinv.x;
-                const f32x2 d01 = (f32x2){ka.x, ka.y} - R01, d23 = (f32x2){ka.z, ka.w} - R23;
-                const f32x2 s = fma2(d23, g23, d01 * g01);
-                R01 = fma2(splat2(al.x), d01, R01);
-                R23 = fma2(splat2(al.x), d23, R23);
-                dLa.x = fmaf(s.x + s.y, T_, -(Tb * rinv.x));
-                const f32x2 w = splat2(al.x * T_);
-                const f32x2 c01 = w * g01, c23 = w * g23;
-                va[6] = c01.x; va[7] = c01.y; va[8] = c23.x; va[9] = c23.y;
-            }
-            {   // survivor b (in front of a)
-                T_ = T_ * rinv.y;
-                const f32x2 d01 = (f32x2){kb.x, kb.y} - R01, d23 = (f32x2){kb.z, kb.w} - R23;
-                const f32x2 s = fma2(d23, g23, d01 * g01);
-                R01 = fma2(splat2(al.y), d01, R01);
-                R23 = fma2(splat2(al.y), d23, R23);
-                dLa.y = fmaf(s.x + s.y, T_, -(Tb * rinv.y));
-                const f32x2 w = splat2(al.y * T_);
-                const f32x2 c01 = w * g01, c23 = w * g23;
-                vb[6] = c01.x; vb[7] = c01.y; vb[8] = c23.x; vb[9] = c23.y;
-            }
-            // per-Gaussian derivative terms of both survivors, packed [a, b].  The five geometric partials leave as MOMENT
-            // sums of w = dL/dG * G over the pixels -- S_x = sum w dx, S_y = sum w dy, S_xx = sum w dx^2, S_xy = sum w dx dy,
-            // S_yy = sum w dy^2 -- and preprocess_bwd combines them per Gaussian with the conic:
-            //   dL/dmean2D = -(W/2, H/2) * (a S_x + b S_y, c S_y + b S_x),   dL/dconic = -1/2 (S_xx, S_xy, S_yy)
-            // (linear in the partials, so summing first is the same sum; 9 packed operations per pair instead of 20).
-            const f32x2 dL_dG = (f32x2){c3.x, c3.y} * dLa;
-            const f32x2 v_op = G * dLa;
-            const f32x2 wdx = dL_dG * (G * dx), wdy = dL_dG * (G * dy);
-            const f32x2 sxx = wdx * dx, sxy = wdx * dy, syy = wdy * dy;
-            va[0] = wdx.x; va[1] = wdy.x; va[2] = sxx.x; va[3] = sxy.x; va[4] = syy.x; va[5] = v_op.x;
-            vb[0] = wdx.y; vb[1] = wdy.y; vb[2] = sxx.y; vb[3] = sxy.y; vb[4] = syy.y; vb[5] = v_op.y;
-            float tot[5];
-            wave_sum_pair(va, vb, tot);
-            // row r of the wavefront: components 5*(r&1) .. +4 of survivor (r >> 1); lane (r, j < 5) flushes component j
-            const float4 ids = q[6];
-            if (col < 5) {
-                const float v = col == 0 ? tot[0] : col == 1 ? tot[1] : col == 2 ? tot[2] : col == 3 ? tot[3] : tot[4];
-                const uint32_t id = __float_as_uint(row < 2 ? ids.x : ids.y);
-                if (v != 0.0f) atomicAdd(&grad[(size_t)id * kGradStride + 5 * (row & 1) + col], v);
-            }
+        // An odd survivor is CARRIED into the next batch (it stays in the front slot as the `a` half; the next batch's
+        // first survivor -- in front of it in the list -- becomes its `b`): one half-empty pair per quadrant, not per batch.
+        const int total = rem + cnt, npairs = total >> 1;
+        for (int p = 0; p < npairs; ++p) do_pair(cp + p * kBwdQuads);
+        rem = total & 1;
+        if (rem != 0 && npairs != 0) {
+            float4 t = {};
+            if (lane < kBwdQuads) t = cp[npairs * kBwdQuads + lane];
+            if (lane < kBwdQuads) cp[lane] = t;        // (DS operations of one wavefront execute in order)
         }
         wave_lds_sync();  // the next batch's compaction overwrites the slots
+    }
+    if (rem != 0) {
+        // the quadrant's last survivor has no partner: the unused `b` half must hold finite numbers (it enters with weight 0)
+        if (lane == 0) {
+            float* d = (float*)cp;
+            d[1] = 0.0f; d[3] = 0.0f; d[5] = 0.0f; d[7] = 0.0f; d[9] = 0.0f; d[11] = 0.0f; d[13] = 0.0f;
+            d[15] = __int_as_float(0x7fffffff);
+            cp[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            d[25] = 0.0f;
+        }
+        wave_lds_sync();
+        do_pair(cp);
     }
 }
 
