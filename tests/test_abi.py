@@ -55,3 +55,40 @@ def test_product_has_no_oracle_dependency():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "raster_oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_key_area_sizing_and_retry_capacity():
+    """Host logic of the single-pass binning (no GPU): fs_raster_buffer_sizes sizes the scratch as one fixed key area per
+    tile -- tile_capacity(cap, T) = the power of two >= max(2048, 4 cap / T), bounded so that T * tile_capacity indexes
+    in 32 bits -- and rasterizer.retry_capacity(instances, largest tile list, H, W) returns a capacity whose key areas
+    hold that list and whose saved lists hold the instances."""
+    import ctypes as C
+    import random
+    from freesplat_amd import _lib, rasterizer as R
+
+    def tile_capacity(cap, T):
+        want = (4 * max(cap, 1) + T - 1) // T
+        c = 2048
+        while c < want and c < (1 << 26):
+            c <<= 1
+        while c > 1 and c * T > 0xFFFFFFFF:
+            c >>= 1
+        return c
+
+    L = _lib.lib()
+    al = lambda x: (x + 255) // 256 * 256
+    rng = random.Random(3)
+    for _ in range(200):
+        H, W = rng.randint(1, 3000), rng.randint(1, 3000)
+        N = rng.randint(0, 2_000_000)
+        cap = rng.choice([1, 64, 5000, 1 << 20, 8 * max(N, 1), rng.randint(1, 1 << 28)])
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        out = (C.c_size_t * 4)()
+        assert L.fs_raster_buffer_sizes(N, H, W, cap, out) == 0
+        tc = tile_capacity(cap, T)
+        assert out[3] == al(T * 4) + al(T * tc * 8), (H, W, cap)
+        assert out[1] == al((T + 1) * 4) + al(max(cap, 1) * 4)
+        n_inst, max_tile = rng.randint(1, 1 << 24), rng.randint(1, 1 << 16)
+        cap2 = R.retry_capacity(n_inst, max_tile, H, W)
+        assert cap2 >= n_inst and (tile_capacity(cap2, T) >= max_tile or tile_capacity(cap2, T) * T * 2 > 0xFFFFFFFF)
+    assert L.fs_abi_version() == _lib.ABI_VERSION
