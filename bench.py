@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--min-time", type=float, default=0.6,
                     help="repeat the timed region of `--steps` steps until this many seconds have been timed; the median "
                          "region is reported (0: one region)")
+    ap.add_argument("--gather-dtype", default="fp32", choices=["fp32", "fp16", "uint8"],
+                    help="N>1: element type of the gathered images.  fp32 (default) = what the decoder returns; fp16 / uint8 "
+                         "(clamped to [0,1], x255, rounded) halve / quarter the bytes every GPU receives over its 7 xGMI links "
+                         "(241 MB per 16-view step and rank in fp32) for evaluation runs that end in 8-bit images anyway")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph capture / replay measurement")
@@ -151,7 +155,12 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                                         check="deferred")
             if gather is not None:
                 gather.wait()  # previous step's gather must be done before its buffers are dropped
-                gather.launch(torch.cat([color, depth], dim=1) if args.gather_depth else color)
+                payload = torch.cat([color, depth], dim=1) if args.gather_depth else color
+                if args.gather_dtype == "fp16":
+                    payload = payload.half()
+                elif args.gather_dtype == "uint8":
+                    payload = (payload.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8)
+                gather.launch(payload)
         return color, depth
 
     for attempt in range(2):
@@ -264,7 +273,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                              "inference instantiation (torch.no_grad: no n_contrib tracking, sorted lists stay in LDS; same image bits)"),
                    "instances_per_view": int(n_inst), "instances_per_gaussian": round(n_inst / max(N, 1), 2),
                    "parallelism": f"view-sharded x{world}" + (f" + {args.grad_exchange}(gaussian grads)" if exchange else
-                                                              (" + all_gather(color,depth)" if args.gather_depth else " + all_gather(color)") if gather else "")},
+                                                              (" + all_gather(color,depth)" if args.gather_depth else " + all_gather(color)")
+                                                              + ("" if args.gather_dtype == "fp32" else f"[{args.gather_dtype}]") if gather else "")},
     }
     if graph_views_per_s is not None:
         out["hipgraph_replay"] = {"value": graph_views_per_s, "unit": "views/s", "same_image_as_eager": graph_ok,
