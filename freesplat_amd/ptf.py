@@ -347,6 +347,12 @@ class _PtfFold(torch.autograd.Function):
         cnt = counts.tolist()                          # the only host sync of the fold
         cnt[0] = [P, 0, 0, P]
         n = cnt[V - 1][3]
+        # The steps were queued into WORST-CASE buffers ((i + 1) P rows of 86 floats each: O(V^2 P) in total, 2.4 GB at
+        # V = 8 and 384x512) because their sizes were still on the device.  Now that the counts are known, keep only the
+        # rows that exist (one copy of sum_i n_i rows, ~0.3 ms at 10 views): what the backward holds on to is O(V n).
+        for i in range(1, V):
+            states[i] = tuple(t[: cnt[i][3]].clone() for t in states[i])
+        state = states[V - 1]
         ctx.cnt, ctx.hw, ctx.states, ctx.scratches = cnt, (h, w), states, scratches
         ctx.tables, ctx.operand_stream = tables, operand_stream
         ctx.save_for_backward(lat, xs, rho, om, dep, Es, *params)

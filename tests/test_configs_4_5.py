@@ -82,14 +82,19 @@ def test_config4_cost_volume_at_its_real_size(hip_device):
 
 
 @pytest.mark.slow
-def test_config4_fold_at_its_real_size(hip_device):
+@pytest.mark.parametrize("V", [5, 10])
+def test_config4_fold_at_its_real_size(hip_device, V):
     """BASELINE config 4's fold at the size bench.py times it (`fold_10_views`: 10 views at 384x512 = 1.97 M raw
     Gaussians): same count, same ORDER (the appended / kept / fused layout of every step) and values within 1e-4 of the
-    reference-pinned oracle.  Minutes of host time: the oracle folds step by step in numpy / torch CPU."""
+    reference-pinned oracle.  The oracle folds step by step in numpy / torch CPU: 2.5 - 5 minutes of host time for the 10
+    views (the later steps fold into a larger state), so the default suite runs the first 5 views of the same scene and the
+    full fold runs with FREESPLAT_SLOW_TESTS=1 (passed in round 3: profiles/r3_gpu_tests.log)."""
+    if V == 10 and os.environ.get("FREESPLAT_SLOW_TESTS") != "1":
+        pytest.skip("10-view oracle fold: minutes of host time; set FREESPLAT_SLOW_TESTS=1")
     from oracle import ptf_oracle as po
     from freesplat_amd.ptf import PixelwiseTripletFusion
     from test_ptf_hip import _scene
-    V, h, w = 10, 384, 512
+    h, w = 384, 512
     E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=5)          # (bench_encoder.bench_ptf's scene)
     torch.manual_seed(1)
     m = PixelwiseTripletFusion()
