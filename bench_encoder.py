@@ -169,8 +169,10 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
         nv = V if cpu_steps is None else min(V, cpu_steps + 1)
         with torch.no_grad():
             t0 = time.perf_counter()
+            # (both sides project with the same world-to-camera matrices -- the product's GPU inverse: see
+            #  tests/test_configs_4_5.py::test_config4_fold_at_its_real_size)
             ref = po.fuse_gaussians(params, lat[:, :nv], coords[:, :nv], dens[:, :nv], wts[:, :nv], depths[:nv], E[None, :nv],
-                                    Kn[None, :nv], (h, w))
+                                    Kn[None, :nv], (h, w), w2c_all=torch.linalg.inv_ex(E[:nv].to(dev)).inverse.cpu())
             t_cpu = time.perf_counter() - t0
             got = out if nv == V else [x.cpu() for x in m.fuse_gaussians([a[0][0][:, :nv]], [a[1][0][:, :nv]], a[2][:, :nv], a[3][:, :nv],
                                                                          a[4][:nv], a[5][:, :nv], a[6][:, :nv], (h, w))]

@@ -72,7 +72,8 @@ def gru(p: dict, x: Tensor, hid: Tensor, xe: Tensor, he: Tensor) -> Tensor:
 
 
 def fuse_gaussians(gru_params: dict, latents: Tensor, coords: Tensor, densities: Tensor, weights: Tensor,
-                   depths: Tensor, extrinsics: Tensor, intrinsics: Tensor, image_shape, depth_thres: float = 0.1):
+                   depths: Tensor, extrinsics: Tensor, intrinsics: Tensor, image_shape, depth_thres: float = 0.1,
+                   w2c_all: Tensor | None = None):
     """latents [1,V,P,64], coords [1,V,P,1,1,3], densities/weights [1,V,P,1,1], depths [V,1,h,w],
     extrinsics [1,V,4,4] (or [V,4,4]), intrinsics [1,V,3,3] normalised.
     Returns (latent [1,M,64], xyz [1,M,3], extrinsics [1,M,4,4], depths [1,M]) -- encoder_freesplat.py:522."""
@@ -94,7 +95,10 @@ def fuse_gaussians(gru_params: dict, latents: Tensor, coords: Tensor, densities:
         K[:1] *= w                                                            # :446-447
         K[1:2] *= h
         kpix = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]], f32)
-        w2c = torch.linalg.inv(E[i]).numpy()
+        # (the reference: `extrinsic.inverse()`, encoder_freesplat.py:455.  `w2c_all` [V,4,4]: use these inverses instead --
+        #  a pixel's round-half-even decision can hinge on the last bit of the matrix, and the LU inverse of a host LAPACK
+        #  and of the GPU's solver differ there; full-size tests hand both sides the same matrices)
+        w2c = (torch.linalg.inv(E[i]) if w2c_all is None else w2c_all[i]).numpy()
         keep, fuse, fpix, app = (torch.from_numpy(a) for a in
                                  match_step(X.detach().numpy(), w2c, kpix, d[i].detach().numpy(), h, w, depth_thres))
         if fuse.numel() > 0:                                                  # :484

@@ -106,8 +106,13 @@ def test_config4_fold_at_its_real_size(hip_device, V):
     with torch.no_grad():
         out = [x.cpu() for x in mg.fuse_gaussians([d(lat)], [d(coords)], d(dens), d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))]
     torch.set_num_threads(os.cpu_count() or 1)
+    # Both sides round their pixels from the SAME world-to-camera matrices (the product's: torch's batched inverse on the
+    # GPU): at ~10^6 projections per step one of them lands within an ulp of a rounding boundary, and the host LAPACK's
+    # inverse differs from the GPU solver's in the last bit (5 views of this scene: 325 619 vs 325 618 Gaussians).  What
+    # is under test is the fold, not the two LU implementations.
+    w2c = torch.linalg.inv_ex(E.to(hip_device)).inverse.cpu()
     with torch.no_grad():
-        ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w))
+        ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w), w2c_all=w2c)
     assert out[0].shape == ref[0].shape and out[0].shape[1] < V * h * w        # same count; something fused
     for a, b, name in zip(out, ref, ("latent", "xyz", "extrinsics", "depths")):
         assert a.shape == b.shape, name
