@@ -49,11 +49,13 @@ __device__ __forceinline__ float row_sum(float v)
 // halving level puts a's sums into the lower half and b's into the upper half (swap_add32), the second leaves
 // values 0..4 in the even row and 5..9 in the odd row of each half (swap_add16: five registers, each lane of row r holding
 // a partial of value 5*(r&1)+k of survivor r>>1 in register k); inside the rows the five registers are merged PAIRWISE on
-// the way down (round 3): at the rotate-by-8 level lanes with bit 3 clear keep register X and lanes with bit 3 set
-// register Y (own = bit ? Y : X, and what is rotated in is the other choice, bit ? X : Y, so each lane adds its own
-// value's partner), likewise at the rotate-by-4 and rotate-by-2 levels -- 5 -> 3 -> 2 -> 1 registers, 15 instructions
-// instead of 4 rotate-adds on each of 5 registers.  The result is ONE register: lane (row r, column c) holds value
-// 5*(r&1) + kcomp(c) of survivor r>>1, kcomp(c) = c & 2 ? 4 : 2*((c>>2)&1) + (c>>3), valid in the columns {0, 8, 4, 12, 2}.
+// the way (round 3): a rotate-by-2^b level sends lane i the value of lane i -+ 2^b, which differs from i in bit b and in
+// no LOWER bit -- so going from the smallest rotation to the largest, the lanes with bit b clear keep register X and the
+// lanes with bit b set register Y (own = bit ? Y : X, and what is rotated in is the other choice, bit ? X : Y: each lane
+// receives its own value's partial from a lane that kept the other one), and every earlier choice (bits < b) agrees
+// between the two lanes.  Rotate by 1, 2, 4: 5 -> 3 -> 2 -> 1 registers; rotate by 8: a plain add.  15 instructions instead
+// of 4 rotate-adds on each of 5 registers, and the result is ONE register: lane (row r, column c < 5) holds value
+// 5*(r&1) + c of survivor r>>1 (column bits 0, 1 pick among values 0..3, bit 2 picks value 4).
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v)
 {
@@ -72,10 +74,10 @@ __device__ __forceinline__ float wave_sum_pair(const float (&va)[10], const floa
     for (int k = 0; k < 10; ++k) h[k] = swap_add32(va[k], vb[k]);
 #pragma unroll
     for (int k = 0; k < 5; ++k) t[k] = swap_add16(h[k], h[5 + k]);
-    constexpr unsigned long long kBit3 = 0xFF00FF00FF00FF00ull, kBit2 = 0xF0F0F0F0F0F0F0F0ull, kBit1 = 0xCCCCCCCCCCCCCCCCull;
-    const float u0 = row_merge<0x128>(t[0], t[1], kBit3), u1 = row_merge<0x128>(t[2], t[3], kBit3), u2 = row_add<0x128>(t[4]);
-    const float w0 = row_merge<0x124>(u0, u1, kBit2), w1 = row_add<0x124>(u2);
-    return row_add<0x121>(row_merge<0x122>(w0, w1, kBit1));
+    constexpr unsigned long long kBit0 = 0xAAAAAAAAAAAAAAAAull, kBit1 = 0xCCCCCCCCCCCCCCCCull, kBit2 = 0xF0F0F0F0F0F0F0F0ull;
+    const float u0 = row_merge<0x121>(t[0], t[1], kBit0), u1 = row_merge<0x121>(t[2], t[3], kBit0), u2 = row_add<0x121>(t[4]);   // row_ror:1
+    const float w0 = row_merge<0x122>(u0, u1, kBit1), w1 = row_add<0x122>(u2);                                                    // row_ror:2
+    return row_add<0x128>(row_merge<0x124>(w0, w1, kBit2));                                                                       // row_ror:4, then 8
 }
 
 constexpr int kBwdQuads = 7;  // float4 per slot of two survivors
@@ -135,8 +137,6 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
     float T_ = Tf;
     f32x2 R01 = splat2(0.0f), R23 = splat2(0.0f);
     const int row = lane >> 4, col = lane & 15;
-    const bool flush_lane = col == 2 || (col & 3) == 0;
-    const int flush_comp = 5 * (row & 1) + ((col & 2) ? 4 : 2 * ((col >> 2) & 1) + (col >> 3));
     float4* const cp = s_pair;
 
     // One pair of survivors (a further back, b in front of it): recompute, recurrences, partials, wavefront sums, flush.
@@ -208,12 +208,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
         va[0] = wdx.x; va[1] = wdy.x; va[2] = sxx.x; va[3] = sxy.x; va[4] = syy.x; va[5] = v_op.x;
         vb[0] = wdx.y; vb[1] = wdy.y; vb[2] = sxx.y; vb[3] = sxy.y; vb[4] = syy.y; vb[5] = v_op.y;
         const float v = wave_sum_pair(va, vb);
-        // row r of the wavefront: components 5*(r&1) .. +4 of survivor (r >> 1); the lanes of columns {0, 8, 4, 12, 2} flush
-        // component kcomp (wave_sum_pair)
+        // row r of the wavefront: components 5*(r&1) .. +4 of survivor (r >> 1); lane (r, c < 5) flushes component c
         const float4 ids = q[6];
-        if (flush_lane) {
+        if (col < 5) {
             const uint32_t id = __float_as_uint(row < 2 ? ids.x : ids.y);
-            if (v != 0.0f) atomicAdd(&grad[(size_t)id * kGradStride + flush_comp], v);
+            if (v != 0.0f) atomicAdd(&grad[(size_t)id * kGradStride + 5 * (row & 1) + col], v);
         }
     };
 
