@@ -157,6 +157,37 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
     return torch.stack(images), torch.stack(depths)
 
 
+def depth_to_relative_disparity(depth: Tensor, near: Tensor, far: Tensor, eps: float = 1e-10) -> Tensor:
+    """src/model/encoder/epipolar/conversions.py:17-27: 0 at near, 1 at far."""
+    disp_near, disp_far, disp = 1 / (near + eps), 1 / (far + eps), 1 / (depth + eps)
+    return 1 - (disp - disp_far) / (disp_near - disp_far + eps)
+
+
+def render_depth_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple[int, int],
+                      gaussian_means: Tensor, gaussian_covariances: Tensor, gaussian_opacities: Tensor,
+                      scale_invariant: bool = True, mode: str = "depth") -> Tensor:
+    """Drop-in for cuda_splatting.py:238-280 (dead code in the reference's own forward, decoder_splatting_cuda.py:66-73, kept
+    for callers of it): the camera-space depth of every Gaussian -- or its disparity / relative disparity / log,
+    `mode` -- rendered as a pre-computed colour (`colors_precomp` path of the rasterizer, black background) and averaged
+    over the three channels.  [B,4,4] ... -> [B,H,W]."""
+    homog = torch.cat([gaussian_means, torch.ones_like(gaussian_means[..., :1])], dim=-1)
+    fake = torch.einsum("bij,bgj->bgi", torch.linalg.inv_ex(extrinsics).inverse, homog)[..., 2]
+    if mode == "disparity":
+        fake = 1 / fake
+    elif mode == "relative_disparity":
+        fake = depth_to_relative_disparity(fake, near[:, None], far[:, None])
+    elif mode == "log":
+        fake = fake.minimum(near[:, None]).maximum(far[:, None]).log()      # (the reference's own clamp order, :262)
+    elif mode != "depth":
+        raise ValueError(f"unknown depth rendering mode {mode!r}")
+    b = fake.shape[0]
+    result, _ = render_cuda(extrinsics, intrinsics, near, far, image_shape,
+                            torch.zeros((b, 3), dtype=fake.dtype, device=fake.device), gaussian_means, gaussian_covariances,
+                            fake[..., None, None].expand(*fake.shape, 3, 1), gaussian_opacities,
+                            scale_invariant=scale_invariant, use_sh=False)
+    return result.mean(dim=1)
+
+
 # ---------------------------------------------------------------------------------------------
 # Batched multi-view path (SURVEY.md 8(f) N1): one shared Gaussian set, v views, one sync.
 # ---------------------------------------------------------------------------------------------
@@ -465,6 +496,16 @@ class DecoderSplattingCUDA(nn.Module):
             depth = depth.reshape(b, v, *depth.shape[1:]).squeeze(2)
         depth = depth / 2  # decoder_splatting_cuda.py:62
         return DecoderOutput(color, None if depth_mode is None else depth)
+
+    def render_depth(self, gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                     image_shape: tuple[int, int], mode: str = "depth") -> Tensor:
+        """decoder_splatting_cuda.py:77-100: [b,v,...] cameras, one Gaussian set per scene -> [b,v,h,w]."""
+        b, v = extrinsics.shape[:2]
+        rep = lambda t: t[:, None].expand(b, v, *t.shape[1:]).reshape(b * v, *t.shape[1:])
+        result = render_depth_cuda(extrinsics.reshape(b * v, 4, 4), intrinsics.reshape(b * v, 3, 3), near.reshape(b * v),
+                                   far.reshape(b * v), image_shape, rep(gaussians.means), rep(gaussians.covariances),
+                                   rep(gaussians.opacities), mode=mode)
+        return result.reshape(b, v, *result.shape[1:])
 
     def _forward_sharded(self, group, dist, gaussians, extrinsics, intrinsics, near, far, image_shape, with_depth=True):
         """View-sharded rendering of every scene of the batch: no collective on the render

@@ -286,6 +286,39 @@ def test_deferred_overflow_backward_is_safe(hip_device, monkeypatch):
         check_deferred()
 
 
+@pytest.mark.parametrize("mode", ["depth", "disparity", "relative_disparity", "log"])
+def test_render_depth_cuda(hip_device, mode):
+    """render_depth_cuda / DecoderSplattingCUDA.render_depth (cuda_splatting.py:238-280, decoder_splatting_cuda.py:77-100):
+    the per-Gaussian camera-space depth (or its transform) rendered as a pre-computed colour == the oracle rasterizing
+    the same colours."""
+    from freesplat_amd.decoder import DecoderSplattingCUDA, Gaussians, depth_to_relative_disparity, render_depth_cuda
+    H, W, v = 48, 64, 2
+    scene, cams = small_scene(N=900, H=H, W=W, seed=33, n_views=v)
+    dev = hip_device
+    cam = {k: t.to(dev) for k, t in cams.items()}
+    rep = lambda t: t.to(dev)[None].expand(v, *t.shape).contiguous()
+    out = render_depth_cuda(cam["extrinsics"], cam["intrinsics"], cam["near"], cam["far"], (H, W), rep(scene["means"]),
+                            rep(scene["covariances"]), rep(scene["opacities"]), mode=mode)
+    assert out.shape == (v, H, W)
+    for i in range(v):
+        vi = view_inputs(scene, cams, i, H, W)
+        homog = torch.cat([scene["means"], torch.ones(scene["means"].shape[0], 1)], -1)
+        z = (torch.linalg.inv(cams["extrinsics"][i]) @ homog.T)[2]
+        n, f = cams["near"][i], cams["far"][i]
+        fake = {"depth": z, "disparity": 1 / z, "relative_disparity": depth_to_relative_disparity(z, n, f),
+                "log": z.minimum(n).maximum(f).log()}[mode]
+        vi["colors_precomp"] = fake[:, None].expand(-1, 3).contiguous()
+        vi["shs"] = None
+        st = oracle_forward(vi)
+        ref = st["color"].mean(axis=0)
+        assert np.abs(out[i].cpu().numpy() - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), (mode, i)
+    dec = DecoderSplattingCUDA(None, None).to(dev)
+    g = Gaussians(scene["means"].to(dev)[None], scene["covariances"].to(dev)[None], scene["harmonics"].to(dev)[None],
+                  scene["opacities"].to(dev)[None])
+    d2 = dec.render_depth(g, cam["extrinsics"][None], cam["intrinsics"][None], cam["near"][None], cam["far"][None], (H, W), mode)
+    assert d2.shape == (1, v, H, W) and torch.equal(d2[0], out)
+
+
 def test_empty_inputs_forward_backward(hip_device):
     """N == 0 (torch hands out NULL data pointers) and v == 0: background image, empty gradients, no error."""
     from freesplat_amd.decoder import render_views
