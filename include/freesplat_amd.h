@@ -99,7 +99,9 @@ typedef struct fs_raster_dims {
 #define FS_RASTER_FAST_EXP 16
 /* Inference: the caller will not run fs_raster_backward on this forward.  The blend does not track the per-pixel
  * contributor count (n_contrib of the image buffer is left unwritten; colour / depth / alpha / final_T are the same
- * bits); fs_raster_backward(_views) refuses dims that carry the flag. */
+ * bits) and a tile's sorted list stays in LDS instead of being written to `binning` (only the tile ranges are, and the
+ * lists of tiles with more than 2048 entries, which are sorted through global memory -- `binning` must still be a buffer
+ * of the size fs_raster_buffer_sizes reports); fs_raster_backward(_views) refuses dims that carry the flag. */
 #define FS_RASTER_NO_BACKWARD_STATE 32
 
 /* Byte sizes of the four caller-owned device buffers for (N, H, W, instance capacity):
