@@ -105,8 +105,8 @@ def _same(a, b, path=""):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
-@pytest.mark.parametrize("V,num_views,with_gt", [(3, 3, False), (4, 3, True)])
-def test_encoder_forward_equals_reference_forward(V, num_views, with_gt):
+@pytest.mark.parametrize("V,num_views,with_gt,b", [(3, 3, False, 1), (4, 3, True, 1), (2, 2, False, 2)])
+def test_encoder_forward_equals_reference_forward(V, num_views, with_gt, b):
     """freesplat_amd.encoder_forward (bound as EncoderFreeSplat.forward by patch_reference) against the reference's own
     forward (encoder_freesplat.py:190-429) on the SAME, unpatched reference sub-modules (CPU): every entry of the two
     result dictionaries is identical -- the glue is the only thing that differs.  V > num_views exercises the
@@ -132,13 +132,13 @@ def test_encoder_forward_equals_reference_forward(V, num_views, with_gt):
     torch.manual_seed(0)
     enc = EncoderFreeSplat(cfg)
     assert type(enc).forward is not encoder_forward
-    E, Kn = inputs.cameras(V, h // 4, w // 4, baseline=0.3, seed=3)
-    ctx = {"image": torch.rand(1, V, 3, h, w), "extrinsics": E[None], "intrinsics": Kn[None],
-           "near": torch.full((1, V), 0.5), "far": torch.full((1, V), 15.0)}
+    cams = [inputs.cameras(V, h // 4, w // 4, baseline=0.3, seed=3 + i) for i in range(b)]      # b scenes (b > 1: the per-scene loops)
+    ctx = {"image": torch.rand(b, V, 3, h, w), "extrinsics": torch.stack([c[0] for c in cams]),
+           "intrinsics": torch.stack([c[1] for c in cams]), "near": torch.full((b, V), 0.5), "far": torch.full((b, V), 15.0)}
     if with_gt:
-        ctx["depth_s-1"] = 3.0 * torch.rand(1, V, 1, h, w)
+        ctx["depth_s-1"] = 3.0 * torch.rand(b, V, 1, h, w)
         for s in range(4):
-            ctx[f"depth_s{s}"] = 3.0 * torch.rand(1, V, 1, h >> (s + 1), w >> (s + 1))
+            ctx[f"depth_s{s}"] = 3.0 * torch.rand(b, V, 1, h >> (s + 1), w >> (s + 1))
     with torch.no_grad():
         ref = enc.forward(dict(ctx), 0)
         mine = encoder_forward(enc, dict(ctx), 0)
