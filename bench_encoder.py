@@ -121,6 +121,11 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
                          "traffic_unit": "HBM bytes per call (all current views)"}}, **extra)
 
 
+def _ptf_w2c(E):
+    from freesplat_amd.ptf import world_to_camera
+    return world_to_camera(E).view(-1, 4, 4).cpu()
+
+
 def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
     """`cpu_steps`: bound the CPU baseline to the fold of the first cpu_steps + 1 views (the later steps of a long fold
     are larger -- the state grows -- so scaling that time to all V - 1 steps UNDER-estimates the CPU time)."""
@@ -172,7 +177,7 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
             # (both sides project with the same world-to-camera matrices -- the product's GPU inverse: see
             #  tests/test_configs_4_5.py::test_config4_fold_at_its_real_size)
             ref = po.fuse_gaussians(params, lat[:, :nv], coords[:, :nv], dens[:, :nv], wts[:, :nv], depths[:nv], E[None, :nv],
-                                    Kn[None, :nv], (h, w), w2c_all=torch.linalg.inv_ex(E[:nv].to(dev)).inverse.cpu())
+                                    Kn[None, :nv], (h, w), w2c_all=_ptf_w2c(E[:nv].to(dev)))
             t_cpu = time.perf_counter() - t0
             got = out if nv == V else [x.cpu() for x in m.fuse_gaussians([a[0][0][:, :nv]], [a[1][0][:, :nv]], a[2][:, :nv], a[3][:, :nv],
                                                                          a[4][:nv], a[5][:, :nv], a[6][:, :nv], (h, w))]

@@ -88,6 +88,7 @@ SIGNATURES = {
     "fs_ptf_write_state_backward": (C.c_int, [C.c_int32] * 3 + [_VP] * 12 + [C.POINTER(C.c_void_p)] * 2 + [_VP] * 6),
     "fs_ptf_gru_inputs_backward": (C.c_int, [C.c_int32] + [_VP] * 14),
     "fs_frame_views": (C.c_int, [C.c_int32] + [_VP] * 4 + [C.c_int32] + [_VP] * 6),
+    "fs_invert_4x4": (C.c_int, [C.c_int32, _VP, _VP, _VP]),
     "fs_depth_tail_forward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 7),
     "fs_depth_tail_backward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 13),
     "fs_raster_tile_ranges": (_VP, [_VP, C.c_int32, C.c_int32]),

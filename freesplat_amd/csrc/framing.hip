@@ -100,9 +100,30 @@ __global__ void frame_views_kernel(int v, const float* __restrict__ extrinsics, 
         }
 }
 
+// n row-major 4x4 matrices -> their inverses (double precision inside, rounded once; NaN rows for a singular matrix)
+__global__ void invert4x4_kernel(int n, const float* __restrict__ src, float* __restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double m[16], o[16];
+    for (int k = 0; k < 16; ++k) m[k] = (double)src[16 * i + k];
+    const bool ok = inv4(m, o);
+    for (int k = 0; k < 16; ++k) dst[16 * i + k] = ok ? (float)o[k] : __builtin_nanf("");
+}
+
 }  // namespace fs
 
 using namespace fs;
+
+FS_API int fs_invert_4x4(int32_t n, const float* src, float* dst, void* stream_)
+{
+    if (n < 0) return FS_ERR_INVALID_ARG;
+    if (n == 0) return FS_OK;
+    if (!src || !dst) return FS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(invert4x4_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream_, n, src, dst);
+    FS_CHECK_LAUNCH("invert_4x4");
+    return FS_OK;
+}
 
 FS_API int fs_frame_views(int32_t v, const float* extrinsics, const float* intrinsics, const float* near,
                           const float* far, int32_t scale_invariant, float* view, float* full, float* campos,

@@ -253,6 +253,23 @@ def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tens
     return dcat, grads
 
 
+_fold_scratch: dict = {}       # (device, V, h, w) -> the inference fold's internal scratch
+
+
+def world_to_camera(Es: Tensor) -> Tensor:
+    """[V,16] (or [V,4,4]) camera-to-world extrinsics -> [V,16] world-to-camera matrices, one launch (fs_invert_4x4: double
+    precision inside, rounded once).  The reference calls `extrinsic.inverse()` per view (encoder_freesplat.py:455);
+    torch's batched LU inverse costs ~0.11 ms of HOST time per fold -- a third of a 2-view call, which is host-bound.
+    A pixel's round-half-even decision can hinge on the last bit of this matrix (about one in 10^6 projections): any
+    two inverses -- the reference's cuSOLVER LU, a host LAPACK, this one -- agree to an ulp, not to the bit, which is why
+    the full-size parity tests hand the oracle THESE matrices (tests/test_configs_4_5.py)."""
+    V = Es.shape[0]
+    src = Es.reshape(V, 16).contiguous()
+    out = torch.empty_like(src)
+    _lib.check(_lib.lib().fs_invert_4x4(V, _lib.ptr(src), _lib.ptr(out), _lib.current_stream()), "fs_invert_4x4")
+    return out
+
+
 def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
                           depth_thres):
     """Inference path (no autograd): ONE library call (fs_ptf_fold) folds all views -- per view match -> GRU inputs ->
@@ -278,12 +295,27 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
     # the state after view 0 is view 0 itself; fs_ptf_fold folds views 1 .. V-1 into it, writing the successive states
     # alternately into two sets of buffers -- one library call (camera constants included), one host sync afterwards
     Kn = f(intrinsics[0]).reshape(V, 9)
-    w2c = torch.linalg.inv_ex(Es.view(V, 4, 4)).inverse.reshape(V, 16).contiguous()   # (the reference's own inverse)
+    w2c = world_to_camera(Es)
     rows = 2 * P if V == 2 else V * P
-    bufs = [[torch.empty(rows, n, device=dev) for n in (64, 3, 1, 1, 16, 1)] for _ in range(1 if V == 2 else 2)]
+    # the call is HOST-bound at two views (0.19 ms of kernels): one allocation for the state buffers (carved into the six
+    # arrays of each set) instead of 6 - 12, and the fold's internal scratch is kept per (device, V, h, w) -- it is dead
+    # when the call returns (the count read-back below waits for the fold)
+    widths = (64, 3, 1, 1, 16, 1)
+    n_sets = 1 if V == 2 else 2
+    big = torch.empty(n_sets * rows * sum(widths), device=dev)
+    bufs, off = [], 0
+    for _ in range(n_sets):
+        one = []
+        for n_ in widths:
+            one.append(big[off: off + rows * n_].view(rows, n_))
+            off += rows * n_
+        bufs.append(one)
     ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in b]) for b in bufs]
     counts = torch.empty(V, 4, dtype=torch.int32, device=dev)
-    scratch = torch.empty(L.fs_ptf_fold_bytes(V, h, w), dtype=torch.uint8, device=dev)
+    key = (str(dev), V, h, w)
+    scratch = _fold_scratch.get(key)
+    if scratch is None:
+        scratch = _fold_scratch[key] = torch.empty(L.fs_ptf_fold_bytes(V, h, w), dtype=torch.uint8, device=dev)
     _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), p(w2c), p(Kn), C.c_float(depth_thres),
                              p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts), _lib.current_stream()), "fs_ptf_fold")
     global LAST_FOLD_COUNTS
@@ -322,7 +354,7 @@ class _PtfFold(torch.autograd.Function):
         p = _lib.ptr
         V, P = lat.shape[0], lat.shape[1]
         dev = lat.device
-        w2c = torch.linalg.inv_ex(Es.view(V, 4, 4)).inverse.reshape(V, 16).contiguous()   # (the reference's own inverse)
+        w2c = world_to_camera(Es)
         kpix = (Kn.view(V, 3, 3)[:, [0, 1, 0, 1], [0, 1, 2, 2]] * torch.tensor([w, h, w, h], dtype=torch.float32, device=dev)).contiguous()
         E0 = Es[0].reshape(1, 16).repeat(P, 1)
         counts = torch.empty(V, 4, dtype=torch.int32, device=dev)

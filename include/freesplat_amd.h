@@ -357,6 +357,11 @@ int fs_frame_views(int32_t v, const float* extrinsics, const float* intrinsics, 
                    const float* far, int32_t scale_invariant, float* view, float* full, float* campos,
                    float* tanfov, float* scale, void* stream);
 
+/* n row-major 4x4 matrices -> their inverses in ONE launch (double precision inside, each entry rounded once to fp32; a
+ * singular matrix gives NaNs).  The world-to-camera matrices of the PTF fold (`extrinsic.inverse()`,
+ * encoder_freesplat.py:455): torch's batched LU inverse costs ~0.11 ms of host time per fold, a third of a 2-view call. */
+int fs_invert_4x4(int32_t n, const float* src, float* dst, void* stream);
+
 /* ------------------------------------------------------------------------------------ *
  * Depth-regression tail of the DepthDecoder (networks.py:130-152)                       *
  * ------------------------------------------------------------------------------------ */

@@ -3,7 +3,7 @@ device ops on the HIP index lists (fs_ptf_match), differentiable through autogra
 (freesplat_amd.ptf.fuse_gaussians) runs the fold and its backward on the HIP kernels; this formulation only checks them."""
 import torch
 
-from freesplat_amd.ptf import match_view, positional_encoding
+from freesplat_amd.ptf import match_view, positional_encoding, world_to_camera
 
 
 def fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
@@ -25,7 +25,7 @@ def fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths,
         K[:1, :] *= w
         K[1:2, :] *= h
         kpix = torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
-        w2c = torch.linalg.inv_ex(extrinsic).inverse
+        w2c = world_to_camera(extrinsic[None]).view(4, 4)      # (the product's own matrices: ptf.world_to_camera)
         keep, fuse, fpix, app = match_view(X[0], w2c, kpix, depths[i], h, w, depth_thres)
         if fuse.numel() > 0:
             xe = positional_encoding(torch.cat([R[:, fuse], weight_emb[:, i, fpix]], dim=-1), 6)

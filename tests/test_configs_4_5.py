@@ -110,7 +110,8 @@ def test_config4_fold_at_its_real_size(hip_device, V):
     # GPU): at ~10^6 projections per step one of them lands within an ulp of a rounding boundary, and the host LAPACK's
     # inverse differs from the GPU solver's in the last bit (5 views of this scene: 325 619 vs 325 618 Gaussians).  What
     # is under test is the fold, not the two LU implementations.
-    w2c = torch.linalg.inv_ex(E.to(hip_device)).inverse.cpu()
+    from freesplat_amd.ptf import world_to_camera
+    w2c = world_to_camera(E.to(hip_device)).view(-1, 4, 4).cpu()
     with torch.no_grad():
         ref = po.fuse_gaussians(params, lat, coords, dens, wts, depths, E[None], Kn[None], (h, w), w2c_all=w2c)
     assert out[0].shape == ref[0].shape and out[0].shape[1] < V * h * w        # same count; something fused
