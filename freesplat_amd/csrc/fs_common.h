@@ -308,7 +308,7 @@ __host__ __device__ inline GeomView geom_view(void* base, int N)
     g.clamp = (uint8_t*)p;
     return g;
 }
-// Tile -> workgroup order of the per-tile kernels (tile_sort, render, render_bwd).  Workgroup b runs on XCD b % 8
+// Tile -> workgroup order of the per-tile kernels (sort_blend, render_bwd).  Workgroup b runs on XCD b % 8
 // (hardware round-robin).  Tiles are grouped in 4x4 super-tiles -- neighbouring tiles share most of their
 // Gaussians, so their records stay in one L2 -- and super-tile s goes to XCD s % 8: every XCD gets super-tiles
 // from all over the image.  (One contiguous band of tiles per XCD left the XCDs up to 25 % apart in work and

@@ -81,7 +81,7 @@ __device__ __forceinline__ float wave_sum_pair(const float (&va)[10], const floa
 }
 
 constexpr int kBwdQuads = 7;  // float4 per slot of two survivors
-// Backward blend loop, same organisation as the forward (raster_fwd.hip:render_kernel): one single-wavefront
+// Backward blend loop, same organisation as the forward (raster_fwd.hip:blend_quadrant): one single-wavefront
 // workgroup per 8x8 quadrant, no barriers; the tile list is walked BACK TO FRONT 64 entries at a time with the
 // records of the next batch in flight; the survivors of a batch are compacted (highest list position first) two per
 // LDS slot with interleaved fields, so exponent, exp, alpha and all per-Gaussian derivative terms of both run on

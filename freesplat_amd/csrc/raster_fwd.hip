@@ -85,7 +85,7 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__
 
 
 // ------------------------------------------------------------------------------------------
-// Tile binning helpers shared by the count (preprocess) and emit passes.
+// Tile binning helpers of the projection kernel's count and key-writing passes.
 // ------------------------------------------------------------------------------------------
 constexpr int kBinLds = 4096;  // tiles of a workgroup's bounding box whose counters live in LDS
 
@@ -161,7 +161,7 @@ __device__ __forceinline__ uint32_t quad_mask_row(const RowBands& rb, const floa
 }
 
 // Quadrant masks of every tile of a (small) rect packed 4 bits per tile, row-major: computed once in
-// preprocess, reused by both phases of emit.  Per tile row the two 8-pixel bands give two u-intervals; instead of
+// the projection kernel, used by both of its binning passes.  Per tile row the two 8-pixel bands give two u-intervals; instead of
 // testing them against every quadrant column with float compares (28 VALU, 8 of them v_cmp, per tile), each interval is
 // turned ONCE into the range of 8-pixel cell columns it can touch -- a bit mask over the rect's <= 32 cells -- and a
 // tile's 4 bits are two 2-bit fields of those masks (7 integer ops).  Conservative like quad_mask_row (intervals
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------
-// tile_sort: per-tile sort by (depth bits, id).  Bitonic network in its "flip" form -- every
+// Per-tile sort by (depth bits, id) -- the networks behind the bucket sort: bitonic network in its "flip" form -- every
 // compare-exchange is ascending, so an arbitrary length n works in place: partners >= n are
 // virtual +inf and never move.
 // ------------------------------------------------------------------------------------------
