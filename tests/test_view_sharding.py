@@ -209,3 +209,30 @@ def test_gloo_world2_sharded_cost_volume(V, ncv):
     source views: reduce-scatter in backward) equal the unsharded ones.  Row compute = the reference-pinned oracle
     (the HIP kernel cannot run on CPU); V=5 with 3-nearest source selection covers ragged shards."""
     assert all(ok for _, ok in _run(2, _cv_worker, V, ncv))
+
+
+def _world3_worker(rank, world, port, q, n_views, N):
+    _init(rank, world, port)
+    try:
+        mine = shard_range(n_views, rank, world)
+        local = torch.stack([_fake_render(v) for v in mine]) if len(mine) else torch.zeros(0, 3, 6, 8)
+        expect = torch.stack([_fake_render(v) for v in range(n_views)])
+        ok = torch.equal(gather_views(local, n_views), expect)          # ragged: 4 views -> [2, 1, 1]; trimmed by block copies
+        g = torch.Generator().manual_seed(11 + rank)
+        grads = [torch.randn(N, 3, generator=g), torch.randn(N, 3, 9, generator=g), torch.randn(N, generator=g)]
+        for _ in range(2):                                              # second call reuses the bucket
+            shards = reduce_scatter_gaussian_grads([t.clone() for t in grads])
+            full = [t.clone() for t in grads]
+            allreduce_gaussian_grads(full)
+            rows = shard_range(N, rank, world)
+            ok = ok and all(torch.allclose(sh, fu[rows.start: rows.stop], atol=1e-6) for sh, fu in zip(shards, full))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_views,N", [(4, 9), (7, 10), (2, 2)])
+def test_gloo_world3_ragged_gather_and_bucket_packing(n_views, N):
+    """Three ranks: the trimmed all-gather of ragged view shards (more than one short shard), the reduce-scatter bucket with
+    evenly divisible rows (N = 9: one strided copy per tensor) and ragged ones (N = 10, N < world), and its reuse."""
+    assert all(ok for _, ok in _run(3, _world3_worker, n_views, N))
