@@ -8,8 +8,12 @@ other rows of the hot path under the same clock.
 
 A "step" renders `--views` target views (default 16) of the synthetic 1.0 M-Gaussian scene at
 968x1296 on every rank (weak scaling, view-sharded: rank r renders its own block of the N*views
-target cameras) and, for N>1, all-gathers the rendered colour+depth images over RCCL on a side
-stream, overlapped with the next step.  Inputs are resident in HBM before the timed region.
+target cameras) and, for N>1, all-gathers the rendered colour images (`--gather-depth`: + depth; `--gather-dtype
+fp32 | fp16 | uint8`) over RCCL on a side stream, overlapped with the next step.  Inputs are resident in HBM before the
+timed region.  The timed region is EXACTLY `--steps` steps between two barriers (max over ranks); at the default sizes it
+lasts ~80 ms, so it is repeated until `--min-time` (0.6 s) has been timed and the MEDIAN region is reported
+(`timed_regions_ms` lists them all).  `--single-rank-collectives` (under `torch.distributed.run --nproc-per-node 1`) takes
+the N>1 code path on RCCL with one rank.
 
 Rank 0 prints ONE JSON line.  Top level = the headline metric (forward rendering, config 3's size) with
 `roofline` (render kernel, HIP-event timed inside the timed region through the library's fs_profile_* hooks),
