@@ -595,23 +595,23 @@ __global__ __launch_bounds__(256) void cv_relayout_back_kernel(const float* __re
     }
 }
 
+// One source's bilinear gather for a (pixel, parity) lane: the 4 tap weights, validity and 32-bit texel indices (the scatter
+// of the gradient needs exactly those) and the blended half-record.
 template <int HC>
 struct SrcWarp {
     float wv[HC];
     float wt[4];
-    size_t off[4];
+    uint32_t tex[4];
     bool ok[4];
     float zz;
 };
 
 template <int HC>
-__device__ __forceinline__ void warp_source(SrcWarp<HC>& W, const float* __restrict__ srcT, int b, int k, int K,
-                                            int h, int w, int hf, bool live, float depth, float rx, float ry,
-                                            float rz, const float* __restrict__ Pmat, float inv_w, float inv_h)
+__device__ __forceinline__ void warp_source(SrcWarp<HC>& W, const float* __restrict__ map, int w, int h, int hf, bool live,
+                                             float depth, float rx, float ry, float rz, const float* __restrict__ P,
+                                             float inv_w, float inv_h)
 {
     constexpr int C = 2 * HC;
-    const int hw = h * w;
-    const float* P = Pmat + ((size_t)b * K + k) * 12;
     const float X = depth * rx, Y = depth * ry, Z = depth * rz;
     const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
     const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
@@ -629,15 +629,14 @@ __device__ __forceinline__ void warp_source(SrcWarp<HC>& W, const float* __restr
     const int x0 = xin0 || xin1 ? (int)fx0 : 0, y0 = yin0 || yin1 ? (int)fy0 : 0;
 #pragma unroll
     for (int s = 0; s < HC; ++s) W.wv[s] = 0.0f;
-    const size_t base = (((size_t)b * K + k) * hw) * C + (size_t)hf * HC;
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
         const int ox = tap & 1, oy = tap >> 1;
         W.ok[tap] = live && (ox ? xin1 : xin0) && (oy ? yin1 : yin0);
         W.wt[tap] = (ox ? tx : 1.0f - tx) * (oy ? ty : 1.0f - ty);
-        W.off[tap] = base + ((size_t)(y0 + oy) * w + (x0 + ox)) * C;
+        W.tex[tap] = W.ok[tap] ? (uint32_t)((y0 + oy) * w + (x0 + ox)) : 0u;
         if (W.ok[tap]) {
-            const float4* q = (const float4*)(srcT + W.off[tap]);
+            const float4* q = (const float4*)(map + (size_t)W.tex[tap] * C + hf * HC);
 #pragma unroll
             for (int s = 0; s < HC / 4; ++s) {
                 const float4 v = q[s];
@@ -655,8 +654,18 @@ __device__ __forceinline__ float dlrelu(float z) { return z > 0.0f ? 1.0f : 0.01
 __device__ __forceinline__ constexpr int row_reg(int i) { return (i & 3) + 4 * (i >> 3); }
 __device__ __forceinline__ constexpr int row_half(int i) { return (i >> 2) & 1; }
 
+// The backward sweep.  TWO wavefronts per SIMD (<= 256 registers, <= 80 KB of LDS per workgroup; the first version held
+// every MFMA operand in registers -- 484 of them, one wavefront per SIMD -- and left the SIMD idle during each wavefront's
+// gather latency and atomic walk: native fwd+bwd 2.30 -> 1.73 ms, the 10-view K = 8 shape 65 -> 47 ms):
+//   * the MLP's weights are not held as per-lane operand registers (121 of them) but read from an LDS copy as each MFMA
+//     needs its A operand: W1 as [32 units][XS] (columns 0..C-1 channels, C the dot feature, C+1 = b1, C+2 = 0; XS odd),
+//     W2 as [32][33] -- both row- and column-wise reads are conflict-free -- w3 and b2 as vectors;
+//   * b2's and w3's gradients are column sums over the points: of the dz2 tile that passes through LDS anyway (each lane
+//     adds the 16 entries of its unit that it reads as MFMA operands) and of a half-height tile of g * h2 (neighbouring
+//     pixels pre-added with one DPP step) -- two accumulators instead of 32, and z2 is dead as soon as it is computed;
+//   * dW2 and dW1 are accumulated in two phases that share the dz tile (dz2, then dz1); lrelu'(z1) is kept as a bit mask.
 template <int HC>
-__global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
+__global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
     int B, int K, int h, int w, int D, int slices, const float* __restrict__ curT, const float* __restrict__ srcT,
     const float* __restrict__ Pmat,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
@@ -669,43 +678,41 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     constexpr int C = 2 * HC;
     constexpr int NBLK = (HC + 1 + 15) / 16;  // row blocks of the permuted W1^T
     constexpr int XW = 2 * (HC + 1);          // features of a point: C channels, dot, 1
-    // wavefront-private LDS tile: [32 points][row] with odd row strides (33 / XS)
-    constexpr int XS = XW | 1, kTile1 = 32 * 33, kTileX = 32 * XS, kStage = 3 * kTile1 + kTileX;
+    constexpr int XS = XW | 1;                // odd row stride of the feature tile and of the W1 copy (column XW: zero)
+    constexpr int kTile1 = 32 * 33, kTileH = 16 * 33, kTileX = 32 * XS, kStage = 2 * kTile1 + kTileH + kTileX;
     constexpr int NCB = (XW + 31) / 32;       // column blocks of dW1
-    __shared__ float s_stage[4 * kStage];
+    constexpr int kW1 = 0, kW2 = 32 * XS, kW3 = kW2 + 32 * 33, kB2 = kW3 + 32, kWts = kB2 + 32;
+    static_assert((kWts + 4 * kStage) * 4 <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
+    static_assert((1 + NCB) * 16 * 64 <= kStage, "final weight-gradient staging exceeds the wavefront's LDS tile");
+    __shared__ float s_all[kWts + 4 * kStage];
     const int hw = h * w;
     const int groups = (hw + 31) / 32;
     const CvBlock blk_ = cv_block(B, groups, slices);
     if (!blk_.ok) return;   // (workgroup-uniform)
+    for (int e = threadIdx.x; e < 32 * XS; e += 256) {
+        const int u = e / XS, f = e - u * XS;
+        s_all[kW1 + e] = f <= C ? w1[u * (C + 1) + f] : (f == C + 1 ? b1[u] : 0.0f);
+    }
+    for (int e = threadIdx.x; e < 32 * 33; e += 256) {
+        const int u = e / 33, c = e - u * 33;
+        s_all[kW2 + e] = c < 32 ? w2[u * 32 + c] : 0.0f;
+    }
+    if (threadIdx.x < 32) { s_all[kW3 + threadIdx.x] = w3[threadIdx.x]; s_all[kB2 + threadIdx.x] = b2[threadIdx.x]; }
+    __syncthreads();
+    const float* const sW1 = s_all + kW1, * const sW2 = s_all + kW2, * const sW3 = s_all + kW3, * const sB2 = s_all + kB2;
     const int b = blk_.b, grp = blk_.grp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, hf = lane >> 5;
+    float* const stage = s_all + kWts + wave * kStage;
     const int pix = grp * 32 + p;
     const bool live = pix < hw;
     const int pu = live ? pix % w : 0, pv = live ? pix / w : 0;
-
-    float a1[HC + 1];
-#pragma unroll
-    for (int s = 0; s < HC; ++s) a1[s] = w1[p * (C + 1) + 2 * s + hf];
-    a1[HC] = hf ? b1[p] : w1[p * (C + 1) + C];
-    float a2[16], a2t[16], w3r[16], b2r[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        a2[s] = w2[p * 32 + acc_row(s, hf)];
-        a2t[s] = w2[acc_row(s, hf) * 32 + p];  // (W2^T)[i = p][k = unit acc_row(s, hf)]
-        w3r[s] = w3[acc_row(s, hf)];
-        b2r[s] = b2[acc_row(s, hf)];
-    }
-    // permuted W1^T: block blk, row i = p  ->  feature of slot sl = 16*blk + row_reg(p), parity row_half(p)
-    float a1t[NBLK][16];
+    // column of the W1 copy that row p of the permuted W1^T block `blk` reads (the zero column where it has no feature)
+    int tcol[NBLK];
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
         const int sl = 16 * blk + row_reg(p), ph = row_half(p);
-        int feat = -1;
-        if (sl < HC) feat = 2 * sl + ph;
-        else if (sl == HC && ph == 0) feat = C;  // the dot feature
-#pragma unroll
-        for (int s = 0; s < 16; ++s) a1t[blk][s] = feat >= 0 ? w1[acc_row(s, hf) * (C + 1) + feat] : 0.0f;
+        tcol[blk] = sl < HC ? 2 * sl + ph : (sl == HC && ph == 0 ? C : XW);
     }
 
     float cur[HC], dcur[HC];
@@ -727,9 +734,7 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
     const int dchunk = (D + slices * 4 - 1) / (slices * 4);
     const int d0 = min(D, (blk_.slice * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
-    float gw3r[16], gb2r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { gw3r[r] = 0.0f; gb2r[r] = 0.0f; }
+    float gw3a = 0.0f, gb2a = 0.0f;   // this lane's 16 points of unit p's sums (the other half holds the other 16)
     float gb3r = 0.0f;
     f32x16 gW2, gW1[NCB];   // dW2[unit acc_row(r,hf)][col p],  dW1[unit acc_row(r,hf)][feature 32 cb + p]
 #pragma unroll
@@ -746,56 +751,117 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
 
     for (int d = d0; d < d1; ++d) {
         FS_CV_T(tq0, rx);
+#ifdef FS_CV_TRACE
+        unsigned long long tq1 = 0;
+#endif
         const float depth = planes[b * ps_b + d * ps_d + (live ? pix : 0) * ps_p];
         const size_t pt = ((size_t)b * D + d) * hw + (live ? pix : 0);
         const float go = live ? g_out[pt] : 0.0f;
+        float* const tA = stage, * const tB = tA + kTile1, * const tC = tB + kTile1, * const tx = tC + kTileH;
         // ---- forward recompute ----
-        float favg[HC];
-#pragma unroll
-        for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
-        float dot_sum = 0.0f, cnt = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, Pmat, inv_w, inv_h);
-            float part = 0.0f;
-#pragma unroll
-            for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
-            float dotk = part + __shfl_xor(part, 32, 64);
-            dotk = (W.zz > 0.0f) ? dotk : 0.0f;
-            if (dotk != 0.0f) {
-                cnt += 1.0f;
-                dot_sum += dotk;
-#pragma unroll
-                for (int s = 0; s < HC; ++s) favg[s] += W.wv[s];
-            }
-        }
-        const float inv = 1.0f / (cnt + 1e-8f);
         f32x16 z1;
+        float inv, xlast;
+        {
+            float favg[HC];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z1[r] = 0.0f;
+            for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
+            float dot_sum = 0.0f, cnt = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                warp_source<HC>(W, srcT + (((size_t)b * K + k) * hw) * C, w, h, hf, live, depth, rx, ry, rz,
+                                 Pmat + ((size_t)b * K + k) * 12, inv_w, inv_h);
+                float part = 0.0f;
 #pragma unroll
-        for (int s = 0; s < HC; ++s) z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], favg[s] * inv, z1, 0, 0, 0);
-        const float xlast = hf ? 1.0f : dot_sum * inv;
-        z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[HC], xlast, z1, 0, 0, 0);
-        f32x16 z2;
+                for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
+                float dotk = part + __shfl_xor(part, 32, 64);
+                dotk = (W.zz > 0.0f) ? dotk : 0.0f;
+                if (dotk != 0.0f) {
+                    cnt += 1.0f;
+                    dot_sum += dotk;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z2[r] = b2r[r];
+                    for (int s = 0; s < HC; ++s) favg[s] += W.wv[s];
+                }
+            }
+            inv = 1.0f / (cnt + 1e-8f);
+            xlast = hf ? 1.0f : dot_sum * inv;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) z2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], lrelu(z1[s]), z2, 0, 0, 0);
-        FS_CV_T(tq1, z2[0] + z2[15]);
-        // ---- backward through the MLP ----
-        f32x16 dz2, dh1;
+            for (int r = 0; r < 16; ++r) z1[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < HC; ++s) {
+                const float x = favg[s] * inv;
+                tx[p * XS + 2 * s + hf] = x;      // the point's features for the dW1 products below
+                z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + 2 * s + hf], x, z1, 0, 0, 0);
+            }
+            tx[p * XS + C + hf] = xlast;
+            z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + C + hf], xlast, z1, 0, 0, 0);
+        }
+        // h1 replaces z1 (lrelu' survives as a bit per unit) and goes to its tile at once
+        uint32_t pos1 = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            gw3r[r] += go * lrelu(z2[r]);
-            dz2[r] = go * w3r[r] * dlrelu(z2[r]);
-            dh1[r] = 0.0f;
+            pos1 |= (z1[r] > 0.0f ? 1u : 0u) << r;
+            z1[r] = lrelu(z1[r]);
+            tB[p * 33 + acc_row(r, hf)] = z1[r];
+        }
+        const float lv = live ? 1.0f : 0.0f;   // points past the image contribute nothing
+        f32x16 dz2;
+        {
+            f32x16 z2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z2[r] = sB2[acc_row(r, hf)];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) z2 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW2[p * 33 + acc_row(s, hf)], z1[s], z2, 0, 0, 0);
+            FS_CV_T(tq1_, z2[0] + z2[15]);
+#ifdef FS_CV_TRACE
+            tq1 = tq1_;
+#endif
+            // ---- backward through the MLP; dW2 += dz2 (x) h1 (phase 1 of the LDS tiles) ----
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = acc_row(r, hf);
+                dz2[r] = go * sW3[u] * dlrelu(z2[r]);
+                tA[p * 33 + u] = dz2[r] * lv;
+                const float g = go * lrelu(z2[r]);   // (go = 0 past the image)
+                const float g2 = g + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g), 0xB1, 0xF, 0xF, true));   // + pixel p ^ 1
+                if ((p & 1) == 0) tC[(p >> 1) * 33 + u] = g2;
+            }
         }
         if (hf == 0) gb3r += go;
+        wave_lds_sync();
+        // k-step m contracts points 2m and 2m+1: A = dz[pt][unit = lane&31], B = x / h1 [pt][column = lane&31]
 #pragma unroll
-        for (int s = 0; s < 16; ++s) dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2t[s], dz2[s], dh1, 0, 0, 0);
+        for (int m = 0; m < 16; ++m) {
+            const int q = 2 * m + hf;
+            const float az2 = tA[q * 33 + p];
+            gb2a += az2;
+            gW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(az2, tB[q * 33 + p], gW2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) gw3a += tC[(8 * hf + m) * 33 + p];
         f32x16 dz1;
+        {
+            f32x16 dh1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dz1[r] = dh1[r] * dlrelu(z1[r]);
+            for (int r = 0; r < 16; ++r) dh1[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW2[acc_row(s, hf) * 33 + p], dz2[s], dh1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz1[r] = dh1[r] * ((pos1 >> r) & 1u ? 1.0f : 0.01f);
+        }
+        wave_lds_sync();   // (phase 1's reads are done)
+        // ---- phase 2: dW1 += dz1 (x) x ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tA[p * 33 + acc_row(r, hf)] = dz1[r] * lv;
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int q = 2 * m + hf;
+            const float az1 = tA[q * 33 + p];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float bx = (32 * cb + p < XW) ? tx[q * XS + 32 * cb + p] : 0.0f;
+                gW1[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(az1, bx, gW1[cb], 0, 0, 0);
+            }
+        }
         float dfavg[HC];
         float ddot = 0.0f;
 #pragma unroll
@@ -804,7 +870,7 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[r] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(a1t[blk][s], dz1[s], dx, 0, 0, 0);
+            for (int s = 0; s < 16; ++s) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[acc_row(s, hf) * XS + tcol[blk]], dz1[s], dx, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (16 * blk + r < HC) dfavg[16 * blk + r] = dx[r];
@@ -813,41 +879,13 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
         }
         ddot = __shfl(ddot, p, 64);  // both parities of the pixel need it
         FS_CV_T(tq2, ddot + dfavg[0]);
-        // ---- weight gradients: transpose this plane's factors through LDS, accumulate the outer products ----
-        {
-            float* tz1 = s_stage + wave * kStage, *tz2 = tz1 + kTile1, *th1 = tz2 + kTile1, *tx = th1 + kTile1;
-            const float lv = live ? 1.0f : 0.0f;   // points past the image contribute nothing
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int u = acc_row(r, hf);
-                tz1[p * 33 + u] = dz1[r] * lv;
-                tz2[p * 33 + u] = dz2[r] * lv;
-                th1[p * 33 + u] = lrelu(z1[r]);
-                gb2r[r] += dz2[r] * lv;
-            }
-#pragma unroll
-            for (int s = 0; s < HC; ++s) tx[p * XS + 2 * s + hf] = favg[s] * inv;
-            tx[p * XS + C + hf] = xlast;
-            wave_lds_sync();
-            // k-step m contracts points 2m and 2m+1: A = dz[pt][unit = lane&31], B = x / h1 [pt][column = lane&31]
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const int pt = 2 * m + hf;
-                const float az1 = tz1[pt * 33 + p], az2 = tz2[pt * 33 + p];
-                gW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(az2, th1[pt * 33 + p], gW2, 0, 0, 0);
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    const float bx = (32 * cb + p < XW) ? tx[pt * XS + 32 * cb + p] : 0.0f;
-                    gW1[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(az1, bx, gW1[cb], 0, 0, 0);
-                }
-            }
-            wave_lds_sync();   // (the next plane overwrites the tile)
-        }
+        wave_lds_sync();   // (the scatter staging below overwrites the tiles)
         FS_CV_T(tq3, gW2[0] + gW1[0][0]);
         // ---- back to the features ----
         for (int k = 0; k < K; ++k) {
             // (K = 1: W still holds this source from the forward recompute above -- no second gather)
-            if (K > 1) warp_source<HC>(W, srcT, b, k, K, h, w, hf, live, depth, rx, ry, rz, Pmat, inv_w, inv_h);
+            if (K > 1) warp_source<HC>(W, srcT + (((size_t)b * K + k) * hw) * C, w, h, hf, live, depth, rx, ry, rz,
+                                        Pmat + ((size_t)b * K + k) * 12, inv_w, inv_h);
             float part = 0.0f;
 #pragma unroll
             for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
@@ -855,30 +893,26 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
             const bool m = W.zz > 0.0f;
             const bool valid = m && dotk != 0.0f;
             const float cf = valid ? inv : 0.0f, cd = m ? inv * ddot : 0.0f;
-            float dwv[HC];
-#pragma unroll
-            for (int s = 0; s < HC; ++s) {
-                dwv[s] = cf * dfavg[s] + cd * cur[s];
-                dcur[s] += cd * W.wv[s];
-            }
             // Scatter to the source map, TRANSPOSED through the wavefront's LDS tile: with lane = pixel one atomic
             // instruction touched 64 different texel records (~40 cache lines, 4 bytes each); with lane = channel it
             // covers ONE texel's contiguous record (2 lines).  The L2 executes atomics per 64-byte request, so the
             // request count is what the 6e8 float atomics of a native call cost: 96 instructions x ~40 lines before,
             // 128 x 2 now, per (32-pixel group, plane, source).
             {
-                float* tD = s_stage + wave * kStage;                // [32 pixels][C slots]  (slot = parity * HC + s)
+                float* tD = stage;                                  // [32 pixels][C slots]  (slot = parity * HC + s)
                 float* tW = tD + 32 * C;                            // [32][4] tap weights (0: tap unused)
                 uint32_t* tO = (uint32_t*)(tW + 32 * 4);            // [32][4] texel index of the tap in the source map
                 static_assert(32 * C + 2 * 32 * 4 <= kStage, "scatter staging exceeds the wavefront's LDS tile");
 #pragma unroll
-                for (int s = 0; s < HC; ++s) tD[p * C + hf * HC + s] = dwv[s];
+                for (int s = 0; s < HC; ++s) {
+                    tD[p * C + hf * HC + s] = cf * dfavg[s] + cd * cur[s];
+                    dcur[s] += cd * W.wv[s];
+                }
                 if (hf == 0) {
-                    const size_t map0 = (((size_t)b * K + k) * hw) * C;
 #pragma unroll
                     for (int tap = 0; tap < 4; ++tap) {
                         tW[p * 4 + tap] = W.ok[tap] ? W.wt[tap] : 0.0f;
-                        tO[p * 4 + tap] = W.ok[tap] ? (uint32_t)((W.off[tap] - map0) / C) : 0u;
+                        tO[p * 4 + tap] = W.tex[tap];
                     }
                 }
                 wave_lds_sync();
@@ -930,7 +964,7 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
     }
 #endif
     {   // d cur: same transposition (one atomic instruction per pixel record instead of 24 over 64 scattered records)
-        float* tD = s_stage + wave * kStage;
+        float* tD = stage;
 #pragma unroll
         for (int s = 0; s < HC; ++s) tD[p * C + hf * HC + s] = live ? dcur[s] : 0.0f;
         wave_lds_sync();
@@ -940,42 +974,27 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_kernel(
             if (lane < C) atomicAdd(dst + (size_t)j * C + lane, tD[j * C + lane]);
         wave_lds_sync();
     }
-    // w3 / b3 gradients: reduce over the 32 pixels of each half, one atomic per unit per wavefront
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = gw3r[r];
-#pragma unroll
-        for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
-        if (p == 0) atomicAdd(&gw3[acc_row(r, hf)], v);
-    }
+    // w3 / b2: the two halves of the wavefront hold 16 points each of unit p's sums;  b3: sum over the pixels
     {
+        const float v3 = gw3a + __shfl_xor(gw3a, 32, 64), v2 = gb2a + __shfl_xor(gb2a, 32, 64);
+        if (hf == 0) { atomicAdd(&gw3[p], v3); atomicAdd(&gb2[p], v2); }
         float v = gb3r;
 #pragma unroll
         for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
         if (lane == 0) atomicAdd(gb3, v);
     }
-    // b2: sum over the 32 pixels of each half
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = gb2r[r];
-#pragma unroll
-        for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
-        if (p == 0) atomicAdd(&gb2[acc_row(r, hf)], v);
-    }
     // W1 (+ b1 = its "1" column) and W2: sum the workgroup's four wavefronts in LDS, one atomic per weight
     __syncthreads();
-    {
-        float* mine = s_stage + wave * kStage;          // (1 + NCB) * 16 * 64 floats <= kStage
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            mine[r * 64 + lane] = gW2[r];
+    for (int r = 0; r < 16; ++r) {
+        stage[r * 64 + lane] = gW2[r];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) mine[(16 * (1 + cb) + r) * 64 + lane] = gW1[cb][r];
-        }
+        for (int cb = 0; cb < NCB; ++cb) stage[(16 * (1 + cb) + r) * 64 + lane] = gW1[cb][r];
     }
     __syncthreads();
+    const float* const st0 = s_all + kWts;
     for (int e = threadIdx.x; e < (1 + NCB) * 16 * 64; e += 256) {
-        const float v = s_stage[e] + s_stage[kStage + e] + s_stage[2 * kStage + e] + s_stage[3 * kStage + e];
+        const float v = st0[e] + st0[kStage + e] + st0[2 * kStage + e] + st0[3 * kStage + e];
         const int blk = e >> 10, r = (e >> 6) & 15, l = e & 63;
         const int unit = acc_row(r, l >> 5), col = l & 31;
         if (blk == 0) {
@@ -1027,12 +1046,12 @@ static int cv_plane_split(int B, int groups, int D)
     return split;
 }
 
-// Backward: one wavefront per SIMD (registers) and every workgroup ends with 3 k weight atomics, so only as many plane
-// slices as it takes to give each of the chip's 256 CUs a few workgroups.
+// Backward: two workgroups per CU, and every workgroup ends with 3 k weight atomics, so only as many plane slices as it
+// takes to give each of the chip's 256 CUs a few rounds of workgroups (and at least 8 planes per wavefront).
 static int cv_bwd_plane_split(int B, int groups, int D)
 {
     int split = 1;
-    while (split * 4 * 8 < D && (long long)B * groups * split < 1024) split *= 2;
+    while (split * 4 * 8 < D && (long long)B * groups * split < 2048) split *= 2;
     return split;
 }
 
@@ -1153,16 +1172,13 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
     hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_src), dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
     const int groups = (hw + 31) / 32;
     const int bslices = cv_bwd_plane_split(B, groups, D);
-    if (C == 48)
-        hipLaunchKernelGGL(cost_volume_bwd_kernel<24>, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
+    auto sweep = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
                            d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3);
-    else
-        hipLaunchKernelGGL(cost_volume_bwd_kernel<8>, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
-                           Pmat, cur_invK, planes, (long long)plane_stride_b,
-                           (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
-                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3);
+    };
+    if (C == 48) sweep(cost_volume_bwd_kernel<24>); else sweep(cost_volume_bwd_kernel<8>);
     hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_cur), dim3(256), 0, st, d_curT, d_cur_feats, C, hw, B);
     hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_src), dim3(256), 0, st, d_srcT, d_src_feats, C, hw, B * K);
     FS_CHECK_LAUNCH("cost_volume_backward");
