@@ -8,20 +8,19 @@
 //
 //   * per (pixel, source) the plane-induced homography  q(d) = d * (P[:, :3] r) + P[:, 3]  is
 //     3 FMAs per plane;
-//   * features are re-laid out once per call to pixel-major [y][x][parity][C/2] so that one
-//     bilinear tap of one lane is 96 contiguous bytes (6 x dwordx4);
-//   * a wavefront owns 32 pixels: lane l = (pixel l&31, channel parity l>>5).  That is exactly
-//     the operand layout of v_mfma_f32_32x32x2_f32 (lane l supplies B[k = l>>5][j = l&31]), so the
-//     averaged warped features feed the 49->32 layer WITHOUT any cross-lane movement, computed
-//     transposed (H1^T = W1 X^T): the accumulator then holds, per lane, 16 hidden units of ITS
-//     pixel, which again is directly the B operand of the 32->32 layer with the k order permuted
-//     to the accumulator's row map; the final 32->1 layer is 16 FMAs + one cross-half add.
-//     41 MFMAs (exact fp32, = fmaf chains) per 32 pixels per plane; the gather/dot VALU work of
-//     one wavefront overlaps the MFMAs of the other wavefronts of the SIMD.
-//   * bias of layer 1 rides in the padding column of the K dimension (feature 49 := 1).
-//   * K = 1 (two-view configurations): cost_volume_proj_kernel -- the first layer's feature block is applied once per
-//     SOURCE TEXEL by the re-layout (it is linear, and so is the bilinear warp) and the sweep blends the result:
-//     16 MFMAs per 32 pixels per plane instead of 41.
+//   * the averaged warped features feed the 49->32 layer on the matrix cores computed transposed (H1^T = W1 X^T), so the
+//     accumulator holds, per lane, hidden units of ITS pixel -- which is directly the B operand of the 32->32 layer with
+//     the k order permuted to the accumulator's row map; the final 32->1 layer is a few FMAs and a cross-lane add.  Exact
+//     fp32 (= fmaf chains); the bias of layer 1 rides in the padding column of the K dimension (feature 49 := 1).
+//   * three sweeps share that scheme:
+//     - K = 1 (two-view configurations), cost_volume_proj_kernel: the first layer's feature block is applied once per
+//       SOURCE TEXEL by the re-layout (it is linear, and so is the bilinear warp) and the sweep blends the result: 16 MFMAs
+//       (32x32x2) per 32 pixels per plane instead of 41; lane = (pixel of 32, channel parity), slot-major source records;
+//     - K >= 2, cost_volume16_kernel: 16-pixel wavefronts, lane = (pixel, channel quarter) with the four lanes of a pixel
+//       adjacent, so that a tap load reads 64 contiguous bytes per quad (the sweep is bound by the delivery of its taps:
+//       1.7x fewer cycles per load instruction than with (pixel, parity) lanes), v_mfma_f32_16x16x4_f32;
+//     - backward, cost_volume_bwd_kernel: 32 pixels x parity on texel-major [y][x][parity][C/2] records, forward
+//       recomputed per plane, every gradient (features and the six MLP tensors) from the one kernel.
 #include <algorithm>
 #include <cstdlib>
 
@@ -177,48 +176,89 @@ static inline unsigned cv_grid(int B, int groups, int slices) { return 8u * (uns
 // here (the multiply, the max and two NaN-canonicalising v_max that IEEE mode puts in front of it).
 __device__ __forceinline__ float lrelu(float x) { return fmaf(0.495f, fabsf(x), 0.505f * x); }
 
-template <int HC>  // HC = C/2 channels per lane
-__global__ __launch_bounds__(256) void cost_volume_kernel(
-    int B, int K, int h, int w, int D, int slices, const float* __restrict__ curT, const float* __restrict__ srcT,
+// ==========================================================================================
+// The K >= 2 sweep on 16-pixel wavefronts: lane = (pixel j of 16, QUARTER c of its channels), the four lanes of a pixel
+// ADJACENT (lane = 4 j + c), source records texel-major in natural channel order.  One tap load instruction then reads,
+// per pixel, 64 contiguous bytes with the four lanes of one quad (bytes [64 s + 16 c, +16) of the texel's record, s < C/16)
+// -- the texture path coalesces a quad's lanes, not the 16-byte chunks of lanes 32 apart: profiles/tools/tap_pattern_rate.hip
+// measures 8.2 ns per wave load instruction per CU for this pattern against 13.9 ns for (pixel of 32, channel parity) lanes
+// on [parity][C/2] records -- the sweep this one replaced: 10 views, K = 8 at 96x128: 5.60 -> 4.07 ms; config-3 scale,
+// K = 2: 3.6 -> 3.45 ms -- at any sampling scale (a chunk-planar map, which coalesces NEIGHBOURING pixels' chunks instead,
+// is as fast at <= 1 texel per pixel and slower than either from 2 texels per pixel on: the round-2 slot-major experiment).
+// The gather, the matching score (a quad reduction: two DPP adds) and the average over the sources all happen in that lane
+// order; once per plane the C/4 + 1 averaged values of a lane move to the operand order of v_mfma_f32_16x16x4_f32
+// (lane = pixel n + 16 k, k = the quarter) with one ds_bpermute each -- a fixed rotation of the lane index bits.
+//   layer 1: H1^T[32 units][16 px] = W1 X^T: 2 row blocks x (C/4 + 1) k-steps of 4 channels (step t, quarter k -> channel
+//            16 (t / 4) + 4 k + t % 4; last step: dot, 1, 0, 0);  accumulator: lane (n, g) holds units 16 blk + 4 g + r
+//   layer 2: those registers ARE the B operands of W2 (k-step (blk, r), quarter g -> unit 16 blk + 4 g + r): 2 x 8 steps
+//   layer 3: 8 FMAs per lane + the sum over the four quarters.
+// ==========================================================================================
+__global__ __launch_bounds__(256) void cv_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int hw,
+                                                           int n_maps)
+{
+    // [map][C][hw] -> [map][hw][C]; one thread per element, reads coalesced along the pixel index
+    const long long total = (long long)n_maps * hw * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int pix = (int)(e % hw);
+        const long long r = e / hw;
+        const int c = (int)(r % C);
+        const long long map = r / C;
+        dst[(map * hw + pix) * C + c] = src[e];
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
+    int B, int K, int h, int w, int D, int slices, const float* __restrict__ curN, const float* __restrict__ srcN,
     const float* __restrict__ Pmat,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
     const float* __restrict__ b3, float* __restrict__ out)
 {
-    constexpr int C = 2 * HC;
+    constexpr int NS = C / 16;          // tap load instructions (float4 per lane each)
+    constexpr int NR = C / 4;           // channels per lane
+    constexpr int NT = NR + 1;          // k-steps of layer 1 (the last one: dot, 1, 0, 0)
     const int hw = h * w;
-    const int groups = (hw + 31) / 32;
+    const int groups = (hw + 15) / 16;
     const CvBlock blk_ = cv_block(B, groups, slices);
     if (!blk_.ok) return;   // (workgroup-uniform)
     const int b = blk_.b, grp = blk_.grp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int p = lane & 31, hf = lane >> 5;
-    const int pix = grp * 32 + p;
+    // gather order
+    const int j = lane >> 2, c = lane & 3;
+    const int pix = grp * 16 + j;
     const bool live = pix < hw;
     const int pu = live ? pix % w : 0, pv = live ? pix / w : 0;
+    // operand order
+    const int n = lane & 15, g = lane >> 4;
+    const int pix_m = grp * 16 + n;
+    const int pull = (4 * n + g) * 4;   // ds_bpermute address: operand lane (n, g) takes gather lane 4 n + g
 
-    // ---- MLP weights in registers, in MFMA A-operand order ----
-    float a1[HC + 1];  // W1[p][2s+hf], s < HC; step HC: {W1[p][C] (dot feature), b1[p]}
+    // ---- MLP weights in registers, in MFMA A-operand order (lane = (row n of the block, k = g)) ----
+    float a1[2][NT], a2[2][8], w3v[2][4], b2v[2][4];
 #pragma unroll
-    for (int s = 0; s < HC; ++s) a1[s] = w1[p * (C + 1) + 2 * s + hf];
-    a1[HC] = hf ? b1[p] : w1[p * (C + 1) + C];
-    float a2[16], w3r[16], b2r[16];
+    for (int blk = 0; blk < 2; ++blk) {
+        const int u = 16 * blk + n;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        a2[s] = w2[p * 32 + acc_row(s, hf)];  // W2[i=p][k = unit held as reg s by half hf]
-        w3r[s] = w3[acc_row(s, hf)];
-        b2r[s] = b2[acc_row(s, hf)];
+        for (int t = 0; t < NR; ++t) a1[blk][t] = w1[u * (C + 1) + 16 * (t >> 2) + 4 * g + (t & 3)];
+        a1[blk][NR] = g == 0 ? w1[u * (C + 1) + C] : (g == 1 ? b1[u] : 0.0f);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a2[blk][t] = w2[u * 32 + 16 * (t >> 2) + 4 * g + (t & 3)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { w3v[blk][r] = w3[16 * blk + 4 * g + r]; b2v[blk][r] = b2[16 * blk + 4 * g + r]; }
     }
     const float b3v = b3[0];
 
-    // ---- current-view feature (this lane's parity) ----
-    float cur[HC];
+    // ---- current-view feature: this lane's quarter of its pixel's channels ----
+    float cur[NR];
     {
-        const float4* q = (const float4*)(curT + ((size_t)b * hw + (live ? pix : 0)) * C + (size_t)hf * HC);
+        const float4* q = (const float4*)(curN + ((size_t)b * hw + (live ? pix : 0)) * C) + c;
 #pragma unroll
-        for (int s = 0; s < HC / 4; ++s) {
-            const float4 v = q[s];
+        for (int s = 0; s < NS; ++s) {
+            const float4 v = q[4 * s];
             cur[4 * s] = v.x; cur[4 * s + 1] = v.y; cur[4 * s + 2] = v.z; cur[4 * s + 3] = v.w;
         }
     }
@@ -234,10 +274,10 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
     const int dchunk = (D + slices * 4 - 1) / (slices * 4);
     const int d0 = min(D, (blk_.slice * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
 
-    // Per plane the sweep used to pay three dependent memory round trips before its first MFMA: the plane's depth,
-    // the projection rows (scalar loads), then the taps.  The depth is now fetched one plane ahead and the projection
-    // rows of the first two sources stay in SGPRs for the whole sweep (the shipped configs have K <= 2 except the
-    // 9-nearest selection of config 4).
+    // Per plane the sweep would pay three dependent memory round trips before its first MFMA: the plane's depth, the
+    // projection rows (scalar loads), then the taps.  The depth is fetched one plane ahead and the projection rows of the
+    // first two sources stay in SGPRs for the whole sweep (the shipped configs have K <= 2 except the 9-nearest selection
+    // of config 4).
     const float* pl = planes + b * ps_b + (live ? pix : 0) * ps_p;
     float depth_next = d0 < d1 ? pl[d0 * ps_d] : 0.0f;
     float P0[12], P1[12];
@@ -254,12 +294,11 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
         FS_CV_T(t_top, rx);
         const float depth = depth_next;
         depth_next = pl[min(d + 1, d1 - 1) * ps_d];
-        float favg[HC];
+        float favg[NR];
 #pragma unroll
-        for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
+        for (int r = 0; r < NR; ++r) favg[r] = 0.0f;
         float dot_sum = 0.0f, cnt = 0.0f;
         auto one_source = [&](int k, const float* P) __attribute__((always_inline)) {
-
             // world point = depth * r (homogeneous 1): geometry_utils.py:56-58
             const float X = depth * rx, Y = depth * ry, Z = depth * rz;
             const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
@@ -281,13 +320,13 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
             const bool xin0 = fx0 >= 0.0f && fx0 <= (float)(w - 1), xin1 = fx0 >= -1.0f && fx0 <= (float)(w - 2);
             const bool yin0 = fy0 >= 0.0f && fy0 <= (float)(h - 1), yin1 = fy0 >= -1.0f && fy0 <= (float)(h - 2);
             const int x0 = xin0 || xin1 ? (int)fx0 : 0, y0 = yin0 || yin1 ? (int)fy0 : 0;
-            float wv[HC];
+            float wv[NR];
 #pragma unroll
-            for (int s = 0; s < HC; ++s) wv[s] = 0.0f;
+            for (int r = 0; r < NR; ++r) wv[r] = 0.0f;
             // wave-uniform map base (SGPR pair) + a 32-bit per-lane byte offset: one address add per tap instead of
             // 64-bit multiply-adds (a source map is far below 4 GB)
-            const char* base = (const char*)(srcT + (((size_t)b * K + k) * hw) * C);
-            const uint32_t off0 = (uint32_t)((y0 * w + x0) * C + hf * HC) * 4u;
+            const char* base = (const char*)(srcN + (((size_t)b * K + k) * hw) * C);
+            const uint32_t off0 = (uint32_t)((y0 * w + x0) * C + 4 * c) * 4u;
 #pragma unroll
             for (int tap = 0; tap < 4; ++tap) {
                 const int ox = tap & 1, oy = tap >> 1;
@@ -296,8 +335,8 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
                 if (ok) {
                     const float4* q = (const float4*)(base + (off0 + (uint32_t)((oy * w + ox) * C) * 4u));
 #pragma unroll
-                    for (int s = 0; s < HC / 4; ++s) {
-                        const float4 v = q[s];
+                    for (int s = 0; s < NS; ++s) {
+                        const float4 v = q[4 * s];
                         wv[4 * s] += wt * v.x; wv[4 * s + 1] += wt * v.y;
                         wv[4 * s + 2] += wt * v.z; wv[4 * s + 3] += wt * v.w;
                     }
@@ -305,44 +344,54 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
             }
             float part = 0.0f;
 #pragma unroll
-            for (int s = 0; s < HC; ++s) part += wv[s] * cur[s];
-            float dotk = part + __shfl_xor(part, 32, 64);
-            dotk = (zz > 0.0f) ? dotk : 0.0f;                             // cost_volume.py:571-572,589-593
-            const bool valid = dotk != 0.0f;                              // :595 (exact zero test)
-            if (valid) {
+            for (int r = 0; r < NR; ++r) part += wv[r] * cur[r];
+            // sum over the pixel's four lanes (one quad)
+            part += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(part), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+            part += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(part), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+            const float dotk = (zz > 0.0f) ? part : 0.0f;                 // cost_volume.py:571-572,589-593
+            if (dotk != 0.0f) {                                           // :595 (exact zero test)
                 cnt += 1.0f;
                 dot_sum += dotk;
 #pragma unroll
-                for (int s = 0; s < HC; ++s) favg[s] += wv[s];
+                for (int r = 0; r < NR; ++r) favg[r] += wv[r];
             }
-        
         };
         one_source(0, P0);
         if (K > 1) one_source(1, P1);
         for (int k = 2; k < K; ++k) one_source(k, Pmat + ((size_t)b * K + k) * 12);
         const float inv = 1.0f / (cnt + 1e-8f);                          // :595-598
-        FS_CV_T(t_gath, favg[0] + favg[HC - 1] + inv + dot_sum);
-        // ---- layer 1: H1^T = W1 [f; dot; 1]^T  (K dimension = C + 2, two features per MFMA) ----
-        f32x16 acc;
+        FS_CV_T(t_gath, favg[0] + favg[NR - 1] + inv + dot_sum);
+        // ---- to the operand order: lane (n, g) takes quarter g of pixel n ----
+        float xm[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < NR; ++r) xm[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(favg[r] * inv)));
+        xm[NR] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(c == 0 ? dot_sum * inv : (c == 1 ? 1.0f : 0.0f))));
+        // ---- layer 1 ----
+        f32x4 h1[2];
 #pragma unroll
-        for (int s = 0; s < HC; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], favg[s] * inv, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[HC], hf ? 1.0f : dot_sum * inv, acc, 0, 0, 0);
-        // ---- layer 2: H2^T = W2 lrelu(H1)^T + b2, k order = accumulator row map ----
-        f32x16 acc2;
+        for (int blk = 0; blk < 2; ++blk) {
+            h1[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = b2r[r];
+            for (int t = 0; t < NT; ++t) h1[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[blk][t], xm[t], h1[blk], 0, 0, 0);
+        }
+        // ---- layer 2 ----
+        f32x4 h2[2];
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], lrelu(acc[s]), acc2, 0, 0, 0);
+        for (int blk = 0; blk < 2; ++blk) {
+            h2[blk] = f32x4{b2v[blk][0], b2v[blk][1], b2v[blk][2], b2v[blk][3]};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                h2[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[blk][t], lrelu(h1[t >> 2][t & 3]), h2[blk], 0, 0, 0);
+        }
         // ---- layer 3 ----
         float o = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o += w3r[r] * lrelu(acc2[r]);
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o += w3v[blk][r] * lrelu(h2[blk][r]);
+        o += __shfl_xor(o, 16, 64);
         o += __shfl_xor(o, 32, 64);
-        if (live && hf == 0) out[((size_t)b * D + d) * hw + pix] = o + b3v;
+        if (g == 0 && pix_m < hw) out[((size_t)b * D + d) * hw + pix_m] = o + b3v;
 #ifdef FS_CV_TRACE
         FS_CV_T(t_end, o);
         tr_g += t_gath - t_top;
@@ -362,11 +411,11 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(
 #endif
 }
 
-
 // The sweep with the first layer's feature block folded into the source records (cv_relayout_project_kernel): 16 MFMAs
 // per (32-pixel group, plane) instead of 41, 160 instead of 96 bytes per tap and lane.  Used for K = 1 (the reference's
 // two-view configurations): with more sources per view the extra tap bytes outweigh the 25 MFMAs saved per plane
-// (config-3 scale, K = 2: on par; 10 views, K = 8: 18 % slower than the sweep above).
+// (config-3 scale, K = 2: on par; 10 views, K = 8: 18 % slower than the 32-pixel texel-major sweep of round 2, which the
+// 16-pixel sweep above has since beaten by another 27 %).
 template <int HC>  // HC = C/2 channels per lane
 __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
     int B, int K, int h, int w, int D, int slices, const float* __restrict__ cur_feats, const float* __restrict__ srcT,
@@ -1104,18 +1153,21 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
         } else {
             hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics,
                                Pmat);
-            hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot1 + 255) / 256, 65536)),
+            const int groups16 = (hw + 15) / 16;
+            const int slices16 = cv_plane_split(B, groups16, D);
+            const dim3 grid16(cv_grid(B, groups16, slices16));
+            hipLaunchKernelGGL(cv_transpose_kernel, dim3((unsigned)std::min<long long>((tot1 + 255) / 256, 65536)),
                                dim3(256), 0, st, cur_feats, curT, C, hw, B);
-            hipLaunchKernelGGL(cv_relayout_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
+            hipLaunchKernelGGL(cv_transpose_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
                                dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
             if (C == 48)
-                hipLaunchKernelGGL(cost_volume_kernel<24>, grid, dim3(256), 0, st, B, K, h, w, D, slices, curT, srcT, Pmat, cur_invK,
-                                   planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
-                                   w1, b1, w2, b2, w3, b3, out);
+                hipLaunchKernelGGL(cost_volume16_kernel<48>, grid16, dim3(256), 0, st, B, K, h, w, D, slices16, curT, srcT, Pmat,
+                                   cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
+                                   (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out);
             else
-                hipLaunchKernelGGL(cost_volume_kernel<8>, grid, dim3(256), 0, st, B, K, h, w, D, slices, curT, srcT, Pmat, cur_invK,
-                                   planes, (long long)plane_stride_b, (long long)plane_stride_d, (long long)plane_stride_pix,
-                                   w1, b1, w2, b2, w3, b3, out);
+                hipLaunchKernelGGL(cost_volume16_kernel<16>, grid16, dim3(256), 0, st, B, K, h, w, D, slices16, curT, srcT, Pmat,
+                                   cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
+                                   (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out);
         }
     }
     FS_CHECK_LAUNCH("cost_volume");
