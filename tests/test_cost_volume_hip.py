@@ -75,16 +75,18 @@ def test_native_size_vs_reference_statistics_and_oracle(hip_device, sweep):
     np.testing.assert_allclose(o[0, ::16, 40, 60], stat["probe"], atol=ATOL)
 
 
-@pytest.mark.parametrize("V,K,h4,w4,D,behind", [(3, 2, 15, 21, 11, True), (4, 3, 30, 40, 16, False),
-                                                 (2, 1, 5, 7, 3, True), (2, 1, 64, 64, 128, False)])
-def test_ragged_shapes_vs_oracle(hip_device, V, K, h4, w4, D, behind, sweep):
+@pytest.mark.parametrize("V,K,h4,w4,D,behind,C", [(3, 2, 15, 21, 11, True, 48), (4, 3, 30, 40, 16, False, 48),
+                                                   (2, 1, 5, 7, 3, True, 48), (2, 1, 64, 64, 128, False, 48),
+                                                   (3, 2, 13, 19, 7, True, 16), (2, 1, 24, 32, 16, False, 16)])
+def test_ragged_shapes_vs_oracle(hip_device, V, K, h4, w4, D, behind, C, sweep):
+    """C = 16 is the module's (and SimpleRecon's) default matching dimension: its own kernel instantiations."""
     import inputs
     from oracle import cost_volume_oracle as cvo
     from freesplat_amd.cost_volume import AVGFeatureVolumeManager
     torch.manual_seed(V * 100 + K)
     m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
-                                mlp_channels=[202, 32, 32, 1], matching_dim_size=48)
-    kw = inputs.cv_inputs(V, K, h4, w4, 48, seed=17 + V, behind=behind)
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=17 + V, behind=behind)
     sd = {k.replace(".", "__"): v for k, v in m.state_dict().items()}
     ref = cvo.cost_volume(kw["cur_feats"], kw["src_feats"], kw["src_extrinsics"], kw["src_Ks"], kw["cur_invK"],
                           kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
@@ -137,16 +139,17 @@ def test_cpu_tensor_raises(hip_device):
         m(**kw)
 
 
-@pytest.mark.parametrize("V,K,h4,w4,D,behind", [(2, 1, 12, 16, 8, False), (3, 2, 15, 21, 6, True), (2, 1, 48, 64, 32, False)])
-def test_backward_matches_oracle_autograd(hip_device, V, K, h4, w4, D, behind):
+@pytest.mark.parametrize("V,K,h4,w4,D,behind,C", [(2, 1, 12, 16, 8, False, 48), (3, 2, 15, 21, 6, True, 48),
+                                                   (2, 1, 48, 64, 32, False, 48), (3, 2, 14, 18, 5, True, 16)])
+def test_backward_matches_oracle_autograd(hip_device, V, K, h4, w4, D, behind, C):
     """Gradients w.r.t. both feature maps and all six MLP tensors vs torch autograd of the oracle."""
     import inputs
     from oracle import cost_volume_oracle as cvo
     from freesplat_amd.cost_volume import AVGFeatureVolumeManager
     torch.manual_seed(V * 10 + K)
     m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
-                                mlp_channels=[202, 32, 32, 1], matching_dim_size=48)
-    kw = inputs.cv_inputs(V, K, h4, w4, 48, seed=23 + V, behind=behind)
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=23 + V, behind=behind)
     g = torch.randn(V, D, h4, w4, generator=torch.Generator().manual_seed(3))
     # oracle + autograd on CPU
     cur_c = kw["cur_feats"].clone().requires_grad_(True)
