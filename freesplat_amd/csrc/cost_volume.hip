@@ -957,42 +957,55 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
                     tD[p * C + hf * HC + s] = cf * dfavg[s] + cd * cur[s];
                     dcur[s] += cd * W.wv[s];
                 }
+                // (pixel, tap) records in WALK order: texel row (tap >> 1), then pixel, then column (tap & 1) -- equal texels
+                // of a row are neighbours (pixel p's right tap is pixel p+1's left one when the source is sampled at
+                // about its own resolution)
                 if (hf == 0) {
 #pragma unroll
                     for (int tap = 0; tap < 4; ++tap) {
-                        tW[p * 4 + tap] = W.ok[tap] ? W.wt[tap] : 0.0f;
-                        tO[p * 4 + tap] = W.tex[tap];
+                        tW[(tap >> 1) * 64 + 2 * p + (tap & 1)] = W.ok[tap] ? W.wt[tap] : 0.0f;
+                        tO[(tap >> 1) * 64 + 2 * p + (tap & 1)] = W.tex[tap];
                     }
                 }
                 wave_lds_sync();
                 float* const dmap = d_srcT + (((size_t)b * K + k) * hw) * C;
-                // the 128 (pixel, tap) weights and texel indices come back as two registers each (entry e in lane e & 63)
-                // and are handed out with v_readlane: the walk then has no LDS round trip in its control flow (as a loop
-                // over tW[e] / tO[e] every step waited for its own broadcast read before it could branch)
+                // Everything the walk needs comes back from LDS ONCE: the 128 weights and texel indices as two registers
+                // each (record e in lane e & 63, handed out with v_readlane) and this lane's channel of the pixels, 16
+                // registers at a time.  Runs of the same texel are summed in a register and leave as ONE atomic instruction
+                // (~66 instead of 128 per (group, plane, source)); where a run starts is decided for all records at once
+                // (two ballots), so a step of the walk is a scalar bit test, a v_readlane and an FMA -- the first version
+                // read its value from LDS and compared its index inside every step: ~190 cycles of latency per step,
+                // 80 % of the kernel's time at K = 8.
                 const float w_lo = tW[lane], w_hi = tW[64 + lane];
                 const uint32_t o_lo = tO[lane], o_hi = tO[64 + lane];
-                // Walked texel row by texel row in pixel order, equal texels in a row are neighbours in the walk (pixel p's
-                // right tap is pixel p+1's left one when the source is sampled at about its own resolution): runs of the
-                // same texel are summed in a register and leave as ONE atomic instruction -- ~66 instead of 128 per
-                // (group, plane, source).  All control flow is scalar (indices and weights live in SGPRs).
-                uint32_t run_idx = 0xffffffffu;
+                const unsigned long long act_lo = __builtin_amdgcn_ballot_w64(w_lo != 0.0f), act_hi = __builtin_amdgcn_ballot_w64(w_hi != 0.0f);
+                const unsigned long long same_lo = __builtin_amdgcn_ballot_w64(o_lo == (uint32_t)__shfl_up((int)o_lo, 1, 64));
+                const unsigned long long same_hi = __builtin_amdgcn_ballot_w64(o_hi == (uint32_t)__shfl_up((int)o_hi, 1, 64));
+                // a record starts a run unless its predecessor is in use and names the same texel (record 64 always does)
+                const unsigned long long head_lo = act_lo & ~((act_lo << 1) & same_lo), head_hi = act_hi & ~((act_hi << 1) & same_hi);
+                uint32_t run_idx = 0;
+                bool have = false;
                 float run_acc = 0.0f;
 #pragma unroll
-                for (int e2 = 0; e2 < 128; ++e2) {                  // texel row e2 >> 6, pixel (e2 >> 1) & 31, column e2 & 1
-                    const int px = (e2 >> 1) & 31, e = px * 4 + (e2 >> 6) * 2 + (e2 & 1);
-                    const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e < 64 ? w_lo : w_hi), e & 63));
-                    if (wt == 0.0f) continue;
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)(e < 64 ? o_lo : o_hi), e & 63);
-                    const float val = wt * tD[px * C + lane];
-                    if (idx == run_idx) {
-                        run_acc += val;
-                    } else {
-                        if (run_idx != 0xffffffffu && lane < C) atomicAdd(dmap + (size_t)run_idx * C + lane, run_acc);
-                        run_idx = idx;
-                        run_acc = val;
+                for (int q = 0; q < 4; ++q) {                       // texel row q >> 1, pixels 16 (q & 1) ..
+                    float tv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tv[i] = tD[(16 * (q & 1) + i) * C + lane];
+#pragma unroll
+                    for (int e2 = 32 * q; e2 < 32 * q + 32; ++e2) { // texel row e2 >> 6, pixel (e2 >> 1) & 31, column e2 & 1
+                        const int i = (e2 >> 1) & 15, ln = e2 & 63;
+                        const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2 < 64 ? w_lo : w_hi), ln));
+                        if (((e2 < 64 ? head_lo : head_hi) >> ln) & 1ull) {
+                            if (have && lane < C) atomicAdd(dmap + (size_t)run_idx * C + lane, run_acc);
+                            run_idx = (uint32_t)__builtin_amdgcn_readlane((int)(e2 < 64 ? o_lo : o_hi), ln);
+                            have = true;
+                            run_acc = wt * tv[i];
+                        } else {
+                            run_acc = fmaf(wt, tv[i], run_acc);     // (an unused record has weight 0)
+                        }
                     }
                 }
-                if (run_idx != 0xffffffffu && lane < C) atomicAdd(dmap + (size_t)run_idx * C + lane, run_acc);
+                if (have && lane < C) atomicAdd(dmap + (size_t)run_idx * C + lane, run_acc);
                 wave_lds_sync();
             }
         }
