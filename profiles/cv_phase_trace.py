@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Where a wavefront of the cost-volume sweep spends its time (debug build of the library with -DFS_CV_TRACE:
   make -C freesplat_amd/csrc clean && make -C freesplat_amd/csrc EXTRA=-DFS_CV_TRACE
-or a separate .so selected with FREESPLAT_LIB).  Prints mean shader cycles per (32-pixel group, plane) in the gather
-phase (plane depth -> projection -> bilinear taps -> reduction) and in the MLP phase (41 MFMAs + glue)."""
+or a separate .so selected with FREESPLAT_LIB).  Prints mean shader cycles per (pixel group, plane) -- 32 pixels in the K = 1
+sweep and in the backward, 16 in the K >= 2 sweep -- in the gather phase (plane depth -> projection -> bilinear taps ->
+reduction) and in the MLP phase (K = 1: 16 MFMAs 32x32x2; K >= 2: 42 MFMAs 16x16x4; + glue)."""
 import ctypes as C
 import json
 import os
@@ -42,15 +43,16 @@ def main(V=2, K=1, h4=96, w4=128, D=128):
     ticks, wall = (raw[:, 3] >> np.uint64(32)).astype(np.float64), (raw[:, 3] & np.uint64(0xffffffff)).astype(np.float64)
     out = {"config": f"V={V} K={K} {h4}x{w4} D={D}", "wavefronts": int(len(a)), "planes_per_wavefront": float(a[:, 2].mean()),
            "gather_cycles_per_plane": float(a[:, 0].sum() / planes), "mlp_cycles_per_plane": float(a[:, 1].sum() / planes),
-           "mfma_cycles_per_plane": 41 * 64,
+           "pixels_per_group": 32 if K == 1 else 16, "mfma_cycles_per_plane": 16 * 64 if K == 1 else 42 * 32,
            "s_memtime_ticks_per_us": float(ticks.sum() / (wall.sum() / 100.0)),
            "mean_wavefront_us": float(wall.mean() / 100.0)}
     print(json.dumps(out))
 
 
 def backward(V=2, K=1, h4=96, w4=128, D=128):
-    """The same for the backward kernel (fs_debug_cvb_trace): forward recompute / MLP backward / weight-gradient
-    outer products / feature gradients, shader cycles per (32-pixel group, plane)."""
+    """The same for the backward kernel (fs_debug_cvb_trace): forward recompute / MLP backward with the weight-gradient
+    outer products (the two-phase LDS tiles interleave them; the third stamp follows at once) / feature gradients (re-gather
+    for K > 1 + scatter), shader cycles per (32-pixel group, plane)."""
     dev = torch.device("cuda:0")
     L = C.CDLL(_lib.LIB_PATH)
     n = 16384 * 6
