@@ -9,7 +9,7 @@ below copies reference source: it stubs the reference's missing third-party impo
 (SURVEY.md Appendix D), imports its modules, and calls them.
 
 Fixtures (fp32, torch.manual_seed, sizes per SURVEY.md 8(c)):
-  cv_small_k1.npz / cv_small_k2.npz   AVGFeatureVolumeManager.forward (cost_volume.py:351-381, 429-619)
+  cv_small_k1.npz / cv_small_k2.npz / cv_small_c16.npz   AVGFeatureVolumeManager.forward (cost_volume.py:351-381, 429-619)
   cv_native_stat.json                  96x128, D=128 summary statistics + SHA-256 of the output
   ptf_small.npz / ptf_tie.npz          EncoderFreeSplat.fuse_gaussians (encoder_freesplat.py:431-522)
   adapter_small.npz                    GaussianAdapter.forward fusion=True / False (gaussian_adapter.py:135-201)
@@ -30,6 +30,8 @@ import torch
 
 REF = "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
+# python make_golden.py [fixture names ...]: regenerate only those cost-volume fixtures (the others stay byte-identical)
+ONLY = set(sys.argv[1:])
 sys.path.insert(0, OUT)
 from inputs import cameras, cv_inputs, ptf_inputs  # noqa: E402  (seeded input generators shared with the tests)
 
@@ -101,8 +103,11 @@ def save(name, **arrs):
 
 def gen_cost_volume():
     from src.model.encoder.modules.cost_volume import AVGFeatureVolumeManager
-    for name, V, K, behind in (("cv_small_k1", 2, 1, False), ("cv_small_k2", 3, 2, True)):
-        h4, w4, D, C = 12, 16, 8, 48
+    for name, V, K, behind, C in (("cv_small_k1", 2, 1, False, 48), ("cv_small_k2", 3, 2, True, 48),
+                                  ("cv_small_c16", 3, 2, True, 16)):   # 16: the module's default matching dimension
+        if ONLY and name not in ONLY:
+            continue
+        h4, w4, D = 12, 16, 8
         torch.manual_seed(100 + V)
         cv = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
                                      mlp_channels=[202, 32, 32, 1], matching_dim_size=C).eval()
@@ -111,6 +116,8 @@ def gen_cost_volume():
             out = cv(**kw)
         sd = {k.replace(".", "__"): v for k, v in cv.state_dict().items()}
         save(name + ".npz", out=out, D=D, **kw, **sd)
+    if ONLY:
+        return
     # native-size statistics
     h4, w4, D, C, V, K = 96, 128, 128, 48, 2, 1
     torch.manual_seed(7)
@@ -280,6 +287,9 @@ def gen_ply():
 
 if __name__ == "__main__":
     install_shim()
+    if ONLY:
+        gen_cost_volume()
+        sys.exit(0)
     gen_ply()
     gen_depth_tail()
     gen_glue()

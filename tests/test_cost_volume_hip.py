@@ -44,12 +44,12 @@ def _run(m, kw, dev, **extra):
         return m(**args, **extra).cpu()
 
 
-@pytest.mark.parametrize("name", ["cv_small_k1.npz", "cv_small_k2.npz"])
+@pytest.mark.parametrize("name", ["cv_small_k1.npz", "cv_small_k2.npz", "cv_small_c16.npz"])
 def test_matches_reference_golden(hip_device, name, sweep):
     g = _load(name)
     kw = {k: g[k] for k in ("cur_feats", "src_feats", "src_extrinsics", "src_poses", "src_Ks", "cur_invK",
                             "min_depth", "max_depth")}
-    m = _module_from_fixture(g, 12, 16, int(g["D"]), 48, hip_device)
+    m = _module_from_fixture(g, 12, 16, int(g["D"]), g["cur_feats"].shape[1], hip_device)
     out = _run(m, kw, hip_device)
     assert out.shape == g["out"].shape
     assert (out - g["out"]).abs().max().item() <= ATOL
