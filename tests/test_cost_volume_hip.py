@@ -31,7 +31,8 @@ def _module_from_fixture(g, h4, w4, D, C, dev):
 
 @pytest.fixture(params=["by_K", "classic", "projected"])
 def sweep(request, monkeypatch):
-    """Which forward sweep the library runs: its own choice (projected first layer for K = 1, classic otherwise) or
+    """Which forward sweep the library runs: its own choice (projected first layer for K = 1; otherwise the general
+    sweep on 16-pixel wavefronts, here "classic") or
     either one forced (FS_CV_PROJECTED is read at every call) -- both must meet the same bar at every K."""
     if request.param != "by_K":
         monkeypatch.setenv("FS_CV_PROJECTED", "1" if request.param == "projected" else "0")
