@@ -1137,6 +1137,8 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
         !w2 || !b2 || !w3 || !b3 || !workspace || !out)
         return FS_ERR_INVALID_ARG;
     if (C != 48 && C != 16) return FS_ERR_UNSUPPORTED;  // matching_dim_size of FreeSplat (48) / SimpleRecon (16)
+    // (the sweeps address a tap as a wave-uniform map base + a 32-bit per-lane byte offset)
+    if ((unsigned long long)h * w * (C + 2 * kCvU) * sizeof(float) >= (1ull << 32)) return FS_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream_;
     const int hw = h * w;
     float* curT = (float*)workspace;
@@ -1212,6 +1214,7 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
         !d_w3 || !d_b3)
         return FS_ERR_INVALID_ARG;
     if (C != 48 && C != 16) return FS_ERR_UNSUPPORTED;
+    if ((unsigned long long)h * w * (C + 2 * kCvU) * sizeof(float) >= (1ull << 32)) return FS_ERR_UNSUPPORTED;   // (32-bit texel offsets)
     hipStream_t st = (hipStream_t)stream_;
     const int hw = h * w;
     const size_t n_cur = (size_t)B * hw * C, n_src = n_cur * K;

@@ -191,7 +191,8 @@ size_t fs_cost_volume_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h
  * planes: depth of plane d for batch b at pixel p = planes[b*stride_b + d*stride_d + p*stride_pix]
  * (the generated planes of cost_volume.py:98-134 use strides (0,1,0) over a [D] array);
  * MLP (networks.py:218-236): w1[32,C+1], b1[32], w2[32,32], b2[32], w3[1,32], b3[1], LeakyReLU(0.01).
- * out[B,D,h,w].  C must be 48 (FreeSplat) or 16.  fp32 throughout; the 49->32->32 layers run on
+ * out[B,D,h,w].  C must be 48 (FreeSplat) or 16, and one feature map below 4 GB (h*w*(C+32)*4 < 2^32), else
+ * FS_ERR_UNSUPPORTED.  fp32 throughout; the 49->32->32 layers run on
  * v_mfma_f32_32x32x2_f32 (exact fp32).
  */
 int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
