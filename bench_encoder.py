@@ -118,7 +118,10 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
                          "mfma_busy_note": "matrix-pipe busy fraction from SQ_VALU_MFMA_BUSY_CYCLES (native K = 1 profile); `frac` "
                                            "prices the reference formulation's flops (41 MFMAs per cell), the K = 1 sweep issues 16",
                          "traffic": _traffic(wl_name)[0], "traffic_source": _traffic(wl_name)[1],
-                         "traffic_unit": "HBM bytes per call (all current views)"}}, **extra)
+                         "traffic_unit": "HBM bytes per call (all current views)",
+                         "traffic_note": None if K == 1 else "PMC passes of round 3 on the 32-pixel K >= 2 sweep; not re-taken for the "
+                                         "16-pixel sweep that replaced it (same algorithm and maps, natural instead of parity-split "
+                                         "channel order)"}}, **extra)
 
 
 def _ptf_w2c(E):
