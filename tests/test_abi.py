@@ -92,3 +92,21 @@ def test_key_area_sizing_and_retry_capacity():
         cap2 = R.retry_capacity(n_inst, max_tile, H, W)
         assert cap2 >= n_inst and (tile_capacity(cap2, T) >= max_tile or tile_capacity(cap2, T) * T * 2 > 0xFFFFFFFF)
     assert L.fs_abi_version() == _lib.ABI_VERSION
+
+
+def test_cost_volume_rejects_maps_of_4GB_and_more():
+    """The sweeps address a tap as map base + 32-bit byte offset: a feature map of >= 4 GB is refused (FS_ERR_UNSUPPORTED, -3)
+    before anything is launched -- so fake non-NULL pointers are enough here, no device involved."""
+    import ctypes as C
+    from freesplat_amd import _lib
+    L = _lib.lib()
+    p = C.c_void_p(4096)
+    h, w = 4096, 4096                      # 16.8 M texels x (48 + 32) floats x 4 B = 5.4 GB
+    fwd = [1, 1, 48, h, w, 8] + [p] * 6 + [0, 0, 1] + [p] * 9
+    assert L.fs_cost_volume_forward(*fwd) == -3
+    bwd = [1, 1, 48, h, w, 8] + [p] * 6 + [0, 0, 1] + [p] * 16
+    assert L.fs_cost_volume_backward(*bwd) == -3
+    fwd[2] = 32                            # unsupported matching dimension
+    assert L.fs_cost_volume_forward(*fwd) == -3
+    fwd[2], fwd[3] = 48, 0
+    assert L.fs_cost_volume_forward(*fwd) == -1
