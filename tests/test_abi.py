@@ -110,3 +110,28 @@ def test_cost_volume_rejects_maps_of_4GB_and_more():
     assert L.fs_cost_volume_forward(*fwd) == -3
     fwd[2], fwd[3] = 48, 0
     assert L.fs_cost_volume_forward(*fwd) == -1
+
+
+def test_every_entry_point_validates_its_arguments_before_touching_a_device():
+    """Error behaviour of the boundary, checked without a GPU: every int-returning entry point called with NULL pointers
+    answers FS_ERR_INVALID_ARG (-1) when its sizes are positive, and -1 or FS_OK (an empty job) when they are zero --
+    nothing dereferences or launches first."""
+    import ctypes as C
+    from freesplat_amd import _lib
+    L = _lib.lib()
+    getters = {"fs_abi_version", "fs_ptf_gru_table_rows", "fs_ptf_gru_table_t_rows", "fs_ptf_gru_stream_rows", "fs_ptf_gru_side_cols",
+               "fs_profile_enable", "fs_profile_collect"}
+
+    def call(name, size):
+        _, at = _lib.SIGNATURES[name]
+        args = [size if a in (C.c_int32, C.c_int64, C.c_int) else (0.0 if a is C.c_float else None) for a in at]
+        return getattr(L, name)(*args)
+
+    checked = 0
+    for name, (rt, _) in _lib.SIGNATURES.items():
+        if rt is not C.c_int or name in getters:
+            continue
+        assert call(name, 0) in (0, -1), name
+        assert call(name, 1) == -1, name
+        checked += 1
+    assert checked >= 24
