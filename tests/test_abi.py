@@ -135,3 +135,29 @@ def test_every_entry_point_validates_its_arguments_before_touching_a_device():
         assert call(name, 1) == -1, name
         checked += 1
     assert checked >= 24
+
+
+def test_workspace_size_queries():
+    """The size queries a caller allocates from (host logic, no GPU): the cost volume's forward workspace holds the
+    current view's [hw, C] copy, the sources' [hw, C + 32] records (features + the projected first-layer block of the
+    K = 1 sweep) and the projection rows; the backward's holds the pixel-major copies and their gradients and does NOT
+    grow with the plane count; the PTF sizes are monotone in their arguments; nonsense arguments give 0."""
+    from freesplat_amd import _lib
+    L = _lib.lib()
+    al = lambda x: (x + 255) // 256 * 256
+    for B, K, C, h, w in ((2, 1, 48, 96, 128), (3, 2, 48, 242, 324), (10, 8, 48, 96, 128), (3, 2, 16, 13, 19)):
+        hw = h * w
+        assert L.fs_cost_volume_workspace_bytes(B, K, C, h, w) == al((B * C + B * K * (C + 32)) * hw * 4) + al(B * K * 12 * 4)
+        b8 = L.fs_cost_volume_backward_workspace_bytes(B, K, C, h, w, 8)
+        assert b8 == al(B * (1 + K) * C * hw * 2 * 4) + al(B * K * 12 * 4)
+        assert L.fs_cost_volume_backward_workspace_bytes(B, K, C, h, w, 128) == b8
+    assert L.fs_cost_volume_workspace_bytes(1, 1, 0, 8, 8) == 0 and L.fs_cost_volume_backward_workspace_bytes(0, 1, 48, 8, 8, 8) == 0
+    prev = 0
+    for V in (2, 3, 10, 30):
+        n = L.fs_ptf_fold_bytes(V, 384, 512)
+        assert n > prev
+        prev = n
+    assert L.fs_ptf_fold_bytes(1, 384, 512) == 0 and L.fs_ptf_fold_bytes(2, 0, 512) == 0
+    assert L.fs_ptf_scratch_bytes(1000, 48, 64) <= L.fs_ptf_scratch_bytes(100000, 48, 64)
+    assert L.fs_ptf_fold_scratch_bytes(1000, 48, 64) <= L.fs_ptf_fold_scratch_bytes(100000, 48, 64)
+    assert L.fs_ptf_scratch_bytes(-1, 48, 64) == 0 and L.fs_ptf_fold_scratch_bytes(10, 48, 0) == 0
