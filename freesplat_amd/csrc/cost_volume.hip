@@ -713,7 +713,7 @@ __device__ __forceinline__ constexpr int row_half(int i) { return (i >> 2) & 1; 
 //     adds the 16 entries of its unit that it reads as MFMA operands) and of a half-height tile of g * h2 (neighbouring
 //     pixels pre-added with one DPP step) -- two accumulators instead of 32, and z2 is dead as soon as it is computed;
 //   * dW2 and dW1 are accumulated in two phases that share the dz tile (dz2, then dz1); lrelu'(z1) is kept as a bit mask.
-template <int HC>
+template <int HC, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
     int B, int K, int h, int w, int D, int slices, const float* __restrict__ curT, const float* __restrict__ srcT,
     const float* __restrict__ Pmat,
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
     const float* __restrict__ g_out, float* __restrict__ d_curT, float* __restrict__ d_srcT,
     float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
-    float* __restrict__ gw3, float* __restrict__ gb3)
+    float* __restrict__ gw3, float* __restrict__ gb3, float4* __restrict__ recS, float2* __restrict__ recM)
 {
     constexpr int C = 2 * HC;
     constexpr int NBLK = (HC + 1 + 15) / 16;  // row blocks of the permuted W1^T
@@ -810,6 +810,7 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
         // ---- forward recompute ----
         f32x16 z1;
         float inv, xlast;
+        uint32_t flags = 0, rare = 0;   // SPLIT: bit 2k = source k valid (dot != 0), bit 2k+1 = in front of it (z > 0)
         {
             float favg[HC];
 #pragma unroll
@@ -823,7 +824,14 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
                 for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
                 float dotk = part + __shfl_xor(part, 32, 64);
                 dotk = (W.zz > 0.0f) ? dotk : 0.0f;
+                if (SPLIT) {
+                    flags |= (W.zz > 0.0f ? 2u : 0u) << (2 * k);
+                    // in front, some tap inside the source image, and still an exactly zero score (all-zero features): the
+                    // score's gradient reaches the current feature although the source is not averaged -- see below
+                    if (W.zz > 0.0f && dotk == 0.0f && (W.ok[0] || W.ok[1] || W.ok[2] || W.ok[3])) rare |= 1u << k;
+                }
                 if (dotk != 0.0f) {
+                    if (SPLIT) flags |= 1u << (2 * k);
                     cnt += 1.0f;
                     dot_sum += dotk;
 #pragma unroll
@@ -928,10 +936,45 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
         }
         ddot = __shfl(ddot, p, 64);  // both parities of the pixel need it
         FS_CV_T(tq2, ddot + dfavg[0]);
+        if (SPLIT) {
+            // Two-pass form (round 4): the source-feature gradient is NOT scattered from here.  What a source that counts
+            // receives from this point through each bilinear tap -- S = d favg / cnt + d dot / cnt * cur, this lane's
+            // channels -- goes to memory once, chunk-planar ([view, plane][float4 chunk][pixel]: neighbouring pixels are
+            // neighbours in memory for the writer and for the reader), with d dot / cnt and the sources' (valid, in-front)
+            // bits beside it; cv_src_grad_kernel, whose workgroups own TILES OF SOURCE TEXELS, walks the pixels that
+            // sample its tile plane by plane and accumulates in LDS: no global float atomics (259 M 192-byte atomic
+            // records per 10-view K = 8 call before: 38 of the backward's 41.5 ms).
+            if (live) {
+                const size_t pl = (size_t)b * D + d;
+                float4* rp = recS + (pl * (C / 4) + (size_t)hf * (HC / 4)) * hw + pix;
+                const float di = ddot * inv;
+#pragma unroll
+                for (int s = 0; s < HC / 4; ++s)
+                    rp[(size_t)s * hw] = make_float4(fmaf(di, cur[4 * s], dfavg[4 * s] * inv), fmaf(di, cur[4 * s + 1], dfavg[4 * s + 1] * inv),
+                                                     fmaf(di, cur[4 * s + 2], dfavg[4 * s + 2] * inv), fmaf(di, cur[4 * s + 3], dfavg[4 * s + 3] * inv));
+                if (hf == 0) recM[pl * hw + pix] = make_float2(di, __uint_as_float(flags));
+            }
+            // d cur = d dot / cnt * sum_k [z_k > 0] warped_k.  For every source that counts, [z_k > 0] = valid_k, so the
+            // sum is favg = cnt * x, and x is still in this lane's entries of the feature tile.
+#pragma unroll
+            for (int s = 0; s < HC; ++s) dcur[s] = fmaf(ddot, tx[p * XS + 2 * s + hf], dcur[s]);
+            // (a source in front whose score is EXACTLY zero with taps inside its image -- all-zero features -- is not
+            //  averaged but still passes d dot / cnt on: re-gather those, wave-uniformly; never taken on real data)
+            if (__builtin_amdgcn_ballot_w64(rare != 0u) != 0ull) {
+                for (int k = 0; k < K; ++k) {
+                    if (__builtin_amdgcn_ballot_w64(((rare >> k) & 1u) != 0u) == 0ull) continue;
+                    warp_source<HC>(W, srcT + (((size_t)b * K + k) * hw) * C, w, h, hf, live, depth, rx, ry, rz,
+                                     Pmat + ((size_t)b * K + k) * 12, inv_w, inv_h);
+                    const float cd = ((rare >> k) & 1u) ? inv * ddot : 0.0f;
+#pragma unroll
+                    for (int s = 0; s < HC; ++s) dcur[s] = fmaf(cd, W.wv[s], dcur[s]);
+                }
+            }
+        }
         wave_lds_sync();   // (the scatter staging below overwrites the tiles)
         FS_CV_T(tq3, gW2[0] + gW1[0][0]);
         // ---- back to the features ----
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; !SPLIT && k < K; ++k) {
             // (K = 1: W still holds this source from the forward recompute above -- no second gather)
             if (K > 1) warp_source<HC>(W, srcT + (((size_t)b * K + k) * hw) * C, w, h, hf, live, depth, rx, ry, rz,
                                         Pmat + ((size_t)b * K + k) * 12, inv_w, inv_h);
@@ -1069,8 +1112,313 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
     }
 }
 
+
+// ==========================================================================================
+// Backward, second pass (round 4): the source-feature gradient WITHOUT global atomics.
+//   d src_k[t] = sum over (pixel p, plane d) whose bilinear taps cover texel t of
+//                w_tap * (valid_k * dfavg'(p, d) + [z_k > 0] * ddot'(p, d) * cur(p))
+// with dfavg' = d favg / cnt, ddot' = d dot / cnt and the two bits per source from the first pass's records.  A workgroup
+// owns a TILE of 16 x 16 source texels of one (view, source) -- its gradient lives in LDS, channel-planar, for the whole
+// sweep -- and walks the planes: for plane d the current pixels that can touch the tile are the preimage of the tile
+// rectangle (grown by the bilinear footprint) under the plane-induced homography, a convex quadrilateral whose bounding
+// box comes from the four corners through the INVERSE homography (cv_ginv_kernel; profiles/tools/cv_tile_box_count.py
+// checks on the CPU that no pixel with a tap in a tile falls outside its box, and counts 1.0 - 1.1 visited pixels per
+// (pixel, plane, source)).  Every pixel of the box is projected exactly as the first pass did, and the taps that fall
+// into the tile are added into LDS (see below how); the tile leaves once, as plain stores in the caller's [C, h, w] layout.
+// Tiles whose corners are all behind the source (c < 0 <=> z_k < 0) skip the plane; a tile that straddles the plane's
+// horizon walks the whole image (never seen with forward-looking cameras; exercised by the tests' turned-round source).
+// ==========================================================================================
+__global__ void cv_ginv_kernel(int n_maps, int K, int D, const float* __restrict__ Pmat, const float* __restrict__ cur_invK,
+                               const float* __restrict__ planes, long long ps_b, long long ps_d, float* __restrict__ Ginv)
+{
+    // G_d = d * P[:, :3] * invK[:3, :3] + P[:, 3] e3^T maps (u + .5, v + .5, 1) to (x z, y z, z) in the source; its inverse
+    // in double precision, rounded once (NaN when singular: the sweep then walks the whole image)
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_maps * D) return;
+    const int m = e / D, d = e - m * D, b = m / K;
+    const double depth = (double)planes[b * ps_b + d * ps_d];
+    const float* P = Pmat + (size_t)m * 12;
+    const float* iK = cur_invK + (size_t)b * 16;
+    double G[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0.0;
+            for (int l = 0; l < 3; ++l) a += (double)P[4 * i + l] * (double)iK[4 * l + j];
+            G[3 * i + j] = depth * a + (j == 2 ? (double)P[4 * i + 3] : 0.0);
+        }
+    const double c00 = G[4] * G[8] - G[5] * G[7], c01 = G[5] * G[6] - G[3] * G[8], c02 = G[3] * G[7] - G[4] * G[6];
+    const double det = G[0] * c00 + G[1] * c01 + G[2] * c02;
+    const double id = 1.0 / det;   // (inf / NaN propagate)
+    float* o = Ginv + (size_t)e * 9;
+    const double nan_ = __longlong_as_double(0x7ff8000000000000ll);
+    const bool bad = !(fabs(det) > 0.0) || !(fabs(id) < 1e300);
+    const double r[9] = {c00, G[2] * G[7] - G[1] * G[8], G[1] * G[5] - G[2] * G[4],
+                         c01, G[0] * G[8] - G[2] * G[6], G[2] * G[3] - G[0] * G[5],
+                         c02, G[1] * G[6] - G[0] * G[7], G[0] * G[4] - G[1] * G[3]};
+    for (int i = 0; i < 9; ++i) o[i] = (float)(bad ? nan_ : r[i] * id);
+}
+
+constexpr int kSgTW = 8, kSgTH = 8, kSgG = 4;
+#ifdef FS_CV_SG_STATS   // debug build: [0] wave iterations, [1] pixels with a tap in the tile, [2] (tile, plane) cells walked,
+__device__ unsigned long long g_sg_stats[8];   // [3] whole-image fallbacks, [4] cells skipped (behind), [5] box pixels, [6] claim rounds
+#define FS_SG_COUNT(i, n) do { atomicAdd(&g_sg_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define FS_SG_COUNT(i, n) do {} while (0)
+#endif
+
+// How the taps are ADDED.  LDS float atomics are not an option on this chip: ds_add_f32 costs 193 cycles per wave
+// instruction per CU -- ds_add_u32 4.3, a ds_read_b32 + ds_write_b32 pair 11.7 (profiles/tools/lds_atomic_rate.hip,
+// profiles/r4_lds_atomic_rate.txt); the first build of this kernel, (pixel, quarter) lanes adding with ds_add_f32, ran
+// 116 ms on the 10-view K = 8 shape, 3x slower than the global atomics it was meant to replace.  So the adds are plain
+// read-modify-writes, made safe by construction: a workgroup is ONE wavefront with a tile of 8 x 8 texels (no other
+// wavefront ever touches its accumulators, no barriers), lane = pixel with all C channels (texel-major accumulator rows
+// of C + 4 floats: a tap is C/4 ds_read_b128 + C/4 ds_write_b128, and the 208-byte row stride keeps neighbouring
+// texels conflict-free); inside the wavefront two pixels collide iff they have the same tap base (x0, y0) (the taps
+// of one pixel are distinct texels, and the four taps are four instruction groups, executed in order): each pending
+// lane writes its id to claim[base], reads it back, the survivors add their four taps, the others go round again -- one
+// round at >= 1 texel per pixel, n rounds where n pixels share a base.  (The second build split the CHANNELS over the
+// four wavefronts of a 16 x 16 tile: every wavefront repeated the projection, and a serial chain of record loads, claim
+// and four dependent read-modify-writes per 64 pixels left it latency-bound -- 9.9 ms on the 10-view K = 8 shape, of which
+// the adds were hidden entirely: profiles/r4_cv_sg_v2_variants.txt.)
+//   A tile's box is ~10 x 10 pixels, so kSgG = 4 planes (a quarter of the sweep apart) are walked together as one list of
+// pixels (plane by lane);
+// the four boxes are computed by 16 lanes at once (lane 4 g + q: corner q of plane g, quad reductions).  The loads of the
+// next 64 pixels are issued before the taps of the current 64 are added.
+template <int C>
+__global__ __launch_bounds__(64) void cv_src_grad_kernel(
+    int B, int K, int h, int w, int D, int chunks, int tiles_x, int tiles_y, const float* __restrict__ curT,
+    const float4* __restrict__ recS, const float2* __restrict__ recM, const float* __restrict__ Pmat,
+    const float* __restrict__ Ginv, const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
+    long long ps_d, float* __restrict__ d_src)
+{
+    constexpr int TW = kSgTW, TH = kSgTH, NT = TW * TH, NV = C / 4, ST = C + 4, HC = C / 2, G = kSgG;
+    constexpr int kClaim = (TW + 1) * (TH + 1) + 3;   // bases (lx, ly) in [-1, TW - 1] x [-1, TH - 1]
+    __shared__ __attribute__((aligned(16))) float acc[NT * ST];
+    __shared__ uint32_t claim_[kClaim];
+    const int hw = h * w, T = tiles_x * tiles_y;
+    // XCD x (= workgroup id % 8) owns the x-th contiguous range of tiles of every view: the workgroups in flight on an XCD
+    // -- the same tiles of all K sources, which read the same records -- share one L2
+    const int xcd = (int)(blockIdx.x & 7u), jb = (int)(blockIdx.x >> 3);
+    const int gb = (T + 7) >> 3, per_b = gb * K * chunks;
+    const int b = jb / per_b;
+    const int r0 = jb - b * per_b, tl = r0 / (K * chunks), r1 = r0 - tl * (K * chunks);
+    const int k = r1 / chunks, chunk = r1 - k * chunks;
+    const int tile = xcd * gb + tl;
+    if (b >= B || tile >= T) return;   // (workgroup-uniform)
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const int tw_ = min(TW, w - tx0), th_ = min(TH, h - ty0);
+    const int lane = threadIdx.x;
+    for (int e = lane; e < NT * ST / 4; e += 64) ((float4*)acc)[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    wave_lds_sync();
+    volatile uint32_t* const claim = claim_;
+    const float* P = Pmat + ((size_t)b * K + k) * 12;
+    const float* iK = cur_invK + (size_t)b * 16;
+    const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
+    const int dchunk = (D + chunks - 1) / chunks;
+    const int d0 = min(D, chunk * dchunk), d1 = min(D, d0 + dchunk);
+    const float X0 = (float)tx0 - 0.55f, X1 = (float)(tx0 + tw_) + 0.55f;     // qx / qz = ix + 0.5, taps at floor(ix), + 1
+    const float Y0 = (float)ty0 - 0.55f, Y1 = (float)(ty0 + th_) + 0.55f;
+    const uint32_t kbit = 2u * (uint32_t)k;
+
+    struct Geo { int t00, cid; float tx, ty; uint32_t okm; bool pend; };
+
+    // The four planes of a group lie a quarter of the sweep apart (dg + g * gstride): walked together, the same pixel in
+    // two of them samples texels many disparity steps apart -- with neighbouring planes (~0.56 texel apart at the native
+    // size) every batch that straddles two planes had lanes with the same tap base, i.e. a second claim round.
+    const int gstride = (d1 - d0 + G - 1) / G;
+    for (int dg = d0; dg < d0 + gstride; ++dg) {
+        // ---- the tile's preimage boxes in the current view, four planes at once: lane 4 g + q = corner q of its plane ----
+        int bx0s[G], by0s[G], Wbs[G], ns[G];
+        float rcps[G], deps[G];
+        {
+            const int g = (lane >> 2) & 3, q = lane & 3, d = dg + g * gstride;
+            const float* Gi = Ginv + (((size_t)b * K + k) * D + min(d, D - 1)) * 9;
+            const float X = (q & 1) ? X1 : X0, Y = (q & 2) ? Y1 : Y0;
+            const float cu = fmaf(Gi[0], X, fmaf(Gi[1], Y, Gi[2]));
+            const float cv_ = fmaf(Gi[3], X, fmaf(Gi[4], Y, Gi[5]));
+            const float cc = fmaf(Gi[6], X, fmaf(Gi[7], Y, Gi[8]));
+            auto qx1 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); };   // lane ^ 1
+            auto qx2 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); };   // lane ^ 2
+            auto qmin = [&](float v) { v = fminf(v, qx1(v)); return fminf(v, qx2(v)); };
+            auto qmax = [&](float v) { v = fmaxf(v, qx1(v)); return fmaxf(v, qx2(v)); };
+            float csum = cc + qx1(cc);
+            csum += qx2(csum);
+            const float cmin = qmin(cc), cmax = qmax(cc);
+            const float amax = fmaxf(fabsf(cmin), fabsf(cmax));
+            const bool finite = csum * 0.0f == 0.0f;                               // (NaN / inf in the inverse: whole image)
+            const bool behind = finite && cmax < -1e-3f * amax;                    // tile entirely behind the source: z_k < 0
+            const bool front = finite && cmin > 1e-3f * amax;
+            const float u = cu / cc - 0.5f, v = cv_ / cc - 0.5f;
+            const float umin = qmin(u), umax = qmax(u), vmin = qmin(v), vmax = qmax(v);
+            int bx0 = 0, bx1 = w - 1, by0 = 0, by1 = h - 1;
+            const bool boxed = front && (umin + umax + vmin + vmax) * 0.0f == 0.0f;
+            if (boxed) {
+                bx0 = (int)fminf(fmaxf(ceilf(umin - 0.05f), 0.0f), (float)w);
+                bx1 = (int)fmaxf(fminf(floorf(umax + 0.05f), (float)(w - 1)), -1.0f);
+                by0 = (int)fminf(fmaxf(ceilf(vmin - 0.05f), 0.0f), (float)h);
+                by1 = (int)fmaxf(fminf(floorf(vmax + 0.05f), (float)(h - 1)), -1.0f);
+            }
+            int Wb = max(0, bx1 - bx0 + 1), Hb = max(0, by1 - by0 + 1);
+            if (behind || d >= d1) Wb = 0;
+            const int n = Wb * Hb;
+            const float rcp = 1.0f / (float)max(Wb, 1);
+            const float dep = planes[b * ps_b + (long long)min(d, D - 1) * ps_d];
+#ifdef FS_CV_SG_STATS
+            if (lane < 16 && q == 0 && d < d1) {
+                if (behind) FS_SG_COUNT(4, 1); else if (n > 0) { FS_SG_COUNT(2, 1); FS_SG_COUNT(5, n); if (!boxed) FS_SG_COUNT(3, 1); }
+            }
+#endif
+#pragma unroll
+            for (int gg = 0; gg < G; ++gg) {
+                bx0s[gg] = __builtin_amdgcn_readlane(bx0, 4 * gg);
+                by0s[gg] = __builtin_amdgcn_readlane(by0, 4 * gg);
+                Wbs[gg] = __builtin_amdgcn_readlane(Wb, 4 * gg);
+                ns[gg] = __builtin_amdgcn_readlane(n, 4 * gg);
+                rcps[gg] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcp), 4 * gg));
+                deps[gg] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dep), 4 * gg));
+            }
+        }
+        const int o1 = ns[0], o2 = o1 + ns[1], o3 = o2 + ns[2], N = o3 + ns[3];
+        if (N == 0) continue;
+
+        // ---- one batch of 64 pixels: geometry (the first pass's projection, op by op: warp_source), record loads ----
+        auto stage = [&](int i0, Geo& ge, float4 (&S)[NV]) __attribute__((always_inline)) {
+            const int i = i0 + lane;
+            const bool act = i < N;
+            const int gs = (i >= o1 ? 1 : 0) + (i >= o2 ? 1 : 0) + (i >= o3 ? 1 : 0);
+            auto sel = [&](auto a0, auto a1, auto a2, auto a3) { return gs == 0 ? a0 : (gs == 1 ? a1 : (gs == 2 ? a2 : a3)); };
+            const int loc = i - sel(0, o1, o2, o3);
+            const int Wb = sel(Wbs[0], Wbs[1], Wbs[2], Wbs[3]);
+            const float rcpW = sel(rcps[0], rcps[1], rcps[2], rcps[3]);
+            const float depth = sel(deps[0], deps[1], deps[2], deps[3]);
+            int row = (int)(((float)loc + 0.5f) * rcpW), col = loc - row * Wb;
+            if (col < 0) { --row; col += Wb; } else if (col >= Wb) { ++row; col -= Wb; }
+            const int pu = act ? sel(bx0s[0], bx0s[1], bx0s[2], bx0s[3]) + col : 0;
+            const int pv = act ? sel(by0s[0], by0s[1], by0s[2], by0s[3]) + row : 0;
+            const int pix = pv * w + pu;
+            const float ux = (float)pu + 0.5f, vy = (float)pv + 0.5f;
+            const float rx = iK[0] * ux + iK[1] * vy + iK[2];
+            const float ry = iK[4] * ux + iK[5] * vy + iK[6];
+            const float rz = iK[8] * ux + iK[9] * vy + iK[10];
+            const float Xw = depth * rx, Yw = depth * ry, Zw = depth * rz;
+            const float qx = P[0] * Xw + P[1] * Yw + P[2] * Zw + P[3];
+            const float qy = P[4] * Xw + P[5] * Yw + P[6] * Zw + P[7];
+            const float qz = P[8] * Xw + P[9] * Yw + P[10] * Zw + P[11];
+            const float zz = qz + 1e-8f;
+            const float sc = (fabsf(qz) > 1e-8f) ? 1.0f / zz : 1.0f;
+            const float uvx = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qx, sc)), inv_w), 1.0f);
+            const float uvy = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qy, sc)), inv_h), 1.0f);
+            const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvx, 1.0f), (float)w), 1.0f), 0.5f);
+            const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvy, 1.0f), (float)h), 1.0f), 0.5f);
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            ge.tx = ix - fx0; ge.ty = iy - fy0;
+            // tap (ox, oy) = texel (fx0 + ox, fy0 + oy): inside the source image AND inside this tile
+            const float lx = fx0 - (float)tx0, ly = fy0 - (float)ty0;
+            const bool okx0 = lx >= 0.0f && lx <= (float)(tw_ - 1), okx1 = lx >= -1.0f && lx <= (float)(tw_ - 2);
+            const bool oky0 = ly >= 0.0f && ly <= (float)(th_ - 1), oky1 = ly >= -1.0f && ly <= (float)(th_ - 2);
+            ge.okm = (okx0 && oky0 ? 1u : 0u) | (okx1 && oky0 ? 2u : 0u) | (okx0 && oky1 ? 4u : 0u) | (okx1 && oky1 ? 8u : 0u);
+            bool pend = act && zz > 0.0f && ge.okm != 0u;
+            ge.t00 = pend ? (int)ly * TW + (int)lx : 0;       // tile-local index of tap (0, 0), >= -(TW + 1)
+            ge.cid = pend ? ((int)ly + 1) * (TW + 1) + (int)lx + 1 : 0;   // the base's own slot (t00 wraps: (7, y) = (-1, y + 1))
+            if (pend) {
+                const size_t pl = (size_t)b * D + (size_t)(dg + gs * gstride);
+                const float2 mt = recM[pl * hw + pix];
+                const uint32_t fl = __float_as_uint(mt.y) >> kbit;
+                pend = (fl & 2u) != 0u;                       // (the first pass's own z_k > 0)
+                const float4* sp = recS + pl * NV * hw + pix;
+#pragma unroll
+                for (int s = 0; s < NV; ++s) S[s] = sp[(size_t)s * hw];
+                if (pend && !(fl & 1u)) {
+                    // in front, not averaged (an exactly zero score): only d dot / cnt * cur reaches this source
+                    const float4* c4 = (const float4*)(curT + ((size_t)b * hw + pix) * C);
+#pragma unroll
+                    for (int s = 0; s < NV; ++s) {
+                        const float4 cv4 = c4[s];
+                        S[s] = make_float4(mt.x * cv4.x, mt.x * cv4.y, mt.x * cv4.z, mt.x * cv4.w);
+                    }
+                }
+            }
+            ge.pend = pend;
+#ifdef FS_CV_SG_STATS
+            {
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(pend);
+                if (lane == 0) { FS_SG_COUNT(0, 1); FS_SG_COUNT(1, __builtin_popcountll(hit)); }
+            }
+#endif
+        };
+        // ---- the adds: claim rounds, then four taps of C/4 float4 read-modify-writes ----
+        auto process = [&](const Geo& ge, const float4 (&S)[NV]) __attribute__((always_inline)) {
+            bool pend = ge.pend;
+            while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+#ifdef FS_CV_SG_STATS
+                if (lane == 0) FS_SG_COUNT(6, 1);
+#endif
+                if (pend) claim[ge.cid] = (uint32_t)lane;
+                wave_lds_sync();
+                const bool win = pend && claim[ge.cid] == (uint32_t)lane;
+                if (win) {
+#pragma unroll
+                    for (int tap = 0; tap < 4; ++tap) {
+                        const int ox = tap & 1, oy = tap >> 1;
+                        if (ge.okm & (1u << tap)) {
+                            const float wt = (ox ? ge.tx : 1.0f - ge.tx) * (oy ? ge.ty : 1.0f - ge.ty);
+                            float4* a = (float4*)(acc + (ge.t00 + oy * TW + ox) * ST);
+#pragma unroll
+                            for (int s = 0; s < NV; ++s) {
+                                float4 v = a[s];
+                                v.x = fmaf(wt, S[s].x, v.x); v.y = fmaf(wt, S[s].y, v.y);
+                                v.z = fmaf(wt, S[s].z, v.z); v.w = fmaf(wt, S[s].w, v.w);
+                                a[s] = v;
+                            }
+                        }
+                    }
+                }
+                pend = pend && !win;
+                wave_lds_sync();
+            }
+        };
+        Geo gA, gB;
+        float4 SA[NV], SB[NV];
+        stage(0, gA, SA);
+        for (int i0 = 0; i0 < N; i0 += 128) {
+            const bool moreB = i0 + 64 < N;
+            if (moreB) stage(i0 + 64, gB, SB);
+            process(gA, SA);
+            if (!moreB) break;
+            if (i0 + 128 < N) stage(i0 + 128, gA, SA);
+            process(gB, SB);
+        }
+    }
+    wave_lds_sync();
+    // ---- the tile leaves once, in the caller's [C, h, w] layout (slot q = parity * C/2 + s  ->  channel 2 s + parity) ----
+    {
+        float* const dmap = d_src + (((size_t)b * K + k) * C) * hw;
+        const int ty = lane >> 3, tx = lane & 7;
+        const bool inside = tx < tw_ && ty < th_;
+        float* const dpx = dmap + (size_t)(ty0 + ty) * w + (tx0 + tx);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const float4 v = ((const float4*)(acc + lane * ST))[s];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = 4 * s + e, ch = 2 * (q % HC) + q / HC;
+                if (inside) { if (chunks > 1) atomicAdd(dpx + (size_t)ch * hw, vv[e]); else dpx[(size_t)ch * hw] = vv[e]; }
+            }
+        }
+    }
+}
+
 }  // namespace fs
 
+#ifdef FS_CV_SG_STATS
+extern "C" __attribute__((visibility("default"))) int fs_debug_cv_sg_stats(unsigned long long* dst, int reset)
+{
+    static unsigned long long z[8];
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(fs::g_sg_stats), z, sizeof(z));
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fs::g_sg_stats), sizeof(z));
+}
+#endif
 #ifdef FS_CV_TRACE
 extern "C" __attribute__((visibility("default"))) int fs_debug_cv_trace(unsigned long long* dst, int reset)
 {
@@ -1194,8 +1542,20 @@ FS_API size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int3
 {
     if (B <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return 0;
     const size_t hw = (size_t)h * w;
-    // pixel-major copies curT, srcT and their gradients d_curT, d_srcT
-    return align_up((size_t)B * (1 + (size_t)K) * C * hw * 2 * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256);
+    // pixel-major copies curT, srcT and their gradients d_curT, d_srcT; the projection rows; and for the two-pass form
+    // (constant planes, K <= 16) one record of C + 2 floats per (view, plane, pixel) and the inverse plane homographies
+    return align_up((size_t)B * (1 + (size_t)K) * C * hw * 2 * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256) +
+           align_up((size_t)B * D * hw * C * sizeof(float), 256) + align_up((size_t)B * D * hw * 2 * sizeof(float), 256) +
+           align_up((size_t)B * K * D * 9 * sizeof(float), 256);
+}
+
+// The two-pass backward (records + source-tile sweep) needs plane depths that do not vary per pixel (a plane-induced
+// homography) and the sources' flag bits in one word; FS_CV_BWD_ATOMIC=1 forces the one-kernel scatter form (A/B runs)
+static bool cv_bwd_two_pass(int K, int64_t plane_stride_pix)
+{
+    const char* e = getenv("FS_CV_BWD_ATOMIC");
+    if (e && *e && atoi(e) != 0) return false;
+    return plane_stride_pix == 0 && K <= 16;
 }
 
 FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
@@ -1223,9 +1583,27 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
     float* d_curT = srcT + n_src;
     float* d_srcT = d_curT + n_cur;
     float* Pmat = (float*)((char*)workspace + align_up((n_cur + n_src) * 2 * sizeof(float), 256));
+    float4* recS = (float4*)((char*)Pmat + align_up((size_t)B * K * 12 * 4, 256));
+    float2* recM = (float2*)((char*)recS + align_up((size_t)B * D * hw * C * sizeof(float), 256));
+    float* Ginv = (float*)((char*)recM + align_up((size_t)B * D * hw * 2 * sizeof(float), 256));
+    const bool two_pass = cv_bwd_two_pass(K, plane_stride_pix);
+    const int tiles_x = (w + kSgTW - 1) / kSgTW, tiles_y = (h + kSgTH - 1) / kSgTH, tiles = tiles_x * tiles_y;
+    // plane chunks of the source-tile sweep: one (plain stores) when there are enough tiles to fill the chip (256 CUs x
+    // 11 single-wavefront workgroups), else enough chunks for one full round (their tiles then leave through atomics
+    // into a zeroed map)
+    int chunks = 1;
+    while ((long long)B * K * tiles * chunks < 2816 && D / (chunks * 2) >= kSgG) chunks *= 2;
     ScopedStage prof_(kStCostVolume, st);
     hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics, Pmat);
-    if (hipMemsetAsync(d_curT, 0, (n_cur + n_src) * sizeof(float), st) != hipSuccess ||
+    if (two_pass) {
+        hipLaunchKernelGGL(cv_ginv_kernel, dim3((B * K * D + 255) / 256), dim3(256), 0, st, B * K, K, D, Pmat, cur_invK, planes,
+                           (long long)plane_stride_b, (long long)plane_stride_d, Ginv);
+        if (chunks > 1 && hipMemsetAsync(d_src_feats, 0, n_src * sizeof(float), st) != hipSuccess) {
+            set_last_error("cost volume backward memset", hipGetLastError());
+            return FS_ERR_LAUNCH;
+        }
+    }
+    if (hipMemsetAsync(d_curT, 0, (two_pass ? n_cur : n_cur + n_src) * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(d_w1, 0, 32 * (size_t)(C + 1) * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(d_b1, 0, 32 * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(d_w2, 0, 32 * 32 * sizeof(float), st) != hipSuccess ||
@@ -1244,11 +1622,22 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
         hipLaunchKernelGGL(kernel, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
-                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3);
+                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM);
     };
-    if (C == 48) sweep(cost_volume_bwd_kernel<24>); else sweep(cost_volume_bwd_kernel<8>);
+    auto tile_sweep = [&](auto kernel) {
+        const unsigned grid = 8u * (unsigned)B * (unsigned)((tiles + 7) >> 3) * (unsigned)K * (unsigned)chunks;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, st, B, K, h, w, D, chunks, tiles_x, tiles_y, curT,
+                           (const float4*)recS, (const float2*)recM, Pmat, Ginv, cur_invK, planes, (long long)plane_stride_b,
+                           (long long)plane_stride_d, d_src_feats);
+    };
+    if (two_pass) {
+        if (C == 48) { sweep(cost_volume_bwd_kernel<24, true>); tile_sweep(cv_src_grad_kernel<48>); }
+        else { sweep(cost_volume_bwd_kernel<8, true>); tile_sweep(cv_src_grad_kernel<16>); }
+    } else {
+        if (C == 48) sweep(cost_volume_bwd_kernel<24, false>); else sweep(cost_volume_bwd_kernel<8, false>);
+        hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_src), dim3(256), 0, st, d_srcT, d_src_feats, C, hw, B * K);
+    }
     hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_cur), dim3(256), 0, st, d_curT, d_cur_feats, C, hw, B);
-    hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_src), dim3(256), 0, st, d_srcT, d_src_feats, C, hw, B * K);
     FS_CHECK_LAUNCH("cost_volume_backward");
     return FS_OK;
 }

@@ -27,14 +27,17 @@ def depth_planes(min_depth, max_depth, D: int) -> Tensor:
 
 
 def cost_volume(cur_feats: Tensor, src_feats: Tensor, src_extrinsics: Tensor, src_Ks: Tensor,
-                cur_invK: Tensor, min_depth, max_depth, D: int, mlp: dict) -> Tensor:
+                cur_invK: Tensor, min_depth, max_depth, D: int, mlp: dict, return_pre: bool = False):
     """cur_feats [B,C,h,w], src_feats [B,K,C,h,w], src_extrinsics [B,K,4,4] (src<-cur),
     src_Ks [B,K,4,4], cur_invK [B,4,4]; mlp = {"w1" [32,C+1], "b1", "w2" [32,32], "b2", "w3" [1,32], "b3"}.
-    Returns [B,D,h,w]."""
+    Returns [B,D,h,w]  (with return_pre: also the two hidden layers' pre-activations [B,D,h*w,32] and the sample positions --
+    the gradient tests mask the points that sit on a LeakyReLU kink or on the border of a source image).  Runs in the dtype of `cur_feats` (float64 for gradient references;
+    the plane depths are the fp32 values the module generates, cast)."""
     B, K, C, h, w = src_feats.shape
+    dt = cur_feats.dtype
     planes = depth_planes(min_depth.reshape(-1)[0] if torch.is_tensor(min_depth) else min_depth,
-                          max_depth.reshape(-1)[0] if torch.is_tensor(max_depth) else max_depth, D)
-    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+                          max_depth.reshape(-1)[0] if torch.is_tensor(max_depth) else max_depth, D).to(dt)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=dt), torch.arange(w, dtype=dt), indexing="ij")
     pix = torch.stack([xs + 0.5, ys + 0.5, torch.ones_like(xs)], 0).reshape(3, -1)       # geometry_utils.py:33-44
     rays = cur_invK[:, :3, :3] @ pix                                                       # [B,3,N]   :56
     pts = planes.view(1, D, 1, 1) * rays[:, None]                                          # [B,D,3,N] :57
@@ -56,9 +59,12 @@ def cost_volume(cur_feats: Tensor, src_feats: Tensor, src_extrinsics: Tensor, sr
     dot_mean = dot.sum(1, keepdim=True) / cnt                                              # [B,1,D,N]
     feat_mean = (warped * valid.unsqueeze(2)).sum(1) / cnt                                 # [B,C,D,N]   :597-598
     x = torch.cat([feat_mean, dot_mean], 1).permute(0, 2, 3, 1)                            # [B,D,N,C+1] :600-607
-    x = F.leaky_relu(F.linear(x, mlp["w1"], mlp["b1"]), 0.01)
-    x = F.leaky_relu(F.linear(x, mlp["w2"], mlp["b2"]), 0.01)
-    x = F.linear(x, mlp["w3"], mlp["b3"])                                                  # networks.py:218-236
+    z1 = F.linear(x, mlp["w1"], mlp["b1"])
+    z2 = F.linear(F.leaky_relu(z1, 0.01), mlp["w2"], mlp["b2"])
+    x = F.linear(F.leaky_relu(z2, 0.01), mlp["w3"], mlp["b3"])                             # networks.py:218-236
+    if return_pre:   # + the sample positions in source texel coordinates [B,K,D,N] (taps at floor, floor + 1)
+        return x.reshape(B, D, h, w), dict(z1=z1, z2=z2, ix=px - 0.5, iy=py - 0.5, feat_mean=feat_mean, dot_mean=dot_mean,
+                                           cnt=cnt, valid=valid, front=depth > 0, P=P, planes=planes)
     return x.reshape(B, D, h, w)
 
 

@@ -188,3 +188,115 @@ def test_backward_matches_oracle_autograd(hip_device, V, K, h4, w4, D, behind, C
         else:                   # parameter gradients: sums over all points, flips average out
             assert e.max().item() < 1e-2, f"{name}: max {e.max().item()}"
             assert e.mean().item() < 2e-3, f"{name}: mean {e.mean().item()}"
+
+
+def _masked_grad_out(aux, g, h4, w4, eps_z=1e-4, eps_px=1e-3):
+    """grad_out with the discontinuity points of the volume zeroed: a (pixel, plane) point whose hidden pre-activation
+    lies within eps_z of a LeakyReLU kink (slope 1 vs 0.01 decided by the last bits of a summation order), or one of whose
+    sources is sampled within eps_px of the position where its first / last bilinear tap enters the source image (the tap's
+    weight is ~0 there, but `dot != 0` -- the validity count -- flips).  What is left is smooth in every input, so fp32
+    results can be held to a tight bar against a float64 oracle."""
+    B, D = g.shape[:2]
+    kink = (aux["z1"].abs() < eps_z).any(-1) | (aux["z2"].abs() < eps_z).any(-1)                     # [B,D,N]
+    edge = torch.zeros_like(kink)
+    for pos, size in ((aux["ix"], w4), (aux["iy"], h4)):                                              # [B,K,D,N]
+        near = ((pos + 1).abs() < eps_px) | ((pos - size).abs() < eps_px) | ((pos - (size - 1)).abs() < eps_px) | (pos.abs() < eps_px)
+        edge |= near.any(1)
+    keep = ~(kink | edge).reshape(B, D, h4, w4)
+    return g * keep, int((~keep).sum())
+
+
+BWD_CASES = {
+    # (V, K, h4, w4, D, C, behind, which current views the float64 oracle differentiates)
+    "k8_24x32": (9, 8, 24, 32, 16, 48, False, None),
+    "k2_60x80": (3, 2, 60, 80, 32, 48, False, None),
+    "k2_behind": (3, 2, 30, 40, 16, 48, True, None),
+    "k3_c16": (4, 3, 28, 36, 12, 16, False, None),
+    "native_k1": (2, 1, 96, 128, 128, 48, False, (1,)),
+}
+
+
+@pytest.mark.parametrize("form", ["two_pass", "atomic"])
+@pytest.mark.parametrize("case", list(BWD_CASES))
+def test_backward_tight_vs_float64_oracle(hip_device, case, form, monkeypatch):
+    """Every gradient of the volume (both feature maps, the six MLP tensors) against autograd of the reference-pinned
+    oracle run in float64, at K = 8, K = 2, a turned-round source, C = 16 and the native 96x128 / D = 128 size, with the
+    discontinuity points masked out of grad_out (identically on both sides): <= 1e-3 of max-abs everywhere, <= 1e-4 on
+    average, for every tensor.  Both forms of the backward: the two-pass one (records + source-tile sweep, no global float
+    atomics; the default) and the one-kernel scatter it replaced (FS_CV_BWD_ATOMIC=1)."""
+    import inputs
+    from oracle import cost_volume_oracle as cvo
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    V, K, h4, w4, D, C, behind, views = BWD_CASES[case]
+    if form == "atomic":
+        monkeypatch.setenv("FS_CV_BWD_ATOMIC", "1")
+    torch.manual_seed(V * 10 + K)
+    m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
+                                mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=31 + V, behind=behind)
+    vs = list(range(V)) if views is None else list(views)
+    kw = {k: (v[vs] if k not in ("min_depth", "max_depth") else v) for k, v in kw.items()}
+    B = len(vs)
+    g = torch.randn(B, D, h4, w4, generator=torch.Generator().manual_seed(3))
+    # float64 oracle + autograd on the CPU
+    torch.set_num_threads(os.cpu_count() or 1)
+    dbl = lambda t: t.double()
+    cur_c = dbl(kw["cur_feats"]).requires_grad_(True)
+    src_c = dbl(kw["src_feats"]).requires_grad_(True)
+    mlp = {k: v.detach().double().requires_grad_(True) for k, v in
+           cvo.mlp_from_state({k.replace(".", "__"): v for k, v in m.state_dict().items()}).items()}
+    ref, aux = cvo.cost_volume(cur_c, src_c, dbl(kw["src_extrinsics"]), dbl(kw["src_Ks"]), dbl(kw["cur_invK"]),
+                               kw["min_depth"], kw["max_depth"], D, mlp, return_pre=True)
+    gm, n_masked = _masked_grad_out({k: v.detach() for k, v in aux.items()}, g, h4, w4)
+    assert n_masked < 0.05 * g.numel(), n_masked
+    (ref * gm.double()).sum().backward()
+    # HIP
+    m = m.to(hip_device)
+    a = {k: v.to(hip_device) for k, v in kw.items()}
+    a["cur_feats"].requires_grad_(True)
+    a["src_feats"].requires_grad_(True)
+    out = m(**a)
+    err = (out.detach().cpu().double() - ref.detach()).abs()
+    assert float(err.median()) < 1e-5 and int((err > 1e-4).sum()) <= max(2, err.numel() // 20000), (float(err.max()), int((err > 1e-4).sum()))
+    (out * gm.to(hip_device)).sum().backward()
+    net = m.mlp.net
+    pairs = [(a["cur_feats"].grad, cur_c.grad, "cur_feats"), (a["src_feats"].grad, src_c.grad, "src_feats"),
+             (net[0].weight.grad, mlp["w1"].grad, "w1"), (net[0].bias.grad, mlp["b1"].grad, "b1"),
+             (net[2].weight.grad, mlp["w2"].grad, "w2"), (net[2].bias.grad, mlp["b2"].grad, "b2"),
+             (net[4].weight.grad, mlp["w3"].grad, "w3"), (net[4].bias.grad, mlp["b3"].grad, "b3")]
+    bad = []
+    for got, want, name in pairs:
+        scale = want.abs().max().item() + 1e-30
+        e = (got.detach().cpu().double() - want).abs() / scale
+        if not (e.max().item() < 1e-3 and e.mean().item() < 1e-4):
+            bad.append((name, e.max().item(), e.mean().item()))
+    assert not bad, (case, form, bad)
+
+
+def test_backward_forms_agree_with_zero_features(hip_device, monkeypatch):
+    """All-zero current features at some pixels and an all-zero source region: the scores there are EXACTLY zero, the
+    source is not averaged, yet d dot / cnt (cnt = 1e-8 when no source counts) still reaches the current feature
+    (cost_volume.py:589-598).  The two-pass backward handles that in its re-gather branch: same gradients as the
+    one-kernel form."""
+    import inputs
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    V, K, h4, w4, D, C = 3, 2, 24, 32, 8, 48
+    torch.manual_seed(5)
+    m = AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C).to(hip_device)
+    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=77)
+    kw["cur_feats"][:, :, 5:9, 7:15] = 0.0
+    kw["src_feats"][:, 0, :, 10:20, 3:12] = 0.0
+    g = torch.randn(V, D, h4, w4, generator=torch.Generator().manual_seed(4)).to(hip_device)
+    res = {}
+    for form in ("two_pass", "atomic"):
+        if form == "atomic":
+            monkeypatch.setenv("FS_CV_BWD_ATOMIC", "1")
+        a = {k: v.to(hip_device) for k, v in kw.items()}
+        a["cur_feats"].requires_grad_(True)
+        a["src_feats"].requires_grad_(True)
+        m.zero_grad()
+        (m(**a) * g).sum().backward()
+        res[form] = [a["cur_feats"].grad.cpu(), a["src_feats"].grad.cpu()] + [p.grad.cpu().clone() for p in m.parameters()]
+    for x, y in zip(res["two_pass"], res["atomic"]):
+        scale = y.abs().max().item() + 1e-30
+        assert ((x - y).abs().max().item() / scale) < 1e-4
