@@ -13,10 +13,23 @@ fs_cost_volume_forward in libfreesplat_hip.so -- no torch fallback.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor, nn
 
 from . import _lib
+
+
+def save_activations(K: int) -> bool:
+    """Whether a training forward keeps the MLP's input of every (view, plane, pixel) point for the backward
+    (fs_cost_volume_forward_train: C + 2 floats per point, what autograd keeps of the averaged features) or the backward
+    gathers the K sources' taps again.  Measured (profiles/r4_cv_bwd_form_ab.txt, forward + backward): 10 views, K = 8:
+    17.2 ms saved vs 18.1 recomputed; config-3 scale, K = 2: 14.85 vs 14.55; native, K = 1: 1.52 vs 1.38 (the K = 1
+    inference sweep, which never forms the averaged features, is the faster forward) -- so by default only from K = 5 up.
+    FREESPLAT_CV_SAVE=1 / 0 (read at every call) forces either."""
+    e = os.environ.get("FREESPLAT_CV_SAVE", "")
+    return e != "0" if e in ("0", "1") else K >= 5
 
 
 class _Backprojector(nn.Module):
@@ -62,12 +75,24 @@ class _CostVolumeFn(torch.autograd.Function):
         ws = torch.empty(L.fs_cost_volume_workspace_bytes(B, K, C, h, w), dtype=torch.uint8, device=dev)
         out = torch.empty(B, D, h, w, dtype=torch.float32, device=dev)
         p = _lib.ptr
-        _lib.check(L.fs_cost_volume_forward(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
-                                            p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
-                                            p(w1), p(b1), p(w2), p(b2), p(w3), p(b3), p(ws), p(out),
-                                            _lib.current_stream()), "fs_cost_volume_forward")
+        # A backward will follow: with many sources per view the training forward keeps the MLP's input of every point and
+        # the backward starts from it instead of gathering all taps again (save_activations)
+        train = (torch.is_grad_enabled() and any(ctx.needs_input_grad) and strides[2] == 0 and K <= 16
+                 and save_activations(K))
+        if train:
+            saved = torch.empty(L.fs_cost_volume_saved_bytes(B, C, h, w, D), dtype=torch.uint8, device=dev)
+            _lib.check(L.fs_cost_volume_forward_train(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
+                                                      p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
+                                                      p(w1), p(b1), p(w2), p(b2), p(w3), p(b3), p(ws), p(out), p(saved),
+                                                      _lib.current_stream()), "fs_cost_volume_forward_train")
+        else:
+            saved = None
+            _lib.check(L.fs_cost_volume_forward(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
+                                                p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
+                                                p(w1), p(b1), p(w2), p(b2), p(w3), p(b3), p(ws), p(out),
+                                                _lib.current_stream()), "fs_cost_volume_forward")
         ctx.save_for_backward(cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, w1, b1, w2, b2, w3)
-        ctx.strides, ctx.D = strides, D
+        ctx.strides, ctx.D, ctx.saved = strides, D, saved
         return out
 
     @staticmethod
@@ -83,12 +108,21 @@ class _CostVolumeFn(torch.autograd.Function):
         d_w1, d_b1, d_w2, d_b2, d_w3, d_b3 = e(32, C + 1), e(32), e(32, 32), e(32), e(1, 32), e(1)
         p = _lib.ptr
         g_ = g.contiguous()
-        _lib.check(L.fs_cost_volume_backward(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
-                                             p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
-                                             p(w1.detach()), p(b1.detach()), p(w2.detach()), p(b2.detach()),
-                                             p(w3.detach()), p(g_), p(ws), p(d_cur), p(d_src), p(d_w1), p(d_b1),
-                                             p(d_w2), p(d_b2), p(d_w3), p(d_b3), _lib.current_stream()),
-                   "fs_cost_volume_backward")
+        if ctx.saved is not None:
+            _lib.check(L.fs_cost_volume_backward_train(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
+                                                       p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
+                                                       p(w1.detach()), p(b1.detach()), p(w2.detach()), p(b2.detach()),
+                                                       p(w3.detach()), p(g_), p(ws), p(ctx.saved), p(d_cur), p(d_src),
+                                                       p(d_w1), p(d_b1), p(d_w2), p(d_b2), p(d_w3), p(d_b3),
+                                                       _lib.current_stream()), "fs_cost_volume_backward_train")
+            ctx.saved = None
+        else:
+            _lib.check(L.fs_cost_volume_backward(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
+                                                 p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
+                                                 p(w1.detach()), p(b1.detach()), p(w2.detach()), p(b2.detach()),
+                                                 p(w3.detach()), p(g_), p(ws), p(d_cur), p(d_src), p(d_w1), p(d_b1),
+                                                 p(d_w2), p(d_b2), p(d_w3), p(d_b3), _lib.current_stream()),
+                       "fs_cost_volume_backward")
         # (every gradient, the MLP's included, comes out of the one kernel: no per-point workspace, no GEMMs here)
         return d_cur, d_src, None, None, None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
 

@@ -209,14 +209,18 @@ __global__ __launch_bounds__(256) void cv_transpose_kernel(const float* __restri
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int C>
+// SAVE (training forward): the MLP's input of every (pixel, plane) point -- the averaged warped features x = favg / cnt,
+// the averaged score and the sources' (valid, in-front) bits -- is kept for the backward, which then starts from it
+// instead of gathering K x 4 taps again (chunk-planar in the backward's channel order: cost_volume_bwd_kernel).
+template <int C, bool SAVE>
 __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
     int B, int K, int h, int w, int D, int slices, const float* __restrict__ curN, const float* __restrict__ srcN,
     const float* __restrict__ Pmat,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
     long long ps_d, long long ps_p, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
-    const float* __restrict__ b3, float* __restrict__ out)
+    const float* __restrict__ b3, float* __restrict__ out, float* __restrict__ xs, float2* __restrict__ xm,
+    uint32_t* __restrict__ xhdr)
 {
     constexpr int NS = C / 16;          // tap load instructions (float4 per lane each)
     constexpr int NR = C / 4;           // channels per lane
@@ -298,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
 #pragma unroll
         for (int r = 0; r < NR; ++r) favg[r] = 0.0f;
         float dot_sum = 0.0f, cnt = 0.0f;
+        uint32_t flags = 0;   // SAVE: bit 2k = source k valid (dot != 0), bit 2k+1 = in front of it (z > 0)
         auto one_source = [&](int k, const float* P) __attribute__((always_inline)) {
             // world point = depth * r (homogeneous 1): geometry_utils.py:56-58
             const float X = depth * rx, Y = depth * ry, Z = depth * rz;
@@ -349,7 +354,14 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
             part += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(part), 0xB1, 0xF, 0xF, true));   // lane ^ 1
             part += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(part), 0x4E, 0xF, 0xF, true));   // lane ^ 2
             const float dotk = (zz > 0.0f) ? part : 0.0f;                 // cost_volume.py:571-572,589-593
+            if (SAVE) {
+                flags |= (zz > 0.0f ? 2u : 0u) << (2 * k);
+                // in front, some tap inside the source image, and still an exactly zero score (all-zero features): the
+                // backward must re-gather such a source (cost_volume_bwd_kernel); flagged once per call, practically never
+                if (live && zz > 0.0f && dotk == 0.0f && (xin0 || xin1) && (yin0 || yin1) && c == 0) atomicOr(xhdr, 1u);
+            }
             if (dotk != 0.0f) {                                           // :595 (exact zero test)
+                if (SAVE) flags |= 1u << (2 * k);
                 cnt += 1.0f;
                 dot_sum += dotk;
 #pragma unroll
@@ -361,6 +373,18 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
         for (int k = 2; k < K; ++k) one_source(k, Pmat + ((size_t)b * K + k) * 12);
         const float inv = 1.0f / (cnt + 1e-8f);                          // :595-598
         FS_CV_T(t_gath, favg[0] + favg[NR - 1] + inv + dot_sum);
+        if (SAVE && live) {
+            // channel 16 s + 4 c + i = parity i & 1, slot 8 s + 2 c + (i >> 1): float4 chunk 2 s + (c >> 1) of that parity's
+            // C/8 chunks, elements 2 (c & 1) + {0, 1}: two lanes of a quad fill one float4, 16 pixels are 256 contiguous bytes
+            const size_t pl = (size_t)b * D + d;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    *(float2*)(xs + ((pl * (C / 4) + (size_t)hf * (C / 8) + 2 * s + (c >> 1)) * hw + pix) * 4 + 2 * (c & 1)) =
+                        make_float2(favg[4 * s + hf] * inv, favg[4 * s + 2 + hf] * inv);
+            if (c == 0) xm[pl * hw + pix] = make_float2(dot_sum * inv, __uint_as_float(flags));
+        }
         // ---- to the operand order: lane (n, g) takes quarter g of pixel n ----
         float xm[NT];
 #pragma unroll
@@ -713,7 +737,7 @@ __device__ __forceinline__ constexpr int row_half(int i) { return (i >> 2) & 1; 
 //     adds the 16 entries of its unit that it reads as MFMA operands) and of a half-height tile of g * h2 (neighbouring
 //     pixels pre-added with one DPP step) -- two accumulators instead of 32, and z2 is dead as soon as it is computed;
 //   * dW2 and dW1 are accumulated in two phases that share the dz tile (dz2, then dz1); lrelu'(z1) is kept as a bit mask.
-template <int HC, bool SPLIT>
+template <int HC, bool SPLIT, bool SAVED>
 __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
     int B, int K, int h, int w, int D, int slices, const float* __restrict__ curT, const float* __restrict__ srcT,
     const float* __restrict__ Pmat,
@@ -722,8 +746,10 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
     const float* __restrict__ g_out, float* __restrict__ d_curT, float* __restrict__ d_srcT,
     float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
-    float* __restrict__ gw3, float* __restrict__ gb3, float4* __restrict__ recS, float2* __restrict__ recM)
+    float* __restrict__ gw3, float* __restrict__ gb3, float4* __restrict__ recS, float2* __restrict__ recM,
+    const float4* __restrict__ xs, const float2* __restrict__ xm, const uint32_t* __restrict__ xhdr)
 {
+    static_assert(SPLIT || !SAVED, "the saved-activation backward exists in the two-pass form only");
     constexpr int C = 2 * HC;
     constexpr int NBLK = (HC + 1 + 15) / 16;  // row blocks of the permuted W1^T
     constexpr int XW = 2 * (HC + 1);          // features of a point: C channels, dot, 1
@@ -810,8 +836,32 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
         // ---- forward recompute ----
         f32x16 z1;
         float inv, xlast;
-        uint32_t flags = 0, rare = 0;   // SPLIT: bit 2k = source k valid (dot != 0), bit 2k+1 = in front of it (z > 0)
-        {
+        uint32_t flags = 0, rare = 0;   // SPLIT: bit 2k = source k valid (dot != 0), bit 2k+1 = in front of it (z > 0); rare: bit 2k
+        if (SAVED) {
+            // the training forward kept the MLP's input of this point (cost_volume16_kernel<C, true>): no gather at all
+            const size_t pl = (size_t)b * D + d;
+            const float2 mt = live ? xm[pl * hw + pix] : make_float2(0.0f, 0.0f);
+            flags = __float_as_uint(mt.y);
+            inv = 1.0f / ((float)__builtin_popcount(flags & 0x55555555u) + 1e-8f);
+            xlast = hf ? 1.0f : mt.x;
+            if (xhdr[0] != 0u) rare = (flags >> 1) & ~flags & 0x55555555u;   // in front but not averaged: re-gathered below
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z1[r] = 0.0f;
+            const float4* xp = xs + (pl * (C / 4) + (size_t)hf * (HC / 4)) * hw + (live ? pix : 0);
+#pragma unroll
+            for (int s4 = 0; s4 < HC / 4; ++s4) {
+                const float4 v4 = live ? xp[(size_t)s4 * hw] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const float xv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = 4 * s4 + i;
+                    tx[p * XS + 2 * s + hf] = xv[i];
+                    z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + 2 * s + hf], xv[i], z1, 0, 0, 0);
+                }
+            }
+            tx[p * XS + C + hf] = xlast;
+            z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + C + hf], xlast, z1, 0, 0, 0);
+        } else {
             float favg[HC];
 #pragma unroll
             for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
@@ -828,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
                     flags |= (W.zz > 0.0f ? 2u : 0u) << (2 * k);
                     // in front, some tap inside the source image, and still an exactly zero score (all-zero features): the
                     // score's gradient reaches the current feature although the source is not averaged -- see below
-                    if (W.zz > 0.0f && dotk == 0.0f && (W.ok[0] || W.ok[1] || W.ok[2] || W.ok[3])) rare |= 1u << k;
+                    if (W.zz > 0.0f && dotk == 0.0f && (W.ok[0] || W.ok[1] || W.ok[2] || W.ok[3])) rare |= 1u << (2 * k);
                 }
                 if (dotk != 0.0f) {
                     if (SPLIT) flags |= 1u << (2 * k);
@@ -962,10 +1012,10 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
             //  averaged but still passes d dot / cnt on: re-gather those, wave-uniformly; never taken on real data)
             if (__builtin_amdgcn_ballot_w64(rare != 0u) != 0ull) {
                 for (int k = 0; k < K; ++k) {
-                    if (__builtin_amdgcn_ballot_w64(((rare >> k) & 1u) != 0u) == 0ull) continue;
+                    if (__builtin_amdgcn_ballot_w64(((rare >> (2 * k)) & 1u) != 0u) == 0ull) continue;
                     warp_source<HC>(W, srcT + (((size_t)b * K + k) * hw) * C, w, h, hf, live, depth, rx, ry, rz,
                                      Pmat + ((size_t)b * K + k) * 12, inv_w, inv_h);
-                    const float cd = ((rare >> k) & 1u) ? inv * ddot : 0.0f;
+                    const float cd = ((rare >> (2 * k)) & 1u) ? inv * ddot : 0.0f;
 #pragma unroll
                     for (int s = 0; s < HC; ++s) dcur[s] = fmaf(cd, W.wv[s], dcur[s]);
                 }
@@ -1472,13 +1522,23 @@ FS_API size_t fs_cost_volume_workspace_bytes(int32_t B, int32_t K, int32_t C, in
     return align_up(((size_t)B * C + (size_t)B * K * (C + 2 * kCvU)) * h * w * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256);
 }
 
-FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
-                                  const float* cur_feats, const float* src_feats,
-                                  const float* src_extrinsics, const float* src_Ks,
-                                  const float* cur_invK, const float* planes, int64_t plane_stride_b,
-                                  int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
-                                  const float* b1, const float* w2, const float* b2, const float* w3,
-                                  const float* b3, void* workspace, float* out, void* stream_)
+// layout of the training forward's `saved` buffer: a 256-byte header (word 0: some source had an exactly zero score with
+// taps inside its image), then x = favg / cnt as [B*D][C/4 float4 chunks][h*w] (parity-major chunks: the backward's
+// channel order), then (averaged score, validity bits) as [B*D][h*w] float2
+static inline size_t cv_saved_xs_bytes(int B, int C, int h, int w, int D) { return align_up((size_t)B * D * h * w * C * sizeof(float), 256); }
+FS_API size_t fs_cost_volume_saved_bytes(int32_t B, int32_t C, int32_t h, int32_t w, int32_t D)
+{
+    if (B <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return 0;
+    return 256 + cv_saved_xs_bytes(B, C, h, w, D) + align_up((size_t)B * D * h * w * 2 * sizeof(float), 256);
+}
+
+static int cv_forward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                           const float* cur_feats, const float* src_feats,
+                           const float* src_extrinsics, const float* src_Ks,
+                           const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                           int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                           const float* b1, const float* w2, const float* b2, const float* w3,
+                           const float* b3, void* workspace, float* out, void* saved, void* stream_)
 {
     if (B <= 0 || K <= 0 || h <= 0 || w <= 0 || D <= 0) return FS_ERR_INVALID_ARG;
     if (!cur_feats || !src_feats || !src_extrinsics || !src_Ks || !cur_invK || !planes || !w1 || !b1 ||
@@ -1498,7 +1558,7 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
         const int groups = (hw + 31) / 32;
         const int slices = cv_plane_split(B, groups, D);
         const dim3 grid(cv_grid(B, groups, slices));
-        if (cv_use_projected(K)) {
+        if (!saved && cv_use_projected(K)) {
             // K = 1: first layer's feature block applied per source texel, 16 MFMAs per (group, plane); two launches
             // (the sweep reads the current view from the caller's map and forms its projection rows itself)
             const unsigned gproj = (unsigned)std::min<long long>(((long long)B * K * hw * 8 + 255) / 256, 65536);
@@ -1523,18 +1583,51 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
                                dim3(256), 0, st, cur_feats, curT, C, hw, B);
             hipLaunchKernelGGL(cv_transpose_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
                                dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
-            if (C == 48)
-                hipLaunchKernelGGL(cost_volume16_kernel<48>, grid16, dim3(256), 0, st, B, K, h, w, D, slices16, curT, srcT, Pmat,
+            // (training: the general sweep for every K -- it forms the averaged features the backward wants to keep; the
+            //  K = 1 projected sweep never does)
+            uint32_t* xhdr = (uint32_t*)saved;
+            float* xs = saved ? (float*)((char*)saved + 256) : nullptr;
+            float2* xm = saved ? (float2*)((char*)saved + 256 + cv_saved_xs_bytes(B, C, h, w, D)) : nullptr;
+            if (saved && hipMemsetAsync(saved, 0, 256, st) != hipSuccess) {
+                set_last_error("cost volume saved header", hipGetLastError());
+                return FS_ERR_LAUNCH;
+            }
+            auto sweep16 = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, grid16, dim3(256), 0, st, B, K, h, w, D, slices16, curT, srcT, Pmat,
                                    cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
-                                   (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out);
-            else
-                hipLaunchKernelGGL(cost_volume16_kernel<16>, grid16, dim3(256), 0, st, B, K, h, w, D, slices16, curT, srcT, Pmat,
-                                   cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
-                                   (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out);
+                                   (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out, xs, xm, xhdr);
+            };
+            if (C == 48) { if (saved) sweep16(cost_volume16_kernel<48, true>); else sweep16(cost_volume16_kernel<48, false>); }
+            else { if (saved) sweep16(cost_volume16_kernel<16, true>); else sweep16(cost_volume16_kernel<16, false>); }
         }
     }
     FS_CHECK_LAUNCH("cost_volume");
     return FS_OK;
+}
+
+FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                  const float* cur_feats, const float* src_feats,
+                                  const float* src_extrinsics, const float* src_Ks,
+                                  const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                                  int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* w3,
+                                  const float* b3, void* workspace, float* out, void* stream_)
+{
+    return cv_forward_impl(B, K, C, h, w, D, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, plane_stride_b,
+                           plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, b3, workspace, out, nullptr, stream_);
+}
+
+FS_API int fs_cost_volume_forward_train(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                        const float* cur_feats, const float* src_feats,
+                                        const float* src_extrinsics, const float* src_Ks,
+                                        const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                                        int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                                        const float* b1, const float* w2, const float* b2, const float* w3,
+                                        const float* b3, void* workspace, float* out, void* saved, void* stream_)
+{
+    if (!saved) return FS_ERR_INVALID_ARG;
+    return cv_forward_impl(B, K, C, h, w, D, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, plane_stride_b,
+                           plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, b3, workspace, out, saved, stream_);
 }
 
 FS_API size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w,
@@ -1558,15 +1651,15 @@ static bool cv_bwd_two_pass(int K, int64_t plane_stride_pix)
     return plane_stride_pix == 0 && K <= 16;
 }
 
-FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
-                                   const float* cur_feats, const float* src_feats,
-                                   const float* src_extrinsics, const float* src_Ks,
-                                   const float* cur_invK, const float* planes, int64_t plane_stride_b,
-                                   int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
-                                   const float* b1, const float* w2, const float* b2, const float* w3,
-                                   const float* grad_out, void* workspace, float* d_cur_feats,
-                                   float* d_src_feats, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
-                                   float* d_w3, float* d_b3, void* stream_)
+static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                            const float* cur_feats, const float* src_feats,
+                            const float* src_extrinsics, const float* src_Ks,
+                            const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                            int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                            const float* b1, const float* w2, const float* b2, const float* w3,
+                            const float* grad_out, void* workspace, float* d_cur_feats,
+                            float* d_src_feats, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                            float* d_w3, float* d_b3, const void* saved, void* stream_)
 {
     if (B <= 0 || K <= 0 || h <= 0 || w <= 0 || D <= 0) return FS_ERR_INVALID_ARG;
     if (!cur_feats || !src_feats || !src_extrinsics || !src_Ks || !cur_invK || !planes || !w1 || !b1 || !w2 ||
@@ -1587,6 +1680,10 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
     float2* recM = (float2*)((char*)recS + align_up((size_t)B * D * hw * C * sizeof(float), 256));
     float* Ginv = (float*)((char*)recM + align_up((size_t)B * D * hw * 2 * sizeof(float), 256));
     const bool two_pass = cv_bwd_two_pass(K, plane_stride_pix);
+    if (!two_pass) saved = nullptr;   // (the one-kernel scatter form needs every source's taps: it recomputes the forward)
+    const uint32_t* xhdr = (const uint32_t*)saved;
+    const float4* xs = saved ? (const float4*)((const char*)saved + 256) : nullptr;
+    const float2* xm = saved ? (const float2*)((const char*)saved + 256 + cv_saved_xs_bytes(B, C, h, w, D)) : nullptr;
     const int tiles_x = (w + kSgTW - 1) / kSgTW, tiles_y = (h + kSgTH - 1) / kSgTH, tiles = tiles_x * tiles_y;
     // plane chunks of the source-tile sweep: one (plain stores) when there are enough tiles to fill the chip (256 CUs x
     // 11 single-wavefront workgroups), else enough chunks for one full round (their tiles then leave through atomics
@@ -1622,7 +1719,7 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
         hipLaunchKernelGGL(kernel, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
-                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM);
+                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM, xs, xm, xhdr);
     };
     auto tile_sweep = [&](auto kernel) {
         const unsigned grid = 8u * (unsigned)B * (unsigned)((tiles + 7) >> 3) * (unsigned)K * (unsigned)chunks;
@@ -1631,13 +1728,49 @@ FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, i
                            (long long)plane_stride_d, d_src_feats);
     };
     if (two_pass) {
-        if (C == 48) { sweep(cost_volume_bwd_kernel<24, true>); tile_sweep(cv_src_grad_kernel<48>); }
-        else { sweep(cost_volume_bwd_kernel<8, true>); tile_sweep(cv_src_grad_kernel<16>); }
+        if (C == 48) {
+            if (saved) sweep(cost_volume_bwd_kernel<24, true, true>); else sweep(cost_volume_bwd_kernel<24, true, false>);
+            tile_sweep(cv_src_grad_kernel<48>);
+        } else {
+            if (saved) sweep(cost_volume_bwd_kernel<8, true, true>); else sweep(cost_volume_bwd_kernel<8, true, false>);
+            tile_sweep(cv_src_grad_kernel<16>);
+        }
     } else {
-        if (C == 48) sweep(cost_volume_bwd_kernel<24, false>); else sweep(cost_volume_bwd_kernel<8, false>);
+        if (C == 48) sweep(cost_volume_bwd_kernel<24, false, false>); else sweep(cost_volume_bwd_kernel<8, false, false>);
         hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_src), dim3(256), 0, st, d_srcT, d_src_feats, C, hw, B * K);
     }
     hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_cur), dim3(256), 0, st, d_curT, d_cur_feats, C, hw, B);
     FS_CHECK_LAUNCH("cost_volume_backward");
     return FS_OK;
+}
+
+FS_API int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                   const float* cur_feats, const float* src_feats,
+                                   const float* src_extrinsics, const float* src_Ks,
+                                   const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                                   int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                                   const float* b1, const float* w2, const float* b2, const float* w3,
+                                   const float* grad_out, void* workspace, float* d_cur_feats,
+                                   float* d_src_feats, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                   float* d_w3, float* d_b3, void* stream_)
+{
+    return cv_backward_impl(B, K, C, h, w, D, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, plane_stride_b,
+                            plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, grad_out, workspace, d_cur_feats, d_src_feats,
+                            d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, nullptr, stream_);
+}
+
+FS_API int fs_cost_volume_backward_train(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                         const float* cur_feats, const float* src_feats,
+                                         const float* src_extrinsics, const float* src_Ks,
+                                         const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                                         int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                                         const float* b1, const float* w2, const float* b2, const float* w3,
+                                         const float* grad_out, void* workspace, const void* saved, float* d_cur_feats,
+                                         float* d_src_feats, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                         float* d_w3, float* d_b3, void* stream_)
+{
+    if (!saved) return FS_ERR_INVALID_ARG;
+    return cv_backward_impl(B, K, C, h, w, D, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, plane_stride_b,
+                            plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, grad_out, workspace, d_cur_feats, d_src_feats,
+                            d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, saved, stream_);
 }

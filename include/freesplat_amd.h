@@ -44,7 +44,7 @@ const char* fs_version(void);
  * it right after loading the library (freesplat_amd/_lib.py does): a stale build would otherwise accept calls with
  * shifted pointers.  3 = round 3 (single-pass binning: scratch = per-tile key areas, counters[1] = largest tile list on
  * overflow, geom without the mask / depth arrays; fused sort + blend). */
-#define FS_ABI_VERSION 3
+#define FS_ABI_VERSION 4
 int fs_abi_version(void);
 /* Last HIP error string observed by a failing call on this thread (never NULL). */
 const char* fs_last_error(void);
@@ -203,6 +203,22 @@ int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
                            const float* w2, const float* b2, const float* w3, const float* b3,
                            void* workspace, float* out, void* stream);
 
+/*
+ * Training forward: fs_cost_volume_forward plus `saved` (fs_cost_volume_saved_bytes) -- the MLP's input of every (view,
+ * plane, pixel) point (the C averaged warped features, the averaged score, the sources' validity bits: C + 2 floats per
+ * point), which fs_cost_volume_backward_train starts from instead of gathering the K sources' taps again.  This is what
+ * autograd keeps of cost_volume.py:506-615 (which retains every plane's warped [B*K,C,h,w] features: 8 times more at
+ * K = 8).  Same output bits as fs_cost_volume_forward's general sweep (FS_CV_PROJECTED=0).
+ */
+size_t fs_cost_volume_saved_bytes(int32_t B, int32_t C, int32_t h, int32_t w, int32_t D);
+int fs_cost_volume_forward_train(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                 const float* cur_feats, const float* src_feats,
+                                 const float* src_extrinsics, const float* src_Ks, const float* cur_invK,
+                                 const float* planes, int64_t plane_stride_b, int64_t plane_stride_d,
+                                 int64_t plane_stride_pix, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, const float* w3, const float* b3,
+                                 void* workspace, float* out, void* saved, void* stream);
+
 size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w,
                                                int32_t D);
 
@@ -210,9 +226,12 @@ size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int32_t C, 
  * Backward of fs_cost_volume_forward w.r.t. the features and the MLP.  grad_out[B,D,h,w] ->
  * d_cur_feats[B,C,h,w], d_src_feats[B,K,C,h,w] and ALL six parameter gradients d_w1[32,C+1], d_b1[32],
  * d_w2[32,32], d_b2[32], d_w3[32], d_b3[1] (everything overwritten).  The weight gradients -- sums of outer products
- * over all B*D*h*w points -- are accumulated on the matrix cores inside the kernel; the workspace
- * (fs_cost_volume_backward_workspace_bytes: pixel-major copies of the feature maps and of their gradients) does not
- * depend on D.
+ * over all B*D*h*w points -- are accumulated on the matrix cores inside the kernel.  With plane depths that do not vary
+ * per pixel (plane_stride_pix == 0: the module's generated planes) and K <= 16 the backward runs in TWO passes with no
+ * global float atomics on the source maps: the first writes one record of C + 2 floats per (view, plane, pixel) into the
+ * workspace (fs_cost_volume_backward_workspace_bytes therefore grows with D), the second owns tiles of source texels and
+ * collects from the pixels that sample them through the inverse plane homography.  Otherwise (per-pixel planes, K > 16,
+ * or FS_CV_BWD_ATOMIC=1) one kernel scatters with float atomics.
  */
 int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
                             const float* cur_feats, const float* src_feats,
@@ -222,6 +241,17 @@ int fs_cost_volume_backward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
                             const float* w2, const float* b2, const float* w3, const float* grad_out,
                             void* workspace, float* d_cur_feats, float* d_src_feats, float* d_w1,
                             float* d_b1, float* d_w2, float* d_b2, float* d_w3, float* d_b3, void* stream);
+
+/* The same from the `saved` buffer of fs_cost_volume_forward_train (same call arguments): no forward recompute. */
+int fs_cost_volume_backward_train(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                  const float* cur_feats, const float* src_feats,
+                                  const float* src_extrinsics, const float* src_Ks, const float* cur_invK,
+                                  const float* planes, int64_t plane_stride_b, int64_t plane_stride_d,
+                                  int64_t plane_stride_pix, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, const float* w3, const float* grad_out,
+                                  void* workspace, const void* saved, float* d_cur_feats, float* d_src_feats,
+                                  float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3, float* d_b3,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * Pixel-wise Triplet Fusion: matching step                                              *

@@ -1,5 +1,6 @@
-"""Same-session A/B of the two forms of the cost-volume backward (two-pass records + source-tile sweep vs the one-kernel
-atomic scatter, FS_CV_BWD_ATOMIC=1) on the three benchmarked shapes; one subprocess per form, twice, interleaved.
+"""Same-session A/B of the three forms of the cost-volume training step (saved: training forward keeps the MLP inputs +
+two-pass backward; two_pass: the backward recomputes the forward, FREESPLAT_CV_SAVE=0; atomic: the one-kernel atomic
+scatter, FS_CV_BWD_ATOMIC=1) on the three benchmarked shapes; one subprocess per form, twice, interleaved.
    python profiles/tools/cv_bwd_form_ab.py [workload ...]        (native_K1 c3scale_K2 fvt10_K8)
 With CV_ONE=<workload> it runs ONE training step loop of that workload in-process (for rocprofv3)."""
 import json
@@ -36,7 +37,8 @@ if __name__ == "__main__":
         kw.pop("steps"); kw.pop("warmup")
         print(b.bench_cost_volume(torch.device("cuda:0"), 4, 1, cpu=False, **kw)["train_fwd_bwd"])
         sys.exit(0)
-    for tag, val in (("two_pass", "0"), ("atomic", "1")) * 2:
-        p = subprocess.run([sys.executable, "-c", CODE], env=dict(env0, FS_CV_BWD_ATOMIC=val), capture_output=True, text=True, cwd=ROOT)
+    for tag, atomic, save in (("default", "0", ""), ("saved", "0", "1"), ("two_pass", "0", "0"), ("atomic", "1", "0")) * 2:
+        p = subprocess.run([sys.executable, "-c", CODE], env=dict(env0, FS_CV_BWD_ATOMIC=atomic, FREESPLAT_CV_SAVE=save),
+                           capture_output=True, text=True, cwd=ROOT)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
         print(tag, line[-1][7:] if line else p.stderr[-800:], "(forward ms per call, fwd+bwd ms)", flush=True)

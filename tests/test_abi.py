@@ -140,17 +140,22 @@ def test_every_entry_point_validates_its_arguments_before_touching_a_device():
 def test_workspace_size_queries():
     """The size queries a caller allocates from (host logic, no GPU): the cost volume's forward workspace holds the
     current view's [hw, C] copy, the sources' [hw, C + 32] records (features + the projected first-layer block of the
-    K = 1 sweep) and the projection rows; the backward's holds the pixel-major copies and their gradients and does NOT
-    grow with the plane count; the PTF sizes are monotone in their arguments; nonsense arguments give 0."""
+    K = 1 sweep) and the projection rows; the backward's holds the pixel-major copies and their gradients, the two-pass
+    form's records (C + 2 floats per (view, plane, pixel)) and the inverse plane homographies; the training forward's
+    saved buffer a header and C + 2 floats per point; the PTF sizes are monotone in their arguments; nonsense arguments
+    give 0."""
     from freesplat_amd import _lib
     L = _lib.lib()
     al = lambda x: (x + 255) // 256 * 256
     for B, K, C, h, w in ((2, 1, 48, 96, 128), (3, 2, 48, 242, 324), (10, 8, 48, 96, 128), (3, 2, 16, 13, 19)):
         hw = h * w
         assert L.fs_cost_volume_workspace_bytes(B, K, C, h, w) == al((B * C + B * K * (C + 32)) * hw * 4) + al(B * K * 12 * 4)
-        b8 = L.fs_cost_volume_backward_workspace_bytes(B, K, C, h, w, 8)
-        assert b8 == al(B * (1 + K) * C * hw * 2 * 4) + al(B * K * 12 * 4)
-        assert L.fs_cost_volume_backward_workspace_bytes(B, K, C, h, w, 128) == b8
+        for D in (8, 128):
+            bD = L.fs_cost_volume_backward_workspace_bytes(B, K, C, h, w, D)
+            assert bD == (al(B * (1 + K) * C * hw * 2 * 4) + al(B * K * 12 * 4) + al(B * D * hw * C * 4) + al(B * D * hw * 2 * 4)
+                          + al(B * K * D * 9 * 4))
+            assert L.fs_cost_volume_saved_bytes(B, C, h, w, D) == 256 + al(B * D * hw * C * 4) + al(B * D * hw * 2 * 4)
+    assert L.fs_cost_volume_saved_bytes(0, 48, 8, 8, 8) == 0
     assert L.fs_cost_volume_workspace_bytes(1, 1, 0, 8, 8) == 0 and L.fs_cost_volume_backward_workspace_bytes(0, 1, 48, 8, 8, 8) == 0
     prev = 0
     for V in (2, 3, 10, 30):

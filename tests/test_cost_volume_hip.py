@@ -216,20 +216,32 @@ BWD_CASES = {
 }
 
 
-@pytest.mark.parametrize("form", ["two_pass", "atomic"])
+_ORACLE_CACHE = {}
+
+
+def _set_form(monkeypatch, form):
+    """saved: the training forward keeps the MLP's inputs (FREESPLAT_CV_SAVE=1; the default from K = 5 sources up),
+    two-pass backward; two_pass: the backward recomputes the forward (FREESPLAT_CV_SAVE=0); atomic: the one-kernel
+    scatter form (FS_CV_BWD_ATOMIC=1)."""
+    monkeypatch.setenv("FREESPLAT_CV_SAVE", "1" if form == "saved" else "0")
+    if form == "atomic":
+        monkeypatch.setenv("FS_CV_BWD_ATOMIC", "1")
+
+
 @pytest.mark.parametrize("case", list(BWD_CASES))
+@pytest.mark.parametrize("form", ["saved", "two_pass", "atomic"])
 def test_backward_tight_vs_float64_oracle(hip_device, case, form, monkeypatch):
     """Every gradient of the volume (both feature maps, the six MLP tensors) against autograd of the reference-pinned
     oracle run in float64, at K = 8, K = 2, a turned-round source, C = 16 and the native 96x128 / D = 128 size, with the
     discontinuity points masked out of grad_out (identically on both sides): <= 1e-3 of max-abs everywhere, <= 1e-4 on
-    average, for every tensor.  Both forms of the backward: the two-pass one (records + source-tile sweep, no global float
-    atomics; the default) and the one-kernel scatter it replaced (FS_CV_BWD_ATOMIC=1)."""
+    average, for every tensor.  All three forms of the backward: from the training forward's saved MLP inputs, with the
+    forward recomputed (both two-pass: records + source-tile sweep, no global float atomics), and the
+    one-kernel scatter they replaced (FS_CV_BWD_ATOMIC=1)."""
     import inputs
     from oracle import cost_volume_oracle as cvo
     from freesplat_amd.cost_volume import AVGFeatureVolumeManager
     V, K, h4, w4, D, C, behind, views = BWD_CASES[case]
-    if form == "atomic":
-        monkeypatch.setenv("FS_CV_BWD_ATOMIC", "1")
+    _set_form(monkeypatch, form)
     torch.manual_seed(V * 10 + K)
     m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
                                 mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
@@ -238,32 +250,36 @@ def test_backward_tight_vs_float64_oracle(hip_device, case, form, monkeypatch):
     kw = {k: (v[vs] if k not in ("min_depth", "max_depth") else v) for k, v in kw.items()}
     B = len(vs)
     g = torch.randn(B, D, h4, w4, generator=torch.Generator().manual_seed(3))
-    # float64 oracle + autograd on the CPU
-    torch.set_num_threads(os.cpu_count() or 1)
-    dbl = lambda t: t.double()
-    cur_c = dbl(kw["cur_feats"]).requires_grad_(True)
-    src_c = dbl(kw["src_feats"]).requires_grad_(True)
-    mlp = {k: v.detach().double().requires_grad_(True) for k, v in
-           cvo.mlp_from_state({k.replace(".", "__"): v for k, v in m.state_dict().items()}).items()}
-    ref, aux = cvo.cost_volume(cur_c, src_c, dbl(kw["src_extrinsics"]), dbl(kw["src_Ks"]), dbl(kw["cur_invK"]),
-                               kw["min_depth"], kw["max_depth"], D, mlp, return_pre=True)
-    gm, n_masked = _masked_grad_out({k: v.detach() for k, v in aux.items()}, g, h4, w4)
-    assert n_masked < 0.05 * g.numel(), n_masked
-    (ref * gm.double()).sum().backward()
+    # float64 oracle + autograd on the CPU (once per case: the three forms share it)
+    if case not in _ORACLE_CACHE:
+        torch.set_num_threads(os.cpu_count() or 1)
+        dbl = lambda t: t.double()
+        cur_c = dbl(kw["cur_feats"]).requires_grad_(True)
+        src_c = dbl(kw["src_feats"]).requires_grad_(True)
+        mlp = {k: v.detach().double().requires_grad_(True) for k, v in
+               cvo.mlp_from_state({k.replace(".", "__"): v for k, v in m.state_dict().items()}).items()}
+        ref, aux = cvo.cost_volume(cur_c, src_c, dbl(kw["src_extrinsics"]), dbl(kw["src_Ks"]), dbl(kw["cur_invK"]),
+                                   kw["min_depth"], kw["max_depth"], D, mlp, return_pre=True)
+        gm, n_masked = _masked_grad_out({k: v.detach() for k, v in aux.items()}, g, h4, w4)
+        assert n_masked < 0.05 * g.numel(), n_masked
+        (ref * gm.double()).sum().backward()
+        _ORACLE_CACHE.clear()       # (one case at a time: the native one holds a few hundred MB)
+        _ORACLE_CACHE[case] = (ref.detach(), gm, cur_c.grad, src_c.grad, {k: v.grad for k, v in mlp.items()})
+    ref, gm, cur_g, src_g, mlp_g = _ORACLE_CACHE[case]
     # HIP
     m = m.to(hip_device)
     a = {k: v.to(hip_device) for k, v in kw.items()}
     a["cur_feats"].requires_grad_(True)
     a["src_feats"].requires_grad_(True)
     out = m(**a)
-    err = (out.detach().cpu().double() - ref.detach()).abs()
+    err = (out.detach().cpu().double() - ref).abs()
     assert float(err.median()) < 1e-5 and int((err > 1e-4).sum()) <= max(2, err.numel() // 20000), (float(err.max()), int((err > 1e-4).sum()))
     (out * gm.to(hip_device)).sum().backward()
     net = m.mlp.net
-    pairs = [(a["cur_feats"].grad, cur_c.grad, "cur_feats"), (a["src_feats"].grad, src_c.grad, "src_feats"),
-             (net[0].weight.grad, mlp["w1"].grad, "w1"), (net[0].bias.grad, mlp["b1"].grad, "b1"),
-             (net[2].weight.grad, mlp["w2"].grad, "w2"), (net[2].bias.grad, mlp["b2"].grad, "b2"),
-             (net[4].weight.grad, mlp["w3"].grad, "w3"), (net[4].bias.grad, mlp["b3"].grad, "b3")]
+    pairs = [(a["cur_feats"].grad, cur_g, "cur_feats"), (a["src_feats"].grad, src_g, "src_feats"),
+             (net[0].weight.grad, mlp_g["w1"], "w1"), (net[0].bias.grad, mlp_g["b1"], "b1"),
+             (net[2].weight.grad, mlp_g["w2"], "w2"), (net[2].bias.grad, mlp_g["b2"], "b2"),
+             (net[4].weight.grad, mlp_g["w3"], "w3"), (net[4].bias.grad, mlp_g["b3"], "b3")]
     bad = []
     for got, want, name in pairs:
         scale = want.abs().max().item() + 1e-30
@@ -276,8 +292,8 @@ def test_backward_tight_vs_float64_oracle(hip_device, case, form, monkeypatch):
 def test_backward_forms_agree_with_zero_features(hip_device, monkeypatch):
     """All-zero current features at some pixels and an all-zero source region: the scores there are EXACTLY zero, the
     source is not averaged, yet d dot / cnt (cnt = 1e-8 when no source counts) still reaches the current feature
-    (cost_volume.py:589-598).  The two-pass backward handles that in its re-gather branch: same gradients as the
-    one-kernel form."""
+    (cost_volume.py:589-598).  The two-pass backward handles that in its re-gather branch (from saved activations: behind
+    the header flag the training forward raises): same gradients as the one-kernel form."""
     import inputs
     from freesplat_amd.cost_volume import AVGFeatureVolumeManager
     V, K, h4, w4, D, C = 3, 2, 24, 32, 8, 48
@@ -288,15 +304,15 @@ def test_backward_forms_agree_with_zero_features(hip_device, monkeypatch):
     kw["src_feats"][:, 0, :, 10:20, 3:12] = 0.0
     g = torch.randn(V, D, h4, w4, generator=torch.Generator().manual_seed(4)).to(hip_device)
     res = {}
-    for form in ("two_pass", "atomic"):
-        if form == "atomic":
-            monkeypatch.setenv("FS_CV_BWD_ATOMIC", "1")
+    for form in ("saved", "two_pass", "atomic"):
+        _set_form(monkeypatch, form)
         a = {k: v.to(hip_device) for k, v in kw.items()}
         a["cur_feats"].requires_grad_(True)
         a["src_feats"].requires_grad_(True)
         m.zero_grad()
         (m(**a) * g).sum().backward()
         res[form] = [a["cur_feats"].grad.cpu(), a["src_feats"].grad.cpu()] + [p.grad.cpu().clone() for p in m.parameters()]
-    for x, y in zip(res["two_pass"], res["atomic"]):
-        scale = y.abs().max().item() + 1e-30
-        assert ((x - y).abs().max().item() / scale) < 1e-4
+    for form in ("saved", "two_pass"):
+        for x, y in zip(res[form], res["atomic"]):
+            scale = y.abs().max().item() + 1e-30
+            assert ((x - y).abs().max().item() / scale) < 1e-4, form
