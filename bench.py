@@ -22,7 +22,8 @@ carries sub-objects measured in the same run, each with its own roofline / cpu_b
   "train"        fwd+bwd training step at config 3 (roofline: render_bwd kernel)
   "c2"           config 2 (640x480, 300 k Gaussians, forward)
   "cost_volume"  plane-sweep cost volume: native 96x128 K=1 and config-3 scale 242x324 K=2 (roofline: fp32 MFMA)
-  "ptf"          Pixel-wise Triplet Fusion folds: 2 and 10 views at 384x512 (roofline: HBM)
+  "c3_fp16_sh"   the headline workload with the SH coefficients stored in fp16 (BASELINE config 5's storage option)
+  "ptf"          Pixel-wise Triplet Fusion folds: 2, 10 and 30 views at 384x512, 3 views at 968x1296 (roofline: HBM)
 (`--sections raster` restricts the run to the top-level metric.)
 """
 from __future__ import annotations
@@ -112,8 +113,11 @@ class Ctx:
         torch.cuda.synchronize()
 
 
-def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warmup: int, cpu_baseline: bool) -> dict | None:
-    """One rasterizer measurement (forward, or forward+backward): returns the JSON object on rank 0."""
+def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warmup: int, cpu_baseline: bool,
+                 sh_fp16: bool = False) -> dict | None:
+    """One rasterizer measurement (forward, or forward+backward): returns the JSON object on rank 0.
+    `sh_fp16` (forward only): the SH coefficients are STORED in fp16 (BASELINE config 5; FS_RASTER_SH_FP16: converted on
+    load, fp32 arithmetic) -- algorithmic bytes N*94 + P*16, parity against the oracle fed the fp16-rounded coefficients."""
     args = cx.args
     world, rank, dev = cx.world, cx.rank, cx.dev
     from freesplat_amd import _lib, synthetic
@@ -131,6 +135,9 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
     sl = slice(mine.start, mine.stop)
     cams = {k: v[sl].to(dev) for k, v in cams_all.items()}
     g = {k: scene[k].to(dev) for k in ("means", "covariances", "harmonics", "opacities")}
+    if sh_fp16:
+        g["harmonics"] = g["harmonics"].half()
+        scene = dict(scene, harmonics=scene["harmonics"].half().float())     # (what the oracle is fed)
     bg = torch.zeros(len(mine), 3, device=dev)
     train = mode == "train"
     if train:
@@ -196,11 +203,22 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
     regions = []
     while True:
         t0 = time.perf_counter()
-        for _ in range(steps):
-            color, depth = step()
-        if gather is not None:
-            gather.wait()
-        check_deferred()  # raises if any view of the timed region overflowed its instance capacity
+        failure = None
+        try:
+            for _ in range(steps):
+                color, depth = step()
+            if gather is not None:
+                gather.wait()
+            check_deferred()  # raises if any view of the timed region overflowed its instance capacity
+        except Exception as e:  # noqa: BLE001 -- re-raised below, on EVERY rank
+            failure = e
+        # a failure on one rank (capacity overflow, out of memory) must not leave the others in the barrier / all-reduce
+        # below: every rank learns of it and all of them stop
+        flag = torch.tensor([1.0 if failure is not None else 0.0], device=dev)
+        if cx.dist_on:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() > 0:
+            raise failure if failure is not None else RuntimeError("another rank failed inside the timed region")
         cx.barrier()
         regions.append(time.perf_counter() - t0)
         enough = torch.tensor([1.0 if (sum(regions) >= args.min_time or len(regions) >= 15) else 0.0], device=dev)
@@ -226,6 +244,37 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         _lib.profile_enable(False)
         _R.NUM_STREAMS = streams
         breakdown = _lib.profile_collect()
+    # N > 1 diagnostics: a few extra untimed steps with the render, the all-gather and the render
+    # stream's wait for the gather (the EXPOSED, non-overlapped part) event-timed separately on every rank
+    multi = None
+    if gather is not None:
+        gather.timing = True
+        spans = []
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            spans.append((e0, e1))
+        gather.wait()
+        check_deferred()
+        torch.cuda.synchronize()
+        gather.timing = False
+        mean = lambda evs: sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
+        mine_ms = [mean(spans), mean(gather.gather_events), mean(gather.wait_events)]
+        allv = torch.tensor(mine_ms, device=dev, dtype=torch.float64)
+        got = [torch.zeros_like(allv) for _ in range(world)]
+        if cx.dist_on:
+            dist.all_gather(got, allv)
+        else:
+            got = [allv]
+        multi = {"per_rank": [{"step_ms": round(float(t[0]), 3), "gather_ms": round(float(t[1]), 3),
+                               "exposed_gather_ms": round(float(t[2]), 3)} for t in got],
+                 "what": "4 extra untimed steps, event-timed per rank: one step on the render stream (render of this rank's views "
+                         "+ its wait for the PREVIOUS step's gather), the all-gather of one step's images on the side stream, "
+                         "and that wait alone = the part of the gather the rendering did not hide",
+                 "gather_bytes_per_rank_per_step": int(n_total_views * H * W * (4 if args.gather_depth else 3)
+                                                       * {"fp32": 4, "fp16": 2, "uint8": 1}[args.gather_dtype])}
     graph_views_per_s = None
     if world == 1 and not cx.dist_on and not train and not args.no_graph:
         # the same step recorded once into a hipGraph (the C ABI never allocates or syncs: framing + 5 kernels per view
@@ -262,7 +311,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
     n_inst = _state(dev).last_instances
     n_views_done = n_total_views * steps      # per timed region
     # algorithmic bytes per rendered view: N*(12+24+4+12*d_sh) + P*(12+4)
-    alg_fwd = N * 148 + H * W * 16
+    alg_fwd = N * (94 if sh_fp16 else 148) + H * W * 16
     alg_bwd = 2 * N * 148 + H * W * 20
     out = {
         "metric": f"rendered views/sec @ {H}x{W}, {N / 1e6:.1f}M Gaussians" + (" (fwd+bwd)" if train else ""),
@@ -271,7 +320,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "mode": mode, "image_hw": [H, W], "gaussians": N,
-                   "sh_degree": 2, "views_per_step_per_gpu": views, "raster_streams": R_NUM_STREAMS,
+                   "sh_degree": 2, "sh_storage": "fp16" if sh_fp16 else "fp32", "views_per_step_per_gpu": views,
+                   "raster_streams": R_NUM_STREAMS,
                    "blend_exp": "hardware v_exp_f32" if _R_FAST() else "contract polynomial",
                    "blend": ("training instantiation (tracks n_contrib, writes the sorted lists for the backward)" if train else
                              "inference instantiation (torch.no_grad: no n_contrib tracking, sorted lists stay in LDS; same image bits)"),
@@ -280,6 +330,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                                                               (" + all_gather(color,depth)" if args.gather_depth else " + all_gather(color)")
                                                               + ("" if args.gather_dtype == "fp32" else f"[{args.gather_dtype}]") if gather else "")},
     }
+    if multi is not None:
+        out["multi_gpu"] = multi
     if graph_views_per_s is not None:
         out["hipgraph_replay"] = {"value": graph_views_per_s, "unit": "views/s", "same_image_as_eager": graph_ok,
                                   "what": "one step captured into a hipGraph, replayed `steps` times"}
@@ -292,6 +344,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         if train:
             traffic, traffic_src = (committed_traffic("fs::render_bwd_kernel<" + ("true" if _R_FAST() else "false"))
                                     if workload.startswith("c3") else (None, None))
+        elif sh_fp16:
+            traffic, traffic_src = None, None
         else:   # per launch of the fused sort + blend kernel (profiles/tools/fwd_traffic.py)
             traffic, traffic_src = traffic_lookup("raster_" + workload[:2], "fs::sort_blend_kernel")
         out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": 8000.0,
@@ -305,13 +359,23 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                                           "launches of adjacent views overlap on config.raster_streams streams")
         iso = breakdown.get(dominant, (0.0, 0))
         out["roofline"]["isolated_launch_ms"] = iso[0] / max(iso[1], 1)
-        if not train:
+        # the three numbers one could mean by "fraction of the HBM roofline", named:
+        #   frac_overlapped    = `frac`: algorithmic bytes / AVERAGE launch duration inside the timed region, where the launches
+        #                        of adjacent views run concurrently on the raster streams (each is slowed by its neighbour)
+        #   frac_isolated      = the same bytes / the duration of a launch running alone (the extra single-stream steps)
+        #   pipeline_frac_wall = algorithmic bytes of all views of a timed region / its wall time: the whole pipeline
+        #                        (projection + binning + scan + sort + blend, launch gaps included) by the driver's clock
+        out["roofline"]["frac_overlapped"] = out["roofline"]["frac"]
+        if iso[1] and iso[0] > 0:
+            out["roofline"]["frac_isolated"] = alg / (iso[0] / iso[1] * 1e-3) / 8e12
+        out["roofline"]["pipeline_frac_wall"] = alg * n_views_done / dt / 8e12
+        if not train and not sh_fp16:
             out["roofline"]["pipeline_traffic_per_view"] = traffic_lookup("raster_" + workload[:2])[0]
         ksum = sum(out["kernel_ms_per_view"].values())
         if ksum > 0:   # the whole pipeline of one view against the same algorithmic bytes
             out["roofline"]["pipeline_frac_isolated"] = (alg_fwd + (alg_bwd if train else 0)) / (ksum * 1e-3) / 8e12
     if world == 1 and cpu_baseline:
-        out.update(cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=train))
+        out.update(cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=train, sh_fp16=sh_fp16))
     return out
 
 
@@ -350,7 +414,7 @@ def committed_traffic(kernel: str):
     return None, None
 
 
-def cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=False):
+def cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=False, sh_fp16=False):
     """Times the CPU oracle (kind "port": OpenMP restatement of the reference algorithm, all host
     cores) on a bounded sample -- whole views of the same workload (forward, or forward + backward in train mode)
     until >= 10 s of CPU work or 3 views -- and checks the GPU result of view 0 against it: image max-abs / PSNR /
@@ -378,7 +442,8 @@ def cpu_baseline_and_parity(scene, cams_all, H, W, workload, train=False):
         n += 1
     # parity of the kernels: the SAME (CPU-framed) inputs through the product rasterizer
     dev = torch.device("cuda", torch.cuda.current_device())
-    (gc, _, _, _), leaves = hip_forward(vi, dev, requires_grad=train)
+    vi_hip = dict(vi, shs=vi["shs"].half()) if sh_fp16 else vi      # (`scene` already holds the fp16-rounded values)
+    (gc, _, _, _), leaves = hip_forward(vi_hip, dev, requires_grad=train)
     g = gc.detach().cpu().numpy()
     err = float(np.abs(g - st0["color"]).max())
     mse = float(((g.clip(0, 1) - st0["color"].clip(0, 1)) ** 2).mean())
@@ -424,7 +489,7 @@ def main():
     out = bench_raster(cx, args.workload, args.mode, args.views, args.steps, args.warmup, cpu)
     sections = []
     if cx.world == 1 and args.sections != "raster":
-        sections = ["train", "c2", "cost_volume", "ptf"] if args.sections == "all" else args.sections.split(",")
+        sections = ["train", "c2", "c5", "cost_volume", "ptf"] if args.sections == "all" else args.sections.split(",")
 
     def section(fn):
         """A secondary measurement must never take the headline line down with it."""
@@ -451,6 +516,9 @@ def main():
         out["train"] = section(lambda: bench_raster(cx, args.workload, "train", min(args.views, 8), max(3, args.steps // 2), 2, cpu))
     if "c2" in sections and not args.workload.startswith("c2"):
         out["c2"] = section(lambda: bench_raster(cx, "c2_640x480_300k", "fwd", args.views, args.steps, args.warmup, cpu))
+    if "c5" in sections and args.mode == "fwd":
+        # BASELINE config 5's storage option on the headline workload: SH coefficients held in fp16
+        out["c3_fp16_sh"] = section(lambda: bench_raster(cx, args.workload, "fwd", args.views, args.steps, args.warmup, cpu, sh_fp16=True))
     if "cost_volume" in sections or "ptf" in sections:
         import bench_encoder as be
         if "cost_volume" in sections:
@@ -458,14 +526,19 @@ def main():
                 "native_96x128_K1": section(lambda: be.bench_cost_volume(cx.dev, args.steps, args.warmup, cpu=cpu)),
                 "c3scale_242x324_K2": section(lambda: be.bench_cost_volume(cx.dev, max(3, args.steps // 4), 1, V=3, K=2, h4=242,
                                                                            w4=324, cpu=cpu, cpu_views=1)),
-                # config 4's shape: 10 context views, the 9 pose-nearest as sources (K = 8); GPU timing only (its parity
-                # case runs in tests/test_configs_4_5.py: the CPU oracle needs minutes at this size)
-                "fvt10_96x128_K8": section(lambda: be.bench_cost_volume(cx.dev, max(3, args.steps // 4), 1, V=10, K=8, cpu=False)),
+                # config 4's shape: 10 context views, the 9 pose-nearest as sources (K = 8); CPU baseline / parity on ONE of
+                # its current views (the whole volume also has a parity test: tests/test_configs_4_5.py)
+                "fvt10_96x128_K8": section(lambda: be.bench_cost_volume(cx.dev, max(3, args.steps // 4), 1, V=10, K=8, cpu=cpu,
+                                                                        cpu_views=1)),
             }
         if "ptf" in sections:
             out["ptf"] = {
                 "fold_2_views": section(lambda: be.bench_ptf(cx.dev, args.steps, args.warmup, cpu=cpu)),
-                "fold_10_views": section(lambda: be.bench_ptf(cx.dev, max(2, args.steps // 4), 1, V=10, cpu=cpu, cpu_steps=1)),
+                "fold_10_views": section(lambda: be.bench_ptf(cx.dev, max(2, args.steps // 4), 1, V=10, cpu=cpu)),
+                # BASELINE config 3's image: 3 views at 968x1296 = 3.76 M raw Gaussians
+                "fold_3_views_968x1296": section(lambda: be.bench_ptf(cx.dev, max(2, args.steps // 4), 1, V=3, h=968, w=1296, cpu=cpu)),
+                # BASELINE config 5's long sequence: 30 views (CPU baseline / parity on the fold of its first 4 views)
+                "fold_30_views": section(lambda: be.bench_ptf(cx.dev, 2, 1, V=30, cpu=cpu, cpu_steps=3, train=False)),
             }
     if cx.rank == 0:
         print(json.dumps(out), flush=True)

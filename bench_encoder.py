@@ -87,18 +87,27 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
         o = mg(**ga)
         o.backward(torch.ones_like(o))
     dt_train = timed(train_step, max(2, steps // 4), 1)
+    # the backward alone, event-timed through the library's stage hooks (every launch of a training step is in the
+    # cost_volume stage: forward sweep + relayouts, then the backward's two passes + relayouts)
+    n_tr = max(2, steps // 4)
+    _lib.profile_collect(); _lib.profile_enable(True)
+    timed(train_step, n_tr, 0)
+    _lib.profile_enable(False)
+    ms_tr, _ = _lib.profile_collect()["cost_volume"]
+    bwd_ms = max(ms_tr / n_tr - kern * 1e3, 1e-6)
     ws_bwd = _lib.lib().fs_cost_volume_backward_workspace_bytes(V, K, C, h4, w4, D)
     extra = {}
     if cpu:
         nv = V if cpu_views is None else min(V, cpu_views)
-        torch.set_num_threads(os.cpu_count() or 1)
+        cores = min(64, os.cpu_count() or 1)     # (large fused tensor ops: more threads than this only add synchronisation)
+        torch.set_num_threads(cores)
         t0 = time.perf_counter()
         ref = cvo.cost_volume(kw["cur_feats"][:nv], kw["src_feats"][:nv], kw["src_extrinsics"][:nv], kw["src_Ks"][:nv],
                               kw["cur_invK"][:nv], kw["min_depth"], kw["max_depth"], D, cvo.mlp_from_state(sd))
         t_cpu = time.perf_counter() - t0
         torch.set_num_threads(8)
         e = (out[:nv] - ref).abs()
-        extra = {"cpu_baseline": {"value": nv / t_cpu, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+        extra = {"cpu_baseline": {"value": nv / t_cpu, "unit": "views/s", "cores": cores, "kind": "port",
                                   "sample": f"{nv} of {V} current view(s) through oracle/cost_volume_oracle.py (torch CPU, "
                                             "vectorised over D; pinned by the reference's golden volumes)"},
                  "parity": {"max_abs_err_vs_oracle": float(e.max()), "median_abs_err": float(e.median()),
@@ -109,8 +118,22 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
             "ms_per_call": dt * 1e3, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cv_native", "views": V, "sources": K, "channels": C},
             "train_fwd_bwd": {"ms": dt_train * 1e3, "backward_workspace_bytes": int(ws_bwd),
-                              "what": "forward + backward (features and all six MLP tensors; weight gradients accumulated "
-                                      "on the matrix cores in the kernel: workspace independent of the plane count)"},
+                              "what": "forward + backward (features and all six MLP tensors); the backward runs in two passes "
+                                      "-- records of C + 2 floats per (view, plane, pixel), then a sweep over tiles of source "
+                                      "texels that accumulates in LDS: no global float atomics on the source maps",
+                              "roofline": {"bound": "mfma", "kernel": "cost-volume backward (relayouts + cost_volume_bwd_kernel + "
+                                                                      "cv_src_grad_kernel)",
+                                           "algorithmic_flops_per_launch": 2 * flops, "avg_launch_ms": bwd_ms,
+                                           "achieved": 2 * flops / (bwd_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                           "frac": 2 * flops / (bwd_ms * 1e-3) / 1e12 / 157.3,
+                                           "flops_note": "priced at twice the forward's algorithmic flops; the first pass issues 137 "
+                                                         "fp32 MFMAs per 32 points (17.5 kFLOP per point: forward recompute, three "
+                                                         "transposed layers, two weight-gradient products)",
+                                           "traffic": _traffic("cvt_" + wl_name[3:])[0] if wl_name else None,
+                                           "traffic_source": _traffic("cvt_" + wl_name[3:])[1] if wl_name else None,
+                                           "traffic_unit": "L2-miss bytes (FETCH_SIZE / WRITE_SIZE) of one whole training step, forward "
+                                                           "included; the tile sweep re-reads the records once per source",
+                                           "global_float_atomics_on_source_maps": 0}},
             "roofline": {"bound": "mfma", "kernel": "cost_volume (relayout + sweep)", "achieved": flops / kern / 1e12,
                          "peak": 157.3, "unit": "TFLOP/s", "frac": flops / kern / 1e12 / 157.3,
                          "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern * 1e3, "launches": cnt,
@@ -119,9 +142,7 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
                                            "prices the reference formulation's flops (41 MFMAs per cell), the K = 1 sweep issues 16",
                          "traffic": _traffic(wl_name)[0], "traffic_source": _traffic(wl_name)[1],
                          "traffic_unit": "HBM bytes per call (all current views)",
-                         "traffic_note": None if K == 1 else "PMC passes of round 3 on the 32-pixel K >= 2 sweep; not re-taken for the "
-                                         "16-pixel sweep that replaced it (same algorithm and maps, natural instead of parity-split "
-                                         "channel order)"}}, **extra)
+                         "algorithmic_bytes_per_call": 4 * V * ((1 + K) * C + D) * h4 * w4}}, **extra)
 
 
 def _ptf_w2c(E):
@@ -129,7 +150,7 @@ def _ptf_w2c(E):
     return world_to_camera(E).view(-1, 4, 4).cpu()
 
 
-def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
+def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, train=True):
     """`cpu_steps`: bound the CPU baseline to the fold of the first cpu_steps + 1 views (the later steps of a long fold
     are larger -- the state grows -- so scaling that time to all V - 1 steps UNDER-estimates the CPU time)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -157,7 +178,7 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
         out = fn([ins[0]], [ins[1]], ins[2], ins[3], ins[4], *a[5:])
         sum(o.sum() for o in out).backward()
     n_tr = max(2, steps // 4)
-    dt_train = timed(lambda: train_step(m.fuse_gaussians), n_tr, 1)
+    dt_train = timed(lambda: train_step(m.fuse_gaussians), n_tr, 1) if train else float("nan")
     with torch.no_grad():
         m.fuse_gaussians(*a)            # (LAST_FOLD_COUNTS of the inference fold)
     from freesplat_amd import ptf as _ptf
@@ -173,7 +194,8 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
     kern_ms = ms / steps   # every launch of the library's ptf stage (event-bracketed), per fold call
     extra = {}
     if cpu:
-        torch.set_num_threads(os.cpu_count() or 1)
+        cores = min(16, os.cpu_count() or 1)     # (the fold is many small operations: on all 256 host threads their
+        torch.set_num_threads(cores)             #  synchronisation made it ~50x slower -- round 3's figures)
         nv = V if cpu_steps is None else min(V, cpu_steps + 1)
         with torch.no_grad():
             t0 = time.perf_counter()
@@ -187,7 +209,7 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
         torch.set_num_threads(8)
         err = max(float((x - y).abs().max()) for x, y in zip(got, ref))
         scale = (V - 1) / (nv - 1)
-        extra = {"cpu_baseline": {"value": 1.0 / (t_cpu * scale), "unit": "folds/s", "cores": os.cpu_count(), "kind": "port",
+        extra = {"cpu_baseline": {"value": 1.0 / (t_cpu * scale), "unit": "folds/s", "cores": cores, "kind": "port",
                                   "sample": (f"1 fold of {V} views" if nv == V else
                                              f"the fold of the first {nv} of {V} views ({nv - 1} of {V - 1} steps, time scaled by "
                                              f"{scale:.1f}: an under-estimate, later steps fold into a larger state)")
@@ -198,9 +220,10 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None):
     M_in, M_out = V * h * w, out[0].shape[1]
     return dict({"metric": f"PTF folds/sec, {V} views @ {h}x{w}", "value": 1.0 / dt, "unit": "folds/s", "ms_per_call": dt * 1e3,
                  "dtype": "f32 / int64 indices", "data": "synthetic",
-                 "config": {"workload": "ptf_native", "views": V, "gaussians_in": M_in, "gaussians_out": M_out,
+                 "config": {"workload": f"ptf_{V}_views_{h}x{w}", "views": V, "gaussians_in": M_in, "gaussians_out": M_out,
                             "fused_pairs_per_step": [c[1] for c in steps_counts[1:]]},
-                 "train_fwd_bwd": {"hip_ms": dt_train * 1e3, 
+                 "train_fwd_bwd": {"hip_ms": dt_train * 1e3 if train else None,
+
                                    "what": "forward + backward of the fold w.r.t. latents, coords, densities, weights, "
                                            "depths and the GRU parameters; gradients checked against the oracle's "
                                            "autograd in tests/test_ptf_hip.py"},

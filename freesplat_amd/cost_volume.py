@@ -24,12 +24,12 @@ from . import _lib
 def save_activations(K: int) -> bool:
     """Whether a training forward keeps the MLP's input of every (view, plane, pixel) point for the backward
     (fs_cost_volume_forward_train: C + 2 floats per point, what autograd keeps of the averaged features) or the backward
-    gathers the K sources' taps again.  Measured (profiles/r4_cv_bwd_form_ab.txt, forward + backward): 10 views, K = 8:
-    17.2 ms saved vs 18.1 recomputed; config-3 scale, K = 2: 14.85 vs 14.55; native, K = 1: 1.52 vs 1.38 (the K = 1
-    inference sweep, which never forms the averaged features, is the faster forward) -- so by default only from K = 5 up.
-    FREESPLAT_CV_SAVE=1 / 0 (read at every call) forces either."""
-    e = os.environ.get("FREESPLAT_CV_SAVE", "")
-    return e != "0" if e in ("0", "1") else K >= 5
+    gathers the K sources' taps again.  Opt-in (FREESPLAT_CV_SAVE=1, read at every call): measured on the final kernels
+    (profiles/r4_cv_bwd_form_ab2.txt, forward + backward) it buys nothing -- 10 views, K = 8: 17.65 ms saved vs 17.6
+    recomputed; config-3 scale, K = 2: 13.5 vs 13.5; native, K = 1: 1.40 vs 1.39 -- because the backward's first pass is
+    bound by its 137 MFMAs and LDS transposes per 32 points, not by the gather its second wavefront per SIMD hides, while
+    the forward pays 0.4 - 0.8 ms for writing the activations."""
+    return os.environ.get("FREESPLAT_CV_SAVE", "0") == "1"
 
 
 class _Backprojector(nn.Module):

@@ -51,20 +51,54 @@ __device__ unsigned long long g_cvb_trace[kCvTraceWaves * 6];
 #define FS_CV_T(var, dep) do {} while (0)
 #endif
 
-// ---- feature re-layout: [C,h,w] -> [h*w][2][C/2]  (channel c -> parity c&1, slot c>>1) --------
-__global__ __launch_bounds__(256) void cv_relayout_kernel(const float* __restrict__ src,
-                                                          float* __restrict__ dst, int C, int hw,
-                                                          int n_maps)
+// ---- feature re-layouts between the caller's [C, h*w] maps and pixel-major [h*w][C] records, through an LDS tile ----
+// One workgroup moves 64 pixels x C channels: rows of 256 contiguous bytes on the channel-major side, 64 x C x 4
+// contiguous bytes on the pixel-major side (the one-thread-per-element versions wrote 4 bytes at a 4 C-byte stride:
+// 0.7 TB/s, 0.25 ms per call at config-3 scale; these: profiles/r4_cv_*).  PARITY: record position of channel c is
+// (c & 1) * C/2 + (c >> 1) (the backward's layout), else c (the forward's).  BACK: pixel-major -> channel-major.
+template <int C, bool PARITY, bool BACK>
+__global__ __launch_bounds__(256) void cv_relayout_tiled_kernel(const float* __restrict__ src, float* __restrict__ dst, int hw,
+                                                                 int n_maps)
 {
-    // one thread per (map, pixel, channel-pair slot); reads are coalesced along the pixel index
-    const long long total = (long long)n_maps * hw * C;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int pix = (int)(e % hw);
-        const long long r = e / hw;
-        const int c = (int)(r % C);
-        const long long map = r / C;
-        const float v = src[(map * C + c) * hw + pix];
-        dst[(map * hw + pix) * C + (size_t)(c & 1) * (C / 2) + (c >> 1)] = v;
+    constexpr int CS = C + 1;
+    __shared__ float tile[64 * CS];                 // [pixel][C + 1] (odd stride: both access directions conflict-free)
+    const int tiles = (hw + 63) / 64;
+    for (long long blk = blockIdx.x; blk < (long long)n_maps * tiles; blk += gridDim.x) {
+        const int map = (int)(blk / tiles), p0 = (int)(blk - (long long)map * tiles) * 64;
+        const int np = min(64, hw - p0);
+        const float* cm = (BACK ? dst : src) + (size_t)map * C * hw;          // channel-major side
+        const float* pm = (BACK ? src : dst) + ((size_t)map * hw + p0) * C;    // pixel-major side
+        if (!BACK) {
+            for (int e = threadIdx.x; e < C * 64; e += 256) {
+                const int c = e >> 6, px = e & 63;
+                if (px < np) tile[px * CS + (PARITY ? (c & 1) * (C / 2) + (c >> 1) : c)] = cm[(size_t)c * hw + p0 + px];
+            }
+            __syncthreads();
+            float* out = const_cast<float*>(pm);
+            for (int e = threadIdx.x; e < np * C; e += 256) out[e] = tile[(e / C) * CS + (e % C)];
+        } else {
+            for (int e = threadIdx.x; e < np * C; e += 256) tile[(e / C) * CS + (e % C)] = pm[e];
+            __syncthreads();
+            float* out = const_cast<float*>(cm);
+            for (int e = threadIdx.x; e < C * 64; e += 256) {
+                const int c = e >> 6, px = e & 63;
+                if (px < np) out[(size_t)c * hw + p0 + px] = tile[px * CS + (PARITY ? (c & 1) * (C / 2) + (c >> 1) : c)];
+            }
+        }
+        __syncthreads();
+    }
+}
+static inline void cv_relayout(bool parity, bool back, const float* src, float* dst, int C, int hw, int n_maps, hipStream_t st)
+{
+    const long long blocks = (long long)n_maps * ((hw + 63) / 64);
+    const dim3 grid((unsigned)std::min<long long>(blocks, 65536));
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, src, dst, hw, n_maps); };
+    if (C == 48) {
+        if (parity) { if (back) go(cv_relayout_tiled_kernel<48, true, true>); else go(cv_relayout_tiled_kernel<48, true, false>); }
+        else go(cv_relayout_tiled_kernel<48, false, false>);
+    } else {   // (C == 16: the entry points accept nothing else)
+        if (parity) { if (back) go(cv_relayout_tiled_kernel<16, true, true>); else go(cv_relayout_tiled_kernel<16, true, false>); }
+        else go(cv_relayout_tiled_kernel<16, false, false>);
     }
 }
 
@@ -193,20 +227,6 @@ __device__ __forceinline__ float lrelu(float x) { return fmaf(0.495f, fabsf(x), 
 //   layer 2: those registers ARE the B operands of W2 (k-step (blk, r), quarter g -> unit 16 blk + 4 g + r): 2 x 8 steps
 //   layer 3: 8 FMAs per lane + the sum over the four quarters.
 // ==========================================================================================
-__global__ __launch_bounds__(256) void cv_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int hw,
-                                                           int n_maps)
-{
-    // [map][C][hw] -> [map][hw][C]; one thread per element, reads coalesced along the pixel index
-    const long long total = (long long)n_maps * hw * C;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int pix = (int)(e % hw);
-        const long long r = e / hw;
-        const int c = (int)(r % C);
-        const long long map = r / C;
-        dst[(map * hw + pix) * C + c] = src[e];
-    }
-}
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // SAVE (training forward): the MLP's input of every (pixel, plane) point -- the averaged warped features x = favg / cnt,
@@ -654,20 +674,6 @@ __global__ __launch_bounds__(256) void cost_volume_proj_kernel(
 // four wavefronts are summed in LDS and leave as one atomic per weight and workgroup.  (The first version wrote the
 // factors to HBM for rocBLAS: 584 B per point -- 1.8 GB per call at the native size, 17.6 GB at config 3's.)
 // ==========================================================================================
-__global__ __launch_bounds__(256) void cv_relayout_back_kernel(const float* __restrict__ srcT,
-                                                               float* __restrict__ dst, int C, int hw,
-                                                               int n_maps)
-{
-    const long long total = (long long)n_maps * hw * C;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int pix = (int)(e % hw);
-        const long long r = e / hw;
-        const int c = (int)(r % C);
-        const long long map = r / C;
-        dst[(map * C + c) * hw + pix] = srcT[(map * hw + pix) * C + (size_t)(c & 1) * (C / 2) + (c >> 1)];
-    }
-}
-
 // One source's bilinear gather for a (pixel, parity) lane: the 4 tap weights, validity and 32-bit texel indices (the scatter
 // of the gradient needs exactly those) and the blended half-record.
 template <int HC>
@@ -1554,7 +1560,6 @@ static int cv_forward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
     float* Pmat = (float*)((char*)workspace + align_up(((size_t)B * C + (size_t)B * K * (C + 2 * kCvU)) * hw * sizeof(float), 256));
     {
         ScopedStage prof_(kStCostVolume, st);
-        const long long tot1 = (long long)B * hw * C, tot2 = tot1 * K;
         const int groups = (hw + 31) / 32;
         const int slices = cv_plane_split(B, groups, D);
         const dim3 grid(cv_grid(B, groups, slices));
@@ -1579,10 +1584,8 @@ static int cv_forward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
             const int groups16 = (hw + 15) / 16;
             const int slices16 = cv_plane_split(B, groups16, D);
             const dim3 grid16(cv_grid(B, groups16, slices16));
-            hipLaunchKernelGGL(cv_transpose_kernel, dim3((unsigned)std::min<long long>((tot1 + 255) / 256, 65536)),
-                               dim3(256), 0, st, cur_feats, curT, C, hw, B);
-            hipLaunchKernelGGL(cv_transpose_kernel, dim3((unsigned)std::min<long long>((tot2 + 255) / 256, 65536)),
-                               dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
+            cv_relayout(false, false, cur_feats, curT, C, hw, B, st);
+            cv_relayout(false, false, src_feats, srcT, C, hw, B * K, st);
             // (training: the general sweep for every K -- it forms the averaged features the backward wants to keep; the
             //  K = 1 projected sweep never does)
             uint32_t* xhdr = (uint32_t*)saved;
@@ -1710,9 +1713,8 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
         set_last_error("cost volume backward memset", hipGetLastError());
         return FS_ERR_LAUNCH;
     }
-    auto blocks = [](size_t n) { return dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)); };
-    hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_cur), dim3(256), 0, st, cur_feats, curT, C, hw, B);
-    hipLaunchKernelGGL(cv_relayout_kernel, blocks(n_src), dim3(256), 0, st, src_feats, srcT, C, hw, B * K);
+    cv_relayout(true, false, cur_feats, curT, C, hw, B, st);
+    cv_relayout(true, false, src_feats, srcT, C, hw, B * K, st);
     const int groups = (hw + 31) / 32;
     const int bslices = cv_bwd_plane_split(B, groups, D);
     auto sweep = [&](auto kernel) {
@@ -1737,9 +1739,9 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
         }
     } else {
         if (C == 48) sweep(cost_volume_bwd_kernel<24, false, false>); else sweep(cost_volume_bwd_kernel<8, false, false>);
-        hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_src), dim3(256), 0, st, d_srcT, d_src_feats, C, hw, B * K);
+        cv_relayout(true, true, d_srcT, d_src_feats, C, hw, B * K, st);
     }
-    hipLaunchKernelGGL(cv_relayout_back_kernel, blocks(n_cur), dim3(256), 0, st, d_curT, d_cur_feats, C, hw, B);
+    cv_relayout(true, true, d_curT, d_cur_feats, C, hw, B, st);
     FS_CHECK_LAUNCH("cost_volume_backward");
     return FS_OK;
 }

@@ -214,7 +214,9 @@ def check_deferred() -> None:
             st.last_instances = max(st.last_instances, n_inst)
             if overflow:    # (non-zero = the largest tile list: sizes the next call's capacity)
                 bad += 1
-                st.retry_cap = max(st.retry_cap, R.retry_capacity(n_inst, overflow & 0xFFFFFFFF, *hw))
+                st.note_overflow(n_inst, overflow & 0xFFFFFFFF, *hw)
+        if not bad:
+            st.note_fit(*hw)
     if bad:
         raise R._lib.FreeSplatHipError(f"{bad} deferred view(s) overflowed their instance capacity; "
                                        "re-render them (capacity history has been updated)")
@@ -229,7 +231,7 @@ class _RenderViews(torch.autograd.Function):
         N = means.shape[0]
         dev = means.device
         st = R._state(dev)
-        cap = R.default_capacity(N, st)
+        cap = R.default_capacity(N, st, h, w)
         color = torch.empty(v, 3, h, w, dtype=torch.float32, device=dev)
         depth = torch.empty(v, h, w, dtype=torch.float32, device=dev)
         alpha = torch.empty(v, h, w, dtype=torch.float32, device=dev)
@@ -285,15 +287,24 @@ class _RenderViews(torch.autograd.Function):
             _pending_checks.append((counters, states if any(ctx.needs_input_grad) else None, dev, (h, w)))
         else:
             counters = torch.stack([rs.counters for rs in states]).tolist()  # the single sync
-            worst = 0
+            worst, redone = 0, []
             for i, (n_inst, overflow) in enumerate(counters):
                 n_inst &= 0xFFFFFFFF
                 if overflow:
-                    st.retry_cap = max(st.retry_cap, R.retry_capacity(n_inst, overflow & 0xFFFFFFFF, h, w))
-                    states[i] = launch(i, st.retry_cap)
+                    states[i] = launch(i, st.note_overflow(n_inst, overflow & 0xFFFFFFFF, h, w))
+                    redone.append(i)
                     batch = None        # that view now lives in its own buffers: backward goes view by view
                 states[i].num_rendered = n_inst
                 worst = max(worst, n_inst)
+            if redone:
+                # the relaunches must have fitted: a second overflow (capacity clamp, saturated instance count) would
+                # leave the blend unrun and the uninitialised colour buffer returned as the image
+                again = torch.stack([states[i].counters for i in redone]).tolist()
+                if any(o for _, o in again):
+                    raise R._lib.FreeSplatHipError("rasterizer instance list overflowed twice (views "
+                                                   f"{[i for i, (_, o) in zip(redone, again) if o]})")
+            else:
+                st.note_fit(h, w)
             st.last_instances = worst
         ctx.states = states
         ctx.batch = batch
@@ -434,7 +445,7 @@ class DecoderSplattingCUDA(nn.Module):
         self.batched = batched
         self.group = group
         self.single_rank_collectives = single_rank_collectives
-        self._replicas_checked = False
+        self._replicas_checked = None      # Gaussian count of the last scene whose replicas were compared
 
     def _dist_group(self):
         if self.group is None or self.group is False:
@@ -446,15 +457,18 @@ class DecoderSplattingCUDA(nn.Module):
         return (g, dist) if (dist.get_world_size(g) > 1 or self.single_rank_collectives) else None
 
     def _check_replicas(self, group, dist, gaussians, extrinsics):
-        """All ranks of the group must hold the same Gaussians and cameras: compare a cheap checksum (sum and
-        sum of squares of the means and of the extrinsics) through one MIN and one MAX all-reduce of 4 doubles."""
+        """All ranks of the group must hold the same scene: compare a cheap signature (Gaussian count; sum and sum of
+        squares of the means and of the extrinsics) through one MIN and one MAX all-reduce of 5 doubles.  The count must
+        be equal; the sums within 1e-6 relative -- replicated encoders agree to rounding, not to the bit (MIOpen algorithm
+        choice, float atomics in the encoder's backward kernels), while different scenes differ in the first digits."""
         from .view_sharding import _stage
         m, e = gaussians.means.detach().double(), extrinsics.detach().double()
-        sig = torch.stack([m.sum(), (m * m).sum(), e.sum(), (e * e).sum()])
+        sig = torch.stack([torch.tensor(float(m.shape[-2]), dtype=torch.float64, device=m.device), m.sum(), (m * m).sum(), e.sum(),
+                           (e * e).sum()])
         lo, hi = _stage(sig.clone(), group), _stage(sig.clone(), group)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-        if not torch.equal(lo, hi):
+        if lo[0] != hi[0] or bool(((hi - lo).abs() > 1e-6 * torch.maximum(hi.abs(), lo.abs()) + 1e-12).any()):
             raise RuntimeError("DecoderSplattingCUDA(group=...): Gaussians / cameras differ between the ranks of the group "
                                f"(checksum min {lo.tolist()} != max {hi.tolist()}); view sharding needs the SAME scene on "
                                "every rank (shard scenes over ranks with group=None instead)")
@@ -470,9 +484,12 @@ class DecoderSplattingCUDA(nn.Module):
         bg = self.background_color
         sharded = self._dist_group()
         if sharded is not None:
-            if not self._replicas_checked or os.environ.get("FREESPLAT_CHECK_REPLICAS") == "1":
+            # on the first sharded call, whenever the Gaussian count changes (a new scene), and always with
+            # FREESPLAT_CHECK_REPLICAS=1
+            n_now = int(gaussians.means.shape[-2])
+            if self._replicas_checked != n_now or os.environ.get("FREESPLAT_CHECK_REPLICAS") == "1":
                 self._check_replicas(sharded[0], sharded[1], gaussians, extrinsics)
-                self._replicas_checked = True
+                self._replicas_checked = n_now
             color, depth = self._forward_sharded(sharded[0], sharded[1], gaussians, extrinsics, intrinsics, near, far,
                                                  image_shape, with_depth=depth_mode is not None)
             if depth is None:

@@ -253,7 +253,8 @@ def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tens
     return dcat, grads
 
 
-_fold_scratch: dict = {}       # (device, V, h, w) -> the inference fold's internal scratch
+_fold_scratch: dict = {}       # (device, stream, V, h, w) -> the inference fold's internal scratch (reuse is ordered by the
+                               # stream; two folds in flight on different streams must not share it; at most 8 shapes are kept)
 
 
 def world_to_camera(Es: Tensor) -> Tensor:
@@ -312,9 +313,11 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
         bufs.append(one)
     ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in b]) for b in bufs]
     counts = torch.empty(V, 4, dtype=torch.int32, device=dev)
-    key = (str(dev), V, h, w)
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream, V, h, w)
     scratch = _fold_scratch.get(key)
     if scratch is None:
+        while len(_fold_scratch) >= 8:                          # (oldest entry first: dicts keep insertion order)
+            _fold_scratch.pop(next(iter(_fold_scratch)))
         scratch = _fold_scratch[key] = torch.empty(L.fs_ptf_fold_bytes(V, h, w), dtype=torch.uint8, device=dev)
     _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), p(w2c), p(Kn), C.c_float(depth_thres),
                              p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts), _lib.current_stream()), "fs_ptf_fold")

@@ -67,8 +67,37 @@ class _DeviceState:
     def __init__(self):
         self.scratch: dict[int, Tensor] = {}   # one reusable scratch per HIP stream
         self.last_instances = 0
-        self.retry_cap = 0                     # capacity a past overflow asked for (retry_capacity)
+        # capacity a past overflow asked for (retry_capacity), per image size; decays on every call that fits (note_fit):
+        # one close-up view must not inflate the scratch of every later call for good
+        self.retry_caps: dict[tuple[int, int], int] = {}
         self.side_streams: list = []
+
+    @property
+    def retry_cap(self) -> int:                # (largest live value: bench / tests reset it through the setter)
+        return max(self.retry_caps.values(), default=0)
+
+    @retry_cap.setter
+    def retry_cap(self, v: int) -> None:
+        if v == 0:
+            self.retry_caps.clear()
+        else:
+            raise ValueError("retry_cap can only be reset to 0; use note_overflow")
+
+    def note_overflow(self, n_inst: int, max_tile: int, H: int, W: int) -> int:
+        cap = max(self.retry_caps.get((H, W), 0), retry_capacity(n_inst, max_tile, H, W))
+        self.retry_caps[(H, W)] = cap
+        return cap
+
+    def note_fit(self, H: int, W: int) -> None:
+        """A call of this image size fitted its capacity: let the overflow-derived capacity decay (x0.9 per call; below the
+        default capacity it no longer matters and is dropped)."""
+        c = self.retry_caps.get((H, W))
+        if c is not None:
+            c = int(c * 0.9)
+            if c < (1 << 20):
+                del self.retry_caps[(H, W)]
+            else:
+                self.retry_caps[(H, W)] = c
 
 
 _states: dict[int, _DeviceState] = {}
@@ -88,9 +117,9 @@ def _buffer_sizes(N: int, H: int, W: int, cap: int):
     return [int(x) for x in out]
 
 
-def default_capacity(N: int, st: _DeviceState) -> int:
+def default_capacity(N: int, st: _DeviceState, H: int = 0, W: int = 0) -> int:
     """Instance capacity: generous (HBM is 288 GB) so the overflow retry is the rare path."""
-    return max(1 << 20, 8 * N, int(st.last_instances * 1.25) + 1024, st.retry_cap)
+    return max(1 << 20, 8 * N, int(st.last_instances * 1.25) + 1024, st.retry_caps.get((H, W), 0))
 
 
 def retry_capacity(n_inst: int, max_tile: int, H: int, W: int) -> int:
@@ -179,12 +208,14 @@ def rasterize_forward_checked(dims, means3D, cov3D, shs, colors, opacities, bg, 
     """Forward + capacity check (one host sync on the 8-byte counter pair), retrying once with the
     exact capacity when the instance list overflowed."""
     st = _state(means3D.device)
-    cap = default_capacity(dims.N, st)
+    cap = default_capacity(dims.N, st, dims.H, dims.W)
     rs, color, depth, alpha = _launch_forward(dims, means3D, cov3D, shs, colors, opacities, bg, view,
                                               proj, campos, cap)
     n_inst, overflow = (int(x) & 0xFFFFFFFF for x in rs.counters.tolist())
-    if overflow:   # (non-zero = the largest tile list)
-        cap = st.retry_cap = max(st.retry_cap, retry_capacity(n_inst, overflow, dims.H, dims.W))
+    if not overflow:
+        st.note_fit(dims.H, dims.W)
+    else:          # (non-zero = the largest tile list)
+        cap = st.note_overflow(n_inst, overflow, dims.H, dims.W)
         rs, color, depth, alpha = _launch_forward(dims, means3D, cov3D, shs, colors, opacities, bg,
                                                   view, proj, campos, cap)
         n_inst, overflow = (int(x) & 0xFFFFFFFF for x in rs.counters.tolist())

@@ -105,6 +105,11 @@ class AsyncViewGather:
         self.cuda = device is not None and device.type == "cuda"
         self.stream = torch.cuda.Stream(device=device) if self.cuda else None
         self.pending: Optional[Tensor] = None
+        # diagnostics (bench.py --gpus N): with `timing` set, every launch / wait is bracketed by events -- (start, end) of
+        # the collective on the side stream, (before, after) of the render stream's wait for it (= the EXPOSED part)
+        self.timing = False
+        self.gather_events: list = []
+        self.wait_events: list = []
 
     def launch(self, local: Tensor) -> None:
         if self.cuda:
@@ -113,7 +118,13 @@ class AsyncViewGather:
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
                 local.record_stream(self.stream)
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
                 self.pending = gather_views(local, self.n_total, self.group)
+                if self.timing:
+                    e1.record(self.stream)
+                    self.gather_events.append((e0, e1))
         else:
             self.pending = gather_views(local, self.n_total, self.group)
 
@@ -121,7 +132,13 @@ class AsyncViewGather:
         out, self.pending = self.pending, None
         if out is not None and self.cuda:
             cur = torch.cuda.current_stream()
+            if self.timing:
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w0.record(cur)
             cur.wait_stream(self.stream)
+            if self.timing:
+                w1.record(cur)
+                self.wait_events.append((w0, w1))
             out.record_stream(cur)   # allocated on the side stream, consumed on this one
         return out
 
@@ -146,11 +163,12 @@ _buckets: dict = {}
 
 
 def _bucket(numel: int, dtype, device) -> Tensor:
-    """The flat exchange bucket, allocated (zeroed) once per (device, dtype) and grown on demand: a training step reuses
-    it instead of allocating world*chunk floats every call.  Pad elements (ragged shards) may hold stale values of an
-    earlier call: they are summed into positions no receiver reads.  Reuse is safe because the collective is ordered
-    on the current stream before the next call's packing copies."""
-    key = (str(device), dtype)
+    """The flat exchange bucket, allocated (zeroed) once per (device, stream, dtype) and grown on demand: a training step
+    reuses it instead of allocating world*chunk floats every call.  Pad elements (ragged shards) may hold stale values of
+    an earlier call: they are summed into positions no receiver reads.  Reuse is safe because the collective is ordered
+    on the current stream before the next call's packing copies (exchanges issued from different streams get different
+    buckets)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0, dtype)
     b = _buckets.get(key)
     if b is None or b.numel() < numel:
         b = _buckets[key] = torch.zeros(numel, dtype=dtype, device=device)

@@ -22,6 +22,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "
 WORKLOADS = {   # name -> (units per call, default calls)
     "raster_c3": (16, 4), "raster_c2": (16, 4), "cv_native_K1": (1, 6), "cv_c3scale_K2": (1, 3), "cv_fvt10_K8": (1, 3),
     "ptf_2_views": (1, 6), "ptf_10_views": (1, 3),
+    # training steps of the cost volume (forward + backward w.r.t. features and MLP): unit = one step
+    "cvt_native_K1": (1, 4), "cvt_c3scale_K2": (1, 2), "cvt_fvt10_K8": (1, 2),
 }
 
 
@@ -41,12 +43,20 @@ def run(name, calls):
     elif name.startswith("cv"):
         import inputs
         from freesplat_amd.cost_volume import AVGFeatureVolumeManager
-        V, K, h4, w4 = {"cv_native_K1": (2, 1, 96, 128), "cv_c3scale_K2": (3, 2, 242, 324), "cv_fvt10_K8": (10, 8, 96, 128)}[name]
+        V, K, h4, w4 = {"native_K1": (2, 1, 96, 128), "c3scale_K2": (3, 2, 242, 324), "fvt10_K8": (10, 8, 96, 128)}[name.split("_", 1)[1]]
         torch.manual_seed(0)
         m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=128, mlp_channels=[202, 32, 32, 1],
                                     matching_dim_size=48).to(dev)
         args = {k: v.to(dev) for k, v in inputs.cv_inputs(V, K, h4, w4, 48, seed=1).items()}
         fn = lambda: m(**args)
+        if name.startswith("cvt_"):
+            args["cur_feats"].requires_grad_(True)
+            args["src_feats"].requires_grad_(True)
+            for _ in range(calls + 1):
+                o = m(**args)
+                o.backward(torch.ones_like(o))
+            torch.cuda.synchronize()
+            return
     else:
         from test_ptf_hip import _scene
         from freesplat_amd.ptf import PixelwiseTripletFusion
@@ -87,7 +97,7 @@ def summarize(tag):
         n = calls * units
         tot_r, tot_w = sum(v["read"] for v in per.values()), sum(v["write"] for v in per.values())
         out["workloads"][name] = {
-            "unit": "view" if name.startswith("raster") else ("call" if name.startswith("cv") else "fold"),
+            "unit": "view" if name.startswith("raster") else ("step" if name.startswith("cvt") else ("call" if name.startswith("cv") else "fold")),
             "units_measured": n, "hbm_bytes_per_unit": (tot_r + tot_w) / n, "read_bytes_per_unit": tot_r / n,
             "write_bytes_per_unit": tot_w / n,
             "kernels": {k: {"bytes_per_unit": (v["read"] + v["write"]) / n, "launches_per_unit": v["launches"] / n,
@@ -98,15 +108,32 @@ def summarize(tag):
         print(f"{k:16s} {v['hbm_bytes_per_unit'] / 1e6:9.1f} MB per {v['unit']}  (rd {v['read_bytes_per_unit'] / 1e6:.1f}, wr {v['write_bytes_per_unit'] / 1e6:.1f})")
 
 
+_LIB_BYTES = None
+
+
+def kernel_shipped(name):
+    """Whether the library still contains a kernel of this (demangled) name: its identifier appears in the mangled symbol
+    inside the embedded code object.  A traffic figure of a kernel that no longer exists must not be reported."""
+    global _LIB_BYTES
+    if _LIB_BYTES is None:
+        from freesplat_amd import _lib
+        _LIB_BYTES = open(_lib.LIB_PATH, "rb").read()
+    ident = name.split("<")[0].split("::")[-1].strip()
+    return f"{len(ident)}{ident}".encode() in _LIB_BYTES
+
+
 def lookup(workload, kernel_prefix=None):
-    """(bytes, source file) of `workload` from the newest committed profiles/*_traffic.json: per unit, or per launch of
-    the kernel whose name starts with `kernel_prefix`.  (None, None) when absent."""
+    """(bytes, source file) of `workload` from the newest committed profiles/*_traffic.json whose kernels ALL still exist
+    in the library (a file that names a deleted kernel is skipped for that workload): per unit, or per launch of the kernel
+    whose name starts with `kernel_prefix`.  (None, None) when absent."""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         try:
             w = json.load(open(f))["workloads"].get(workload)
         except Exception:
             continue
         if not w:
+            continue
+        if not all(kernel_shipped(k) for k in w["kernels"]):
             continue
         if kernel_prefix is None:
             return float(w["hbm_bytes_per_unit"]), os.path.relpath(f, ROOT)

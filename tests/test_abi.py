@@ -166,3 +166,27 @@ def test_workspace_size_queries():
     assert L.fs_ptf_scratch_bytes(1000, 48, 64) <= L.fs_ptf_scratch_bytes(100000, 48, 64)
     assert L.fs_ptf_fold_scratch_bytes(1000, 48, 64) <= L.fs_ptf_fold_scratch_bytes(100000, 48, 64)
     assert L.fs_ptf_scratch_bytes(-1, 48, 64) == 0 and L.fs_ptf_fold_scratch_bytes(10, 48, 0) == 0
+
+
+def test_overflow_capacity_is_per_image_size_and_decays():
+    """Host logic of the rasterizer's capacity history: the capacity an overflow asked for is kept per image
+    size, is what the next call of that size allocates, decays by 10 % with every call that fits, and is dropped once it
+    falls below the default -- one close-up view does not inflate every later call for good."""
+    from freesplat_amd import rasterizer as R
+    st = R._DeviceState()
+    N, H, W = 1000, 968, 1296
+    base = R.default_capacity(N, st, H, W)
+    cap = st.note_overflow(n_inst=5_000_000, max_tile=50_000, H=H, W=W)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    assert cap == max(5_000_000 + 1024, (50_000 * T + 3) // 4 + 1) and R.default_capacity(N, st, H, W) == cap
+    assert R.default_capacity(N, st, 480, 640) == base                     # another image size is unaffected
+    assert st.note_overflow(10, 10, H, W) == cap                           # a smaller overflow never shrinks it
+    seen = []
+    for _ in range(200):
+        st.note_fit(H, W)
+        seen.append(R.default_capacity(N, st, H, W))
+    assert seen[0] == max(base, int(cap * 0.9)) and all(a >= b for a, b in zip(seen, seen[1:])) and seen[-1] == base
+    assert st.retry_cap == 0 and not st.retry_caps
+    st.note_overflow(5_000_000, 50_000, H, W)
+    st.retry_cap = 0                                                       # (bench / tests reset the history)
+    assert R.default_capacity(N, st, H, W) == base

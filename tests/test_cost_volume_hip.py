@@ -252,7 +252,7 @@ def test_backward_tight_vs_float64_oracle(hip_device, case, form, monkeypatch):
     g = torch.randn(B, D, h4, w4, generator=torch.Generator().manual_seed(3))
     # float64 oracle + autograd on the CPU (once per case: the three forms share it)
     if case not in _ORACLE_CACHE:
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
         dbl = lambda t: t.double()
         cur_c = dbl(kw["cur_feats"]).requires_grad_(True)
         src_c = dbl(kw["src_feats"]).requires_grad_(True)

@@ -38,7 +38,8 @@ def _scene(V, h, w, seed, noise=0.02):
     return E, Kn, depths, lat, dens, wts, coords
 
 
-@pytest.mark.parametrize("h,w,M,seed", [(24, 32, 768, 1), (48, 64, 10000, 2), (384, 512, 196608 * 2, 3), (7, 9, 5, 4)])
+@pytest.mark.parametrize("h,w,M,seed", [(24, 32, 768, 1), (48, 64, 10000, 2), (384, 512, 196608 * 2, 3), (7, 9, 5, 4),
+                                         (968, 1296, 1254528 * 2, 5)])     # (the last: BASELINE config 3's image, 2 views of state)
 def test_match_bit_exact_vs_oracle(hip_device, h, w, M, seed):
     from oracle import ptf_oracle as po
     from freesplat_amd.ptf import match_view
@@ -222,3 +223,27 @@ def test_gru_forward_kernel_on_materialised_rows(hip_device, n):
     with torch.no_grad():
         ref = P._gru_from_cat(P._gru_params(gru), cat)
     assert (fused - ref).abs().max().item() < 1e-5
+
+
+def test_invert_4x4_vs_float64_inverse(hip_device):
+    """fs_invert_4x4 (ptf.world_to_camera: double precision inside, rounded once) directly against torch's float64 inverse:
+    camera poses, random well-conditioned matrices and near-singular ones agree to the rounding of the float32 result (the
+    full-size fold tests feed the oracle THIS kernel's matrices, so an error here would cancel out there: ADVICE r3); a
+    singular matrix gives non-finite entries instead of the reference's `.inverse()` exception (ptf.py documents it)."""
+    import inputs
+    from freesplat_amd.ptf import world_to_camera
+    g = torch.Generator().manual_seed(7)
+    poses = inputs.cameras(12, 96, 128, baseline=0.4, seed=3)[0]
+    rnd = torch.randn(64, 4, 4, generator=g) + 2.0 * torch.eye(4)
+    near = torch.eye(4).repeat(8, 1, 1)
+    near[:, 2] = near[:, 1] * (1 + 1e-3 * torch.arange(1, 9).float())[:, None] + 1e-3 * torch.randn(8, 4, generator=g)   # cond ~ 1e3
+    for name, M in (("poses", poses), ("random", rnd), ("near-singular", near)):
+        want = torch.linalg.inv(M.double())
+        got = world_to_camera(M.to(hip_device)).view(-1, 4, 4).cpu().double()
+        # the float32 INPUT is exact; the only error is the final rounding of each entry (half an ulp), plus the double
+        # solve's own error amplified by the condition number (negligible here)
+        tol = 2.0 ** -23 * want.abs().amax(dim=(1, 2), keepdim=True)
+        assert bool(((got - want).abs() <= tol).all()), (name, float(((got - want).abs() / tol).max()))
+    sing = torch.eye(4)[None].clone()
+    sing[0, 3] = sing[0, 2]
+    assert not bool(torch.isfinite(world_to_camera(sing.to(hip_device))).all())

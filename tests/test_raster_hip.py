@@ -197,7 +197,7 @@ def test_capacity_overflow_retry(hip_device, monkeypatch):
     from freesplat_amd import rasterizer as R
     scene, cams = small_scene(N=3000, H=64, W=64, seed=8)
     vi = view_inputs(scene, cams, 0, 64, 64)
-    monkeypatch.setattr(R, "default_capacity", lambda N, st: 100)
+    monkeypatch.setattr(R, "default_capacity", lambda N, st, H=0, W=0: 100)
     st, _, _ = _check_forward(vi, hip_device)
     assert st["num_rendered"] > 100
 
@@ -220,7 +220,7 @@ def test_tile_key_area_overflow_retry(hip_device, monkeypatch):
         tile_cap *= 2
     assert counts.max() > tile_cap                                # the total fits `cap`, the big tiles' key areas do not
     monkeypatch.setattr(R, "TILE_CULL", False)
-    monkeypatch.setattr(R, "default_capacity", lambda N, s: max(cap, s.retry_cap))
+    monkeypatch.setattr(R, "default_capacity", lambda N, s, H=0, W=0: max(cap, s.retry_cap))
     R._state(hip_device).retry_cap = 0
     (color, _, _, _), _ = hip_forward(vi, hip_device)
     assert R._state(hip_device).retry_cap >= (int(counts.max()) * 64 + 3) // 4       # the retry path was taken
@@ -247,7 +247,7 @@ def test_render_views_overflow_now_and_deferred(hip_device, monkeypatch):
     ref = {k: t.grad.clone() for k, t in g.items()}
     for t in g.values():
         t.grad = None
-    monkeypatch.setattr(R, "default_capacity", lambda N, st: 64)
+    monkeypatch.setattr(R, "default_capacity", lambda N, st, H=0, W=0: 64)
     c2, d2 = render_views(*args)                       # overflows, re-rendered view by view
     assert torch.equal(c2, c_ref) and torch.equal(d2, d_ref)
     (c2 * w).sum().backward()
@@ -274,7 +274,7 @@ def test_deferred_overflow_backward_is_safe(hip_device, monkeypatch):
     dev = hip_device
     g = {k: scene[k].to(dev).requires_grad_(True) for k in ("means", "covariances", "harmonics", "opacities")}
     cam = {k: t.to(dev) for k, t in cams.items()}
-    monkeypatch.setattr(R, "default_capacity", lambda N, st: 64)
+    monkeypatch.setattr(R, "default_capacity", lambda N, st, H=0, W=0: 64)
     color, depth = render_views(cam["extrinsics"], cam["intrinsics"], cam["near"], cam["far"], (H, W),
                                 torch.zeros(v, 3, device=dev), g["means"], g["covariances"], g["harmonics"],
                                 g["opacities"], check="deferred")
