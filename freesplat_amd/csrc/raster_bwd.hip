@@ -11,6 +11,8 @@
 //   preprocess_bwd  1 thread / Gaussian: conic -> cov2D -> Sigma & view position, mean2D ->
 //                   mean through the perspective divide, RGB -> SH & view direction.
 //                   SH gradients leave through LDS so the [N, M, 3] rows are written coalesced.
+#include <cstdlib>
+
 #include "fs_common.h"
 
 namespace fs {
@@ -67,11 +69,14 @@ __device__ __forceinline__ float row_merge(float x, float y, unsigned long long 
     const bool hi = __builtin_amdgcn_inverse_ballot_w64(mask);     // (wave-uniform constant: a v_cndmask on an SGPR pair)
     return (hi ? y : x) + dpp_row<CTRL>(hi ? x : y);
 }
+template <int NV>   // values per survivor that can be non-zero (the tenth, the depth partial, only when depth gradients flow)
 __device__ __forceinline__ float wave_sum_pair(const float (&va)[10], const float (&vb)[10])
 {
     float h[10], t[5];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) h[k] = swap_add32(va[k], vb[k]);
+    for (int k = 0; k < NV; ++k) h[k] = swap_add32(va[k], vb[k]);
+#pragma unroll
+    for (int k = NV; k < 10; ++k) h[k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 5; ++k) t[k] = swap_add16(h[k], h[5 + k]);
     constexpr unsigned long long kBit0 = 0xAAAAAAAAAAAAAAAAull, kBit1 = 0xCCCCCCCCCCCCCCCCull, kBit2 = 0xF0F0F0F0F0F0F0F0ull;
@@ -95,7 +100,11 @@ constexpr int kBwdQuads = 7;  // float4 per slot of two survivors
 //   dL/da_j = T_j * sum_ch (c_j - R_j)_ch * dL/dC_ch  -  Tf / (1 - a_j) * (bg . dL/dC)
 // A survivor that does not touch the pixel enters with a_j = 0 and G_j = 0, which makes every update the identity
 // and every partial zero -- no per-value masking.
-template <bool FAST_EXP>
+// DEPTH = false (dL_ddepth == NULL -- FreeSplat's losses never back-propagate the depth map, src/loss/loss_mse.py:32): the
+// fourth channel of the behind-colour recurrence, of the score s and of the colour partials does not exist; what is left of
+// the (blue, depth) pair runs as scalar operations (packed fp32 has no throughput advantage on this chip, fs_common.h), and
+// the wavefront reduction carries 9 instead of 10 values per survivor.
+template <bool FAST_EXP, bool DEPTH>
 __global__ __launch_bounds__(64) void render_bwd_kernel(
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
     const float Tf = inside ? final_T[pix] : 0.0f;
     const int last = inside ? n_contrib[pix] : 0;
     const f32x2 g01 = {inside ? dL_dcolor[pix] : 0.0f, inside ? dL_dcolor[HW + pix] : 0.0f};
-    const f32x2 g23 = {inside ? dL_dcolor[2 * HW + pix] : 0.0f, (inside && dL_ddepth) ? dL_ddepth[pix] : 0.0f};
+    const f32x2 g23 = {inside ? dL_dcolor[2 * HW + pix] : 0.0f, (DEPTH && inside && dL_ddepth) ? dL_ddepth[pix] : 0.0f};
     const float Tb = Tf * (bg[0] * g01.x + bg[1] * g01.y + bg[2] * g23.x);
 
     int maxlast = last;
@@ -174,28 +183,32 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
         const f32x2 rinv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
         float va[10], vb[10];
         f32x2 dLa;
-        {   // survivor a (the one further back)
-            T_ = T_ * rinv.x;
-            const f32x2 d01 = (f32x2){ka.x, ka.y} - R01, d23 = (f32x2){ka.z, ka.w} - R23;
-            const f32x2 s = fma2(d23, g23, d01 * g01);
-            R01 = fma2(splat2(al.x), d01, R01);
-            R23 = fma2(splat2(al.x), d23, R23);
-            dLa.x = fmaf(s.x + s.y, T_, -(Tb * rinv.x));
-            const f32x2 w = splat2(al.x * T_);
-            const f32x2 c01 = w * g01, c23 = w * g23;
-            va[6] = c01.x; va[7] = c01.y; va[8] = c23.x; va[9] = c23.y;
-        }
-        {   // survivor b (in front of a)
-            T_ = T_ * rinv.y;
-            const f32x2 d01 = (f32x2){kb.x, kb.y} - R01, d23 = (f32x2){kb.z, kb.w} - R23;
-            const f32x2 s = fma2(d23, g23, d01 * g01);
-            R01 = fma2(splat2(al.y), d01, R01);
-            R23 = fma2(splat2(al.y), d23, R23);
-            dLa.y = fmaf(s.x + s.y, T_, -(Tb * rinv.y));
-            const f32x2 w = splat2(al.y * T_);
-            const f32x2 c01 = w * g01, c23 = w * g23;
-            vb[6] = c01.x; vb[7] = c01.y; vb[8] = c23.x; vb[9] = c23.y;
-        }
+        auto one = [&](const float4& kc, float al1, float rinv1, float& dL1, float (&vv)[10]) __attribute__((always_inline)) {
+            T_ = T_ * rinv1;
+            const f32x2 d01 = (f32x2){kc.x, kc.y} - R01;
+            const float w1 = al1 * T_;
+            const f32x2 c01 = splat2(w1) * g01;
+            if constexpr (DEPTH) {
+                const f32x2 d23 = (f32x2){kc.z, kc.w} - R23;
+                const f32x2 s = fma2(d23, g23, d01 * g01);
+                R23 = fma2(splat2(al1), d23, R23);
+                dL1 = fmaf(s.x + s.y, T_, -(Tb * rinv1));
+                const f32x2 c23 = splat2(w1) * g23;
+                vv[8] = c23.x; vv[9] = c23.y;
+            } else {
+                const float d2 = kc.z - R23.x;
+                const f32x2 s = d01 * g01;
+                R23.x = fmaf(al1, d2, R23.x);
+                dL1 = fmaf(fmaf(d2, g23.x, s.x + s.y), T_, -(Tb * rinv1));
+                vv[8] = w1 * g23.x; vv[9] = 0.0f;
+            }
+            R01 = fma2(splat2(al1), d01, R01);
+            vv[6] = c01.x; vv[7] = c01.y;
+        };
+        float dLa_a, dLa_b;
+        one(ka, al.x, rinv.x, dLa_a, va);   // survivor a (the one further back)
+        one(kb, al.y, rinv.y, dLa_b, vb);   // survivor b (in front of a)
+        dLa = (f32x2){dLa_a, dLa_b};
         // per-Gaussian derivative terms of both survivors, packed [a, b].  The five geometric partials leave as MOMENT
         // sums of w = dL/dG * G over the pixels -- S_x = sum w dx, S_y = sum w dy, S_xx = sum w dx^2, S_xy = sum w dx dy,
         // S_yy = sum w dy^2 -- and preprocess_bwd combines them per Gaussian with the conic:
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
         const f32x2 sxx = wdx * dx, sxy = wdx * dy, syy = wdy * dy;
         va[0] = wdx.x; va[1] = wdy.x; va[2] = sxx.x; va[3] = sxy.x; va[4] = syy.x; va[5] = v_op.x;
         vb[0] = wdx.y; vb[1] = wdy.y; vb[2] = sxx.y; vb[3] = sxy.y; vb[4] = syy.y; vb[5] = v_op.y;
-        const float v = wave_sum_pair(va, vb);
+        const float v = wave_sum_pair<DEPTH ? 10 : 9>(va, vb);
         // row r of the wavefront: components 5*(r&1) .. +4 of survivor (r >> 1); lane (r, c < 5) flushes component c
         const float4 ids = q[6];
         if (col < 5) {
@@ -564,12 +577,15 @@ int launch_render_bwd(const fs_raster_dims& d, const float* bg, const void* geom
     const int nblk = tile_grid_blocks((d.W + kTile - 1) / kTile, (d.H + kTile - 1) / kTile);
     {
         ScopedStage prof_(kStRenderBwd, st);
-        if (d.flags & FS_RASTER_FAST_EXP)
-            hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
-                           point_list, g.rec, bg, counters, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
-        else
-            hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets,
-                           point_list, g.rec, bg, counters, final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(4 * nblk), dim3(64), 0, st, d.H, d.W, T, offsets, point_list, g.rec, bg, counters,
+                               final_T, n_contrib, dL_dcolor, dL_ddepth, grad);
+        };
+        // FS_RASTER_BWD_DEPTH=1 forces the depth-channel instantiation without a depth gradient (A/B runs)
+        static const bool force_depth = getenv("FS_RASTER_BWD_DEPTH") && atoi(getenv("FS_RASTER_BWD_DEPTH")) != 0;
+        const bool depth = dL_ddepth != nullptr || force_depth;
+        if (d.flags & FS_RASTER_FAST_EXP) { if (depth) go(render_bwd_kernel<true, true>); else go(render_bwd_kernel<true, false>); }
+        else { if (depth) go(render_bwd_kernel<false, true>); else go(render_bwd_kernel<false, false>); }
     }
     FS_CHECK_LAUNCH("render_bwd");
     return FS_OK;
