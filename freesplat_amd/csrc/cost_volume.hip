@@ -19,8 +19,12 @@
 //     - K >= 2, cost_volume16_kernel: 16-pixel wavefronts, lane = (pixel, channel quarter) with the four lanes of a pixel
 //       adjacent, so that a tap load reads 64 contiguous bytes per quad (the sweep is bound by the delivery of its taps:
 //       1.7x fewer cycles per load instruction than with (pixel, parity) lanes), v_mfma_f32_16x16x4_f32;
-//     - backward, cost_volume_bwd_kernel: 32 pixels x parity on texel-major [y][x][parity][C/2] records, forward
-//       recomputed per plane, every gradient (features and the six MLP tensors) from the one kernel.
+//     - backward (round 4: two passes, no global float atomics on the source maps): cost_volume_bwd_kernel -- 32 pixels x
+//       parity on texel-major [y][x][parity][C/2] records, forward recomputed per plane, the six MLP gradients on the matrix
+//       cores, d cur, and one record per (pixel, plane) point -- then cv_src_grad_kernel, whose single-wavefront workgroups
+//       own 8 x 8 tiles of SOURCE texels and collect, plane by plane, from the pixels whose taps cover them (found through
+//       the inverse plane homography), accumulating in LDS.  (Per-pixel plane depths or K > 16: the round-3 one-kernel
+//       form, which scatters with 192-byte atomic records.)
 #include <algorithm>
 #include <cstdlib>
 

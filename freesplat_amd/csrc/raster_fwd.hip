@@ -240,7 +240,25 @@ __device__ __forceinline__ void stage_rows_half(float* lds, const _Float16* __re
 {
     const _Float16* s = src + base * per;
     const int total = cnt * per;
-    for (int k = threadIdx.x; k < total; k += blockDim.x) lds[k] = (float)s[k];
+    // 16-byte loads of 8 coefficients, two in flight per thread (round 3 loaded ONE 2-byte value per thread and iteration:
+    // 27 dependent trips per workgroup -- the fp16 forward was 7 % SLOWER than the fp32 one, profiles/r4a_bench.json)
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    int done = 0;
+    if ((((uintptr_t)s) & 15) == 0) {
+        const int nv = total >> 3;
+        auto put = [&](int k, const half8 v) {
+            ((float4*)lds)[2 * k] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+            ((float4*)lds)[2 * k + 1] = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+        };
+        int k = threadIdx.x;
+        for (; k + 256 < nv; k += 512) {
+            const half8 v0 = ((const half8*)s)[k], v1 = ((const half8*)s)[k + 256];
+            put(k, v0); put(k + 256, v1);
+        }
+        for (; k < nv; k += 256) put(k, ((const half8*)s)[k]);
+        done = nv << 3;
+    }
+    for (int k = done + threadIdx.x; k < total; k += blockDim.x) lds[k] = (float)s[k];
 }
 
 __global__ __launch_bounds__(256) void preprocess_kernel(

@@ -9,7 +9,8 @@ from freesplat_amd.ptf import match_view, positional_encoding, world_to_camera
 def fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
                          depth_thres=0.1):
     """The fold step by step in torch device ops on the HIP index lists (fs_ptf_match), differentiable through
-    autograd; one host sync per view.  Used for b > 1 and as the cross-check of _PtfFold's backward."""
+    autograd; one host sync per view.  The cross-check of _PtfFold's backward (the product folds one scene per call, like the
+    reference's caller, and raises for b > 1)."""
     length = gaussians[0].shape[1]
     G = gaussians[0][:, 0]
     R = densities[:, 0]

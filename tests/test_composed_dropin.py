@@ -259,7 +259,7 @@ def test_composed_dropin_forward_backward_vs_oracle_chain(hip_device, b):
     err = (img.detach().cpu() - ref_img.detach()).abs().flatten()
     p999 = float(err.kthvalue(int(0.999 * err.numel())).values)
     assert float(err.mean()) <= 2e-5 and p999 <= 2e-3 and float(err.max()) <= 0.1, (float(err.max()), p999, float(err.mean()))
-    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss))), (float(loss), float(ref_loss))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-5 * max(1.0, abs(float(ref_loss.detach()))), (float(loss.detach()), float(ref_loss.detach()))
     # ---- backward: every parameter of the chain ----
     assert set(g_hip) == set(g_ref) and len(g_ref) >= 30
     bad = []
