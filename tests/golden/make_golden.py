@@ -285,8 +285,58 @@ def gen_ply():
          table=table, names=np.array(el.dtype.names))
 
 
+def gen_backward():
+    """Gradients computed by autograd THROUGH THE REFERENCE'S OWN MODULES (round 4): the cost volume's w.r.t. both feature
+    maps and the six MLP tensors for a seeded grad_out, and the fold's w.r.t. latents, coordinates, densities, weights and
+    the 12 GRU tensors for seeded output weights -- they pin the oracles' autograd (CPU) and the HIP backward kernels (GPU)
+    to the reference directly, not only through the equality of the forwards."""
+    from src.model.encoder.modules.cost_volume import AVGFeatureVolumeManager
+    from src.model.encoder.encoder_freesplat import EncoderFreeSplat
+    from src.model.encoder.modules.networks import GRU
+    from src.model.encoder.common.gaussian_adapter import GaussianAdapter, GaussianAdapterCfg
+    from src.geometry.projection import sample_image_grid
+    # ---- cost volume: the cv_small_k2 case (3 views, 2 sources, one of them turned round) ----
+    V, K, C, h4, w4, D = 3, 2, 48, 12, 16, 8
+    torch.manual_seed(100 + V)
+    cv = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1],
+                                 matching_dim_size=C).eval()
+    kw = cv_inputs(V, K, h4, w4, C, seed=200 + V, behind=True)
+    kw["cur_feats"].requires_grad_(True)
+    kw["src_feats"].requires_grad_(True)
+    out = cv(**kw)
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(77))
+    (out * g).sum().backward()
+    net = cv.mlp.net
+    save("cv_small_k2_grads.npz", grad_out=g, out=out, d_cur_feats=kw["cur_feats"].grad, d_src_feats=kw["src_feats"].grad,
+         d_w1=net[0].weight.grad, d_b1=net[0].bias.grad, d_w2=net[2].weight.grad, d_b2=net[2].bias.grad,
+         d_w3=net[4].weight.grad, d_b3=net[4].bias.grad)
+    # ---- PTF: the ptf_small case (3 views, 24 x 32) ----
+    V, h, w = 3, 24, 32
+    E, Kn, depths, lat, dens, wts = ptf_inputs(V, h, w, seed=300 + V, tie=False)
+    torch.manual_seed(400 + V)
+    gru = GRU().eval()
+    adapter = GaussianAdapter(GaussianAdapterCfg(0.5, 15.0, 2))
+    with torch.no_grad():
+        xy_ray, _ = sample_image_grid((h, w), torch.device("cpu"))
+        xy_ray = xy_ray.reshape(h * w, 1, 2)[None, None].expand(1, V, h * w, 1, 2)
+        coords = adapter.forward(E[None, :, None, None, None], Kn[None, :, None, None, None], xy_ray[:, :, :, :, None, :],
+                                 depths.view(1, V, h * w, 1, 1), dens, lat, (h, w), fusion=True)
+    leaves = [t.clone().requires_grad_(True) for t in (lat, coords, dens, wts)]
+    out = EncoderFreeSplat.fuse_gaussians(types.SimpleNamespace(gru=gru), [leaves[0]], [leaves[1]], leaves[2], leaves[3],
+                                          depths.view(V, 1, h, w), E[None], Kn[None], (h, w))
+    gen = torch.Generator().manual_seed(78)
+    ws = [torch.randn(o.shape, generator=gen) for o in out]
+    sum((o * w_).sum() for o, w_ in zip(out, ws)).backward()
+    save("ptf_small_grads.npz", w_latent=ws[0], w_xyz=ws[1], w_extrinsics=ws[2], w_depths=ws[3],
+         d_latents=leaves[0].grad, d_coords=leaves[1].grad, d_densities=leaves[2].grad, d_weights=leaves[3].grad,
+         **{"d_gru__" + k.replace(".", "__"): p_.grad for k, p_ in gru.named_parameters()})
+
+
 if __name__ == "__main__":
     install_shim()
+    if ONLY == {"backward"}:          # python make_golden.py backward: only the gradient fixtures
+        gen_backward()
+        sys.exit(0)
     if ONLY:
         gen_cost_volume()
         sys.exit(0)
@@ -296,3 +346,4 @@ if __name__ == "__main__":
     gen_framing()
     gen_cost_volume()
     gen_ptf_and_adapter()
+    gen_backward()

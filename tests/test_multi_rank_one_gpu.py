@@ -53,3 +53,9 @@ def test_bench_two_ranks_runs_the_sharded_branch(hip_device, mode):
     want = "reduce_scatter(gaussian grads)" if mode == "train" else "all_gather(color)"
     assert d["config"]["parallelism"] == f"view-sharded x2 + {want}", d["config"]
     assert d["roofline"]["launches"] == 2 * 3 * len(d["timed_regions_ms"])     # rank 0's own views of every timed region
+    if mode == "fwd":
+        # the N > 1 diagnostics: per rank one step on the render stream, the all-gather on the side stream, and the part of
+        # it the rendering did not hide (the render stream's wait)
+        per = d["multi_gpu"]["per_rank"]
+        assert len(per) == 2 and all(r["step_ms"] > 0 and r["gather_ms"] > 0 and 0 <= r["exposed_gather_ms"] <= r["step_ms"] + r["gather_ms"]
+                                     for r in per), per

@@ -247,3 +247,28 @@ def test_invert_4x4_vs_float64_inverse(hip_device):
     sing = torch.eye(4)[None].clone()
     sing[0, 3] = sing[0, 2]
     assert not bool(torch.isfinite(world_to_camera(sing.to(hip_device))).all())
+
+
+def test_fold_backward_matches_reference_gradients(hip_device):
+    """The HIP fold's backward (_PtfFold: fs_ptf_write_state_backward, fs_ptf_gru_backward, fs_ptf_gru_inputs_backward)
+    against gradients computed THROUGH THE REFERENCE'S OWN fuse_gaussians + GRU (tests/golden/ptf_small_grads.npz,
+    make_golden.gen_backward): latents, coordinates, densities, weights and the 12 GRU tensors."""
+    from freesplat_amd.ptf import PixelwiseTripletFusion
+    g, gru = _load("ptf_small.npz")
+    z = np.load(os.path.join(HERE, "golden", "ptf_small_grads.npz"))
+    gg = {k: torch.from_numpy(z[k]) for k in z.files}
+    m = PixelwiseTripletFusion()
+    m.gru.load_state_dict(gru, strict=True)
+    m = m.to(hip_device)
+    d = lambda t: t.to(hip_device)
+    leaves = [d(g[k]).requires_grad_(True) for k in ("latents", "coords", "densities", "weights")]
+    out = m.fuse_gaussians([leaves[0]], [leaves[1]], leaves[2], leaves[3], d(g["depths"]), d(g["extrinsics"])[None],
+                           d(g["intrinsics"])[None], (int(g["h"]), int(g["w"])))
+    assert out[0].shape == gg["w_latent"].shape
+    sum((o * d(gg[k])).sum() for o, k in zip(out, ("w_latent", "w_xyz", "w_extrinsics", "w_depths"))).backward()
+    rel = lambda a, b: float((a.cpu() - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+    for t, key in zip(leaves, ("d_latents", "d_coords", "d_densities", "d_weights")):
+        assert t.grad.shape == gg[key].shape and rel(t.grad, gg[key]) < 1e-3, (key, rel(t.grad, gg[key]))
+    for k, p_ in m.gru.named_parameters():
+        want = gg["d_gru__" + k.replace(".", "__")]
+        assert rel(p_.grad, want) < 2e-3, (k, rel(p_.grad, want))

@@ -50,3 +50,24 @@ def test_match_step_edge_cases():
     # point 2 -> px = 2.5 -> col 2 (half to even), py = 1.5 -> row 2 ; point 3 -> px 0.5 -> col 0
     assert list(fuse) == [2, 3] and list(fpix) == [2 * w + 2, 2 * w + 0]
     assert list(keep) == [0, 1] and len(app) == h * w - 2
+
+
+def test_oracle_autograd_matches_reference_backward():
+    """Gradients through the oracle's fold (torch autograd) against gradients through the REFERENCE'S OWN fuse_gaussians
+    (tests/golden/ptf_small_grads.npz, make_golden.gen_backward: encoder_freesplat.py:431-522 with networks.py:188-214): latents,
+    coordinates, densities, weights and the 12 GRU tensors, seeded weights on all four outputs."""
+    g, gru = load("ptf_small.npz")
+    z = np.load(os.path.join(HERE, "golden", "ptf_small_grads.npz"))
+    gg = {k: torch.from_numpy(z[k]) for k in z.files}
+    h, w = int(g["h"]), int(g["w"])
+    params = {k: v.clone().requires_grad_(True) for k, v in gru.items()}
+    leaves = [g[k].clone().requires_grad_(True) for k in ("latents", "coords", "densities", "weights")]
+    out = po.fuse_gaussians(params, leaves[0], leaves[1], leaves[2], leaves[3], g["depths"], g["extrinsics"][None],
+                            g["intrinsics"][None], (h, w))
+    sum((o * gg[k]).sum() for o, k in zip(out, ("w_latent", "w_xyz", "w_extrinsics", "w_depths"))).backward()
+    rel = lambda a, b: float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+    for t, key in zip(leaves, ("d_latents", "d_coords", "d_densities", "d_weights")):
+        assert t.grad.shape == gg[key].shape and rel(t.grad, gg[key]) < 2e-5, (key, rel(t.grad, gg[key]))
+    for k, p_ in params.items():
+        want = gg["d_gru__" + k.replace(".", "__")]
+        assert rel(p_.grad, want) < 5e-5, (k, rel(p_.grad, want))
