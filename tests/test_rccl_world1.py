@@ -57,3 +57,8 @@ def test_bench_single_rank_takes_the_rccl_branch(hip_device, mode, extra):
     assert d["n_gpus"] == 1 and d["value"] > 0
     want = "reduce_scatter(gaussian grads)" if mode == "train" else ("all_gather(color,depth)[uint8]" if extra else "all_gather(color)")
     assert d["config"]["parallelism"] == f"view-sharded x1 + {want}", d["config"]
+    if mode == "fwd":   # the N > 1 diagnostics, on RCCL: step / gather / exposed-gather times of the (one) rank
+        per = d["multi_gpu"]["per_rank"]
+        assert len(per) == 1 and per[0]["step_ms"] > 0 and per[0]["gather_ms"] > 0 and per[0]["exposed_gather_ms"] >= 0, per
+        bytes_per = 3 * 256 * 256 * (4 if extra else 3) * (1 if extra else 4)
+        assert d["multi_gpu"]["gather_bytes_per_rank_per_step"] == bytes_per, d["multi_gpu"]
