@@ -1697,6 +1697,10 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
     // into a zeroed map)
     int chunks = 1;
     while ((long long)B * K * tiles * chunks < 2816 && D / (chunks * 2) >= kSgG) chunks *= 2;
+    if (const char* e = getenv("FS_CV_SG_CHUNKS")) {   // (tests: force the plain-store form, chunks = 1, at small sizes, or any split)
+        const int f = atoi(e);
+        if (f >= 1 && f <= D) chunks = f;
+    }
     ScopedStage prof_(kStCostVolume, st);
     hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics, Pmat);
     if (two_pass) {

@@ -343,3 +343,30 @@ def test_backward_matches_reference_gradients(hip_device, form, monkeypatch):
         assert e.mean().item() < 1e-4 and e.max().item() < 2e-2, (key, e.max().item(), e.mean().item())
         if e.numel() > 1000:
             assert e.kthvalue(int(0.995 * e.numel())).values.item() < 1e-3, key
+
+
+@pytest.mark.parametrize("chunks", ["1", "3", "16"])
+def test_tile_sweep_plane_chunks_agree(hip_device, chunks, monkeypatch):
+    """The source-tile sweep splits the planes of a tile over several workgroups when there are too few tiles to fill the
+    chip (their tiles then leave through atomics into a zeroed map) and walks them in ONE workgroup otherwise (plain
+    stores).  The parity cases above are small, i.e. all of the first kind; here the split is forced (FS_CV_SG_CHUNKS: 1 =
+    the plain-store form of the full-size workloads, 3 = a ragged split, 16 = one plane per workgroup): same source-feature
+    gradient as the library's own choice."""
+    import inputs
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    V, K, h4, w4, D, C = 4, 3, 27, 35, 16, 48
+    torch.manual_seed(8)
+    m = AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C).to(hip_device)
+    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=91)
+    g = torch.randn(V, D, h4, w4, generator=torch.Generator().manual_seed(6)).to(hip_device)
+    monkeypatch.setenv("FREESPLAT_CV_SAVE", "0")
+    res = []
+    for forced in (None, chunks):
+        if forced is not None:
+            monkeypatch.setenv("FS_CV_SG_CHUNKS", forced)
+        a = {k: v.to(hip_device) for k, v in kw.items()}
+        a["src_feats"].requires_grad_(True)
+        (m(**a) * g).sum().backward()
+        res.append(a["src_feats"].grad.cpu())
+    scale = res[0].abs().max().item()
+    assert scale > 0 and (res[0] - res[1]).abs().max().item() <= 2e-6 * scale
