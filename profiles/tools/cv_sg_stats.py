@@ -13,15 +13,17 @@ import inputs  # noqa: E402
 from freesplat_amd import _lib  # noqa: E402
 from freesplat_amd.cost_volume import AVGFeatureVolumeManager  # noqa: E402
 
-WL = {"native_K1": (2, 1, 96, 128), "c3scale_K2": (3, 2, 242, 324), "fvt10_K8": (10, 8, 96, 128), "small": (3, 2, 48, 64)}
+WL = {"native_K1": (2, 1, 96, 128), "c3scale_K2": (3, 2, 242, 324), "fvt10_K8": (10, 8, 96, 128), "small": (3, 2, 48, 64),
+      "oblique": (3, 2, 30, 40)}     # (one view turned by 1.2 rad: tiles that straddle the planes' horizon walk the whole image)
 L = _lib.lib()
 dev = torch.device("cuda:0")
 for name in (sys.argv[1:] or ["small", "native_K1", "fvt10_K8"]):
     V, K, h4, w4 = WL[name]
-    D, C = 128, 48
+    D, C = (16 if name == "oblique" else 128), 48
     torch.manual_seed(0)
     m = AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C).to(dev)
-    a = {k: v.to(dev) for k, v in inputs.cv_inputs(V, K, h4, w4, C, seed=1).items()}
+    a = {k: v.to(dev) for k, v in inputs.cv_inputs(V, K, h4, w4, C, seed=34 if name == "oblique" else 1,
+                                                    oblique=1.2 if name == "oblique" else 0.0).items()}
     a["cur_feats"].requires_grad_(True); a["src_feats"].requires_grad_(True)
     o = m(**a)
     buf = (ctypes.c_ulonglong * 8)()

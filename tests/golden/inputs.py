@@ -19,11 +19,16 @@ def cameras(V, h, w, baseline=0.25, seed=0):
 
 
 
-def cv_inputs(V, K, h4, w4, C, seed, behind=False):
+def cv_inputs(V, K, h4, w4, C, seed, behind=False, oblique=0.0):
     """The 8 kwargs of cost_volume.forward as EncoderFreeSplat.forward prepares them
-    (encoder_freesplat.py:216-288) for b=1, V views, each with its K nearest = all-other views."""
+    (encoder_freesplat.py:216-288) for b=1, V views, each with its K nearest = all-other views.
+    `oblique` (radians): the last view is turned about its y axis by that much -- from ~1 rad on, the horizon of the depth
+    planes crosses its image (rays parallel to the planes: projections through infinity, tiles partly behind the camera)."""
     torch.manual_seed(seed)
     E, Kn = cameras(V, h4, w4, seed=seed)
+    if oblique:
+        R = torch.tensor([[np.cos(oblique), 0, np.sin(oblique)], [0, 1, 0], [-np.sin(oblique), 0, np.cos(oblique)]], dtype=torch.float32)
+        E[-1, :3, :3] = E[-1, :3, :3] @ R
     if behind:  # one source looks away / sits in front of the points: exercises the z>0 mask + zero padding
         E[-1, :3, 3] += torch.tensor([0.0, 0.0, 1.2])
         E[-1, :3, :3] = E[-1, :3, :3] @ torch.tensor([[-1.0, 0, 0], [0, 1, 0], [0, 0, -1.0]])

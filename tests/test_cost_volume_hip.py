@@ -212,6 +212,10 @@ BWD_CASES = {
     "k2_60x80": (3, 2, 60, 80, 32, 48, False, None),
     "k2_behind": (3, 2, 30, 40, 16, 48, True, None),
     "k3_c16": (4, 3, 28, 36, 12, 16, False, None),
+    # one view turned by 1.2 rad: the planes' horizon crosses its image -- as a SOURCE its tiles straddle the horizon (the tile
+    # sweep's whole-image fallback: 320 of 1 920 (tile, plane) cells, 128 more entirely behind), as the CURRENT view its rays
+    # run parallel to the planes
+    "k2_oblique": (3, 2, 30, 40, 16, 48, "oblique", None),
     "native_k1": (2, 1, 96, 128, 128, 48, False, (1,)),
 }
 
@@ -245,7 +249,8 @@ def test_backward_tight_vs_float64_oracle(hip_device, case, form, monkeypatch):
     torch.manual_seed(V * 10 + K)
     m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D,
                                 mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
-    kw = inputs.cv_inputs(V, K, h4, w4, C, seed=31 + V, behind=behind)
+    kw = (inputs.cv_inputs(V, K, h4, w4, C, seed=31 + V, oblique=1.2) if behind == "oblique" else
+          inputs.cv_inputs(V, K, h4, w4, C, seed=31 + V, behind=behind))
     vs = list(range(V)) if views is None else list(views)
     kw = {k: (v[vs] if k not in ("min_depth", "max_depth") else v) for k, v in kw.items()}
     B = len(vs)
