@@ -190,3 +190,24 @@ def test_overflow_capacity_is_per_image_size_and_decays():
     st.note_overflow(5_000_000, 50_000, H, W)
     st.retry_cap = 0                                                       # (bench / tests reset the history)
     assert R.default_capacity(N, st, H, W) == base
+
+
+def test_traffic_lookup_refuses_kernels_the_library_no_longer_contains():
+    """bench.py / bench_encoder.py read `roofline.traffic` through profiles/tools/fwd_traffic.lookup(); a committed traffic file
+    that names a kernel the shipped library does not contain (round 3's K >= 2 rows named the deleted cost_volume_kernel<24>)
+    must be skipped for that workload -- checked against the built library's embedded code object, no GPU needed."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "profiles", "tools"))
+    import fwd_traffic
+    assert fwd_traffic.kernel_shipped("fs::cost_volume16_kernel<48, false>") and fwd_traffic.kernel_shipped("fs::cv_src_grad_kernel<48>")
+    assert fwd_traffic.kernel_shipped("fs::sort_blend_kernel<false, false>")
+    assert not fwd_traffic.kernel_shipped("fs::cost_volume_kernel<24>") and not fwd_traffic.kernel_shipped("fs::cv_transpose_kernel")
+    r3 = json.load(open(os.path.join(root, "profiles", "r3_traffic.json")))["workloads"]
+    assert any("cost_volume_kernel<24>" in k for k in r3["cv_fvt10_K8"]["kernels"])          # the stale row is still in the old file
+    val, src = fwd_traffic.lookup("cv_fvt10_K8")
+    assert src is not None and "r3_traffic" not in src and val < 2e9                          # ... and is not what gets reported
+    val, src = fwd_traffic.lookup("cvt_fvt10_K8")
+    assert src is not None and val > 1e10                                                     # the training step's rows exist
