@@ -62,6 +62,7 @@ SIGNATURES = {
     "fs_cost_volume_forward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 9),
     "fs_cost_volume_backward_workspace_bytes": (C.c_size_t, [C.c_int32] * 6),
     "fs_cost_volume_backward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 16),
+    "fs_cost_volume_depth_planes": (C.c_int, [C.c_int32] + [_VP] * 5),
     "fs_cost_volume_saved_bytes": (C.c_size_t, [C.c_int32] * 5),
     "fs_cost_volume_forward_train": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 10),
     "fs_cost_volume_backward_train": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 17),

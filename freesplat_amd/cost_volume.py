@@ -163,7 +163,19 @@ class AVGFeatureVolumeManager(nn.Module):
         B, K, C, h, w = src_feats.shape
         if (h, w) != (self.matching_height, self.matching_width):
             raise RuntimeError("feature maps do not match matching_height/width")
-        if depth_planes_bdhw is None:
+        if depth_planes_bdhw is None and min_depth.numel() == 1 and max_depth.numel() == 1:
+            # the call of encoder_freesplat.py:280-288 (near / far of the first view): generate_depth_planes in ONE launch,
+            # rounded operation by operation as the module's eight elementwise torch launches round it
+            D = self.num_depth_bins
+            flat = torch.empty(D, dtype=torch.float32, device=src_feats.device)
+            md, Md = _dev32(min_depth.reshape(1), "min_depth"), _dev32(max_depth.reshape(1), "max_depth")
+            ramp = _dev32(self.linear_ramp_1d11.reshape(D), "linear_ramp_1d11")
+            p = _lib.ptr
+            _lib.check(_lib.lib().fs_cost_volume_depth_planes(D, p(md), p(Md), p(ramp), p(flat), _lib.current_stream()),
+                       "fs_cost_volume_depth_planes")
+            self.depth_planes_bdhw = flat.view(1, D, 1, 1).expand(B, D, h, w)     # (the attribute the reference leaves, :133)
+            strides = (0, 1, 0)
+        elif depth_planes_bdhw is None:
             planes = self.generate_depth_planes(B, min_depth, max_depth)
             flat = _dev32(planes[0, :, 0, 0], "depth planes")   # [D]: identical for every batch row / pixel
             if planes.shape[0] > 1 and planes.stride(0) != 0:

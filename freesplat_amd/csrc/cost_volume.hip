@@ -1181,41 +1181,60 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
 // owns a TILE of 16 x 16 source texels of one (view, source) -- its gradient lives in LDS, channel-planar, for the whole
 // sweep -- and walks the planes: for plane d the current pixels that can touch the tile are the preimage of the tile
 // rectangle (grown by the bilinear footprint) under the plane-induced homography, a convex quadrilateral whose bounding
-// box comes from the four corners through the INVERSE homography (cv_ginv_kernel; profiles/tools/cv_tile_box_count.py
+// box comes from the four corners through the INVERSE homography (cv_bwd_prep_kernel; profiles/tools/cv_tile_box_count.py
 // checks on the CPU that no pixel with a tap in a tile falls outside its box, and counts 1.0 - 1.1 visited pixels per
 // (pixel, plane, source)).  Every pixel of the box is projected exactly as the first pass did, and the taps that fall
 // into the tile are added into LDS (see below how); the tile leaves once, as plain stores in the caller's [C, h, w] layout.
 // Tiles whose corners are all behind the source (c < 0 <=> z_k < 0) skip the plane; a tile that straddles the plane's
 // horizon walks the whole image (never seen with forward-looking cameras; exercised by the tests' turned-round source).
 // ==========================================================================================
-__global__ void cv_ginv_kernel(int n_maps, int K, int D, const float* __restrict__ Pmat, const float* __restrict__ cur_invK,
-                               const float* __restrict__ planes, long long ps_b, long long ps_d, float* __restrict__ Ginv)
+// One launch for the backward's small preparations (seven hipMemsetAsync + two kernels before): the projection rows P of every
+// (view, source), the inverse plane homographies of the two-pass form (each thread forms the P it needs itself), and zeros in the
+// six MLP-gradient tensors, which the sweep accumulates into with atomics.  At the native size a training step is ~1.25 ms of
+// kernels, and every launch is ~5 us of it.
+__global__ __launch_bounds__(256) void cv_bwd_prep_kernel(
+    int n_maps, int K, int D, int C, int with_ginv, const float* __restrict__ src_Ks, const float* __restrict__ src_extrinsics,
+    const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b, long long ps_d, float* __restrict__ Pmat,
+    float* __restrict__ Ginv, float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
+    float* __restrict__ gw3, float* __restrict__ gb3)
 {
-    // G_d = d * P[:, :3] * invK[:3, :3] + P[:, 3] e3^T maps (u + .5, v + .5, 1) to (x z, y z, z) in the source; its inverse
-    // in double precision, rounded once (NaN when singular: the sweep then walks the whole image)
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_maps * D) return;
-    const int m = e / D, d = e - m * D, b = m / K;
-    const double depth = (double)planes[b * ps_b + d * ps_d];
-    const float* P = Pmat + (size_t)m * 12;
-    const float* iK = cur_invK + (size_t)b * 16;
-    double G[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double a = 0.0;
-            for (int l = 0; l < 3; ++l) a += (double)P[4 * i + l] * (double)iK[4 * l + j];
-            G[3 * i + j] = depth * a + (j == 2 ? (double)P[4 * i + 3] : 0.0);
-        }
-    const double c00 = G[4] * G[8] - G[5] * G[7], c01 = G[5] * G[6] - G[3] * G[8], c02 = G[3] * G[7] - G[4] * G[6];
-    const double det = G[0] * c00 + G[1] * c01 + G[2] * c02;
-    const double id = 1.0 / det;   // (inf / NaN propagate)
-    float* o = Ginv + (size_t)e * 9;
-    const double nan_ = __longlong_as_double(0x7ff8000000000000ll);
-    const bool bad = !(fabs(det) > 0.0) || !(fabs(id) < 1e300);
-    const double r[9] = {c00, G[2] * G[7] - G[1] * G[8], G[1] * G[5] - G[2] * G[4],
-                         c01, G[0] * G[8] - G[2] * G[6], G[2] * G[3] - G[0] * G[5],
-                         c02, G[1] * G[6] - G[0] * G[7], G[0] * G[4] - G[1] * G[3]};
-    for (int i = 0; i < 9; ++i) o[i] = (float)(bad ? nan_ : r[i] * id);
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    auto p_entry = [&](int m, int i, int j) {
+        const float* Ks = src_Ks + (size_t)m * 16;
+        const float* Tx = src_extrinsics + (size_t)m * 16;
+        return Ks[4 * i] * Tx[j] + Ks[4 * i + 1] * Tx[4 + j] + Ks[4 * i + 2] * Tx[8 + j] + Ks[4 * i + 3] * Tx[12 + j];   // (= cv_proj_kernel)
+    };
+    if (e < n_maps * 12) Pmat[e] = p_entry(e / 12, (e % 12) / 4, e % 4);
+    const int nw1 = 32 * (C + 1);
+    if (e < nw1) gw1[e] = 0.0f;
+    if (e < 32 * 32) gw2[e] = 0.0f;
+    if (e < 32) { gb1[e] = 0.0f; gb2[e] = 0.0f; gw3[e] = 0.0f; }
+    if (e == 0) gb3[0] = 0.0f;
+    if (with_ginv && e < n_maps * D) {
+        const int m = e / D, d = e - m * D, b = m / K;
+        const double depth = (double)planes[b * ps_b + d * ps_d];
+        const float* iK = cur_invK + (size_t)b * 16;
+        float P[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) P[q] = p_entry(m, q / 4, q % 4);
+        double G[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double a = 0.0;
+                for (int l = 0; l < 3; ++l) a += (double)P[4 * i + l] * (double)iK[4 * l + j];
+                G[3 * i + j] = depth * a + (j == 2 ? (double)P[4 * i + 3] : 0.0);
+            }
+        const double c00 = G[4] * G[8] - G[5] * G[7], c01 = G[5] * G[6] - G[3] * G[8], c02 = G[3] * G[7] - G[4] * G[6];
+        const double det = G[0] * c00 + G[1] * c01 + G[2] * c02;
+        const double id = 1.0 / det;
+        const double nan_ = __longlong_as_double(0x7ff8000000000000ll);
+        const bool bad = !(fabs(det) > 0.0) || !(fabs(id) < 1e300);
+        const double r[9] = {c00, G[2] * G[7] - G[1] * G[8], G[1] * G[5] - G[2] * G[4],
+                             c01, G[0] * G[8] - G[2] * G[6], G[2] * G[3] - G[0] * G[5],
+                             c02, G[1] * G[6] - G[0] * G[7], G[0] * G[4] - G[1] * G[3]};
+        float* o = Ginv + (size_t)e * 9;
+        for (int i = 0; i < 9; ++i) o[i] = (float)(bad ? nan_ : r[i] * id);
+    }
 }
 
 constexpr int kSgTW = 8, kSgTH = 8, kSgG = 4;
@@ -1702,22 +1721,14 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
         if (f >= 1 && f <= D) chunks = f;
     }
     ScopedStage prof_(kStCostVolume, st);
-    hipLaunchKernelGGL(cv_proj_kernel, dim3((B * K * 12 + 255) / 256), dim3(256), 0, st, B * K, src_Ks, src_extrinsics, Pmat);
-    if (two_pass) {
-        hipLaunchKernelGGL(cv_ginv_kernel, dim3((B * K * D + 255) / 256), dim3(256), 0, st, B * K, K, D, Pmat, cur_invK, planes,
-                           (long long)plane_stride_b, (long long)plane_stride_d, Ginv);
-        if (chunks > 1 && hipMemsetAsync(d_src_feats, 0, n_src * sizeof(float), st) != hipSuccess) {
-            set_last_error("cost volume backward memset", hipGetLastError());
-            return FS_ERR_LAUNCH;
-        }
+    {
+        const int n_thr = std::max(std::max(B * K * 12, 32 * (C + 1)), std::max(32 * 32, two_pass ? B * K * D : 0));
+        hipLaunchKernelGGL(cv_bwd_prep_kernel, dim3((n_thr + 255) / 256), dim3(256), 0, st, B * K, K, D, C, two_pass ? 1 : 0, src_Ks,
+                           src_extrinsics, cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d, Pmat, Ginv, d_w1, d_b1,
+                           d_w2, d_b2, d_w3, d_b3);
     }
-    if (hipMemsetAsync(d_curT, 0, (two_pass ? n_cur : n_cur + n_src) * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(d_w1, 0, 32 * (size_t)(C + 1) * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(d_b1, 0, 32 * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(d_w2, 0, 32 * 32 * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(d_b2, 0, 32 * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(d_w3, 0, 32 * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(d_b3, 0, sizeof(float), st) != hipSuccess) {
+    if ((two_pass && chunks > 1 && hipMemsetAsync(d_src_feats, 0, n_src * sizeof(float), st) != hipSuccess) ||
+        hipMemsetAsync(d_curT, 0, (two_pass ? n_cur : n_cur + n_src) * sizeof(float), st) != hipSuccess) {
         set_last_error("cost volume backward memset", hipGetLastError());
         return FS_ERR_LAUNCH;
     }

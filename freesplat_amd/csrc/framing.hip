@@ -111,6 +111,20 @@ __global__ void invert4x4_kernel(int n, const float* __restrict__ src, float* __
     for (int k = 0; k < 16; ++k) dst[16 * i + k] = ok ? (float)o[k] : __builtin_nanf("");
 }
 
+// generate_depth_planes (cost_volume.py:116-125) in one launch, op by op -- 1 / min, 1 / max, min^-1 + (max^-1 - min^-1) * ramp,
+// 1 / that, every operation rounded as torch rounds it -- instead of the module's eight elementwise launches.  (It lives in THIS
+// translation unit because cost_volume.hip is built with -ffp-contract=fast, under which the backend fuses the multiply-add
+// whatever the source says: one rounding less than torch's.)
+__global__ void cv_depth_planes_kernel(int D, const float* __restrict__ min_depth, const float* __restrict__ max_depth,
+                                       const float* __restrict__ ramp, float* __restrict__ out)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const float inv_min = 1.0f / min_depth[0], inv_max = 1.0f / max_depth[0];
+    const float step = (inv_max - inv_min) * ramp[d];
+    out[d] = 1.0f / (inv_min + step);
+}
+
 }  // namespace fs
 
 using namespace fs;
@@ -136,5 +150,15 @@ FS_API int fs_frame_views(int32_t v, const float* extrinsics, const float* intri
     hipLaunchKernelGGL(frame_views_kernel, dim3((v + 63) / 64), dim3(64), 0, (hipStream_t)stream_, v, extrinsics,
                        intrinsics, near, far, scale_invariant, view, full, campos, tanfov, scale);
     FS_CHECK_LAUNCH("frame_views");
+    return FS_OK;
+}
+
+FS_API int fs_cost_volume_depth_planes(int32_t D, const float* min_depth, const float* max_depth, const float* ramp, float* planes,
+                                       void* stream_)
+{
+    if (D <= 0 || !min_depth || !max_depth || !ramp || !planes) return FS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cv_depth_planes_kernel, dim3((D + 127) / 128), dim3(128), 0, (hipStream_t)stream_, D, min_depth, max_depth, ramp,
+                       planes);
+    FS_CHECK_LAUNCH("cost_volume_depth_planes");
     return FS_OK;
 }

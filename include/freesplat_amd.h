@@ -180,6 +180,11 @@ int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const f
  * Plane-sweep cost volume                                                               *
  * ------------------------------------------------------------------------------------ */
 
+/* generate_depth_planes (cost_volume.py:98-134) in one launch: planes[d] = 1 / (1/min + (1/max - 1/min) * ramp[d]), every
+ * operation rounded as torch rounds it; min_depth, max_depth: device scalars, ramp[D] = the module's `linear_ramp_1d11`. */
+int fs_cost_volume_depth_planes(int32_t D, const float* min_depth, const float* max_depth, const float* ramp,
+                                float* planes, void* stream);
+
 /* Bytes of the re-layout workspace fs_cost_volume_forward needs (pixel-major copies of the
  * current and source feature maps). */
 size_t fs_cost_volume_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w);

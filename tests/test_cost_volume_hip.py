@@ -411,3 +411,28 @@ def test_two_pass_backward_equals_scatter_form_on_random_shapes(hip_device, seed
     for x, y, n in zip(res["two_pass"], res["atomic"], names):
         scale = y.abs().max().item() + 1e-30
         assert torch.isfinite(x).all() and (x - y).abs().max().item() / scale < 2e-4, (n, V, K, h4, w4, D, C, mode, (x - y).abs().max().item() / scale)
+
+
+@pytest.mark.parametrize("D,near,far", [(128, 0.5, 15.0), (64, 0.25, 20.0), (7, 1.0, 3.0)])
+def test_depth_planes_kernel_is_bitwise_generate_depth_planes(hip_device, D, near, far):
+    """fs_cost_volume_depth_planes (what the module's forward uses for the reference's call, one launch) against
+    cost_volume.py:116-125 evaluated op by op in IEEE float32 on the CPU (= the reference-pinned oracle's planes): identical
+    bits; against the same ops as torch launches on the device (whose reciprocal is not correctly rounded): within an ulp;
+    and the module leaves the reference's `depth_planes_bdhw` attribute (an expanded view of the same values)."""
+    import inputs
+    from freesplat_amd.cost_volume import AVGFeatureVolumeManager
+    from oracle import cost_volume_oracle as cvo
+    h4, w4, C = 12, 16, 48
+    m = AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C)
+    cpu = m.generate_depth_planes(2, torch.tensor(near).view(1, 1, 1, 1), torch.tensor(far).view(1, 1, 1, 1)).clone()
+    assert torch.equal(cpu[0, :, 0, 0], cvo.depth_planes(near, far, D))
+    m = m.to(hip_device)
+    kw = {k: v.to(hip_device) for k, v in inputs.cv_inputs(2, 1, h4, w4, C, seed=3).items()}
+    kw["min_depth"] = torch.tensor(near, device=hip_device).view(1, 1, 1, 1)
+    kw["max_depth"] = torch.tensor(far, device=hip_device).view(1, 1, 1, 1)
+    with torch.no_grad():
+        m(**kw)
+        got = m.depth_planes_bdhw
+        dev = m.generate_depth_planes(2, kw["min_depth"], kw["max_depth"])
+    assert got.shape == cpu.shape == (2, D, h4, w4) and torch.equal(got.cpu(), cpu)
+    assert ((got - dev).abs() <= 1.2e-7 * dev.abs()).all()
