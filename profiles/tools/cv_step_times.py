@@ -1,3 +1,8 @@
+"""Per-step wall times (synchronised) of the native cost-volume training step, forward and backward separately, with the
+module's one-launch depth planes and with the torch formulation of generate_depth_planes (two depth values -> the fallback path):
+how round 4 found the one-time 60 ms in the SECOND backward (torch loading its `add` kernel for the first .grad accumulation once the
+forward no longer launched torch kernels), which a five-step timed region with one warm-up step reported as a 3x regression.
+   python profiles/tools/cv_step_times.py"""
 import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests", "golden"))
 import torch, inputs
