@@ -27,6 +27,7 @@
 //       form, which scatters with 192-byte atomic records.)
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fs_common.h"
 
@@ -303,17 +304,13 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
     const int d0 = min(D, (blk_.slice * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
 
     // Per plane the sweep would pay three dependent memory round trips before its first MFMA: the plane's depth, the
-    // projection rows (scalar loads), then the taps.  The depth is fetched one plane ahead and the projection rows of the
-    // first two sources stay in SGPRs for the whole sweep (the shipped configs have K <= 2 except the 9-nearest selection
-    // of config 4).
+    // projection rows, then the taps.  The depth is fetched one plane ahead and the projection rows of the first group of
+    // four sources stay in registers for the whole sweep (one source per lane of the quad; the shipped configs have K <= 4).
     const float* pl = planes + b * ps_b + (live ? pix : 0) * ps_p;
     float depth_next = d0 < d1 ? pl[d0 * ps_d] : 0.0f;
-    float P0[12], P1[12];
+    float Pq[12];      // the rows of source min(c, K - 1): what this lane projects for the first group of four sources
 #pragma unroll
-    for (int e = 0; e < 12; ++e) {
-        P0[e] = Pmat[((size_t)b * K) * 12 + e];
-        P1[e] = K > 1 ? Pmat[((size_t)b * K + 1) * 12 + e] : 0.0f;
-    }
+    for (int e = 0; e < 12; ++e) Pq[e] = Pmat[((size_t)b * K + min(c, K - 1)) * 12 + e];
 #ifdef FS_CV_TRACE
     unsigned long long tr_g = 0, tr_m = 0;
     const unsigned long long tr_c0 = cv_stamp(rx), tr_w0 = wall_clock64();
@@ -327,7 +324,9 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
         for (int r = 0; r < NR; ++r) favg[r] = 0.0f;
         float dot_sum = 0.0f, cnt = 0.0f;
         uint32_t flags = 0;   // SAVE: bit 2k = source k valid (dot != 0), bit 2k+1 = in front of it (z > 0)
-        auto one_source = [&](int k, const float* P) __attribute__((always_inline)) {
+        // One source's sampling position: base texel offset, bilinear fractions, tap validity + in-front bits.
+        struct Proj { uint32_t off; float tx, ty; uint32_t bits; };   // bits: xin0 | xin1 << 1 | yin0 << 2 | yin1 << 3 | (z > 0) << 4
+        auto project = [&](const float* P) __attribute__((always_inline)) -> Proj {
             // world point = depth * r (homogeneous 1): geometry_utils.py:56-58
             const float X = depth * rx, Y = depth * ry, Z = depth * rz;
             const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
@@ -344,18 +343,26 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
             const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvx, 1.0f), (float)w), 1.0f), 0.5f);
             const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvy, 1.0f), (float)h), 1.0f), 0.5f);
             const float fx0 = floorf(ix), fy0 = floorf(iy);
-            const float tx = ix - fx0, ty = iy - fy0;
             // NaN/inf coordinates sample nothing (comparisons false)
             const bool xin0 = fx0 >= 0.0f && fx0 <= (float)(w - 1), xin1 = fx0 >= -1.0f && fx0 <= (float)(w - 2);
             const bool yin0 = fy0 >= 0.0f && fy0 <= (float)(h - 1), yin1 = fy0 >= -1.0f && fy0 <= (float)(h - 2);
             const int x0 = xin0 || xin1 ? (int)fx0 : 0, y0 = yin0 || yin1 ? (int)fy0 : 0;
+            Proj pr;
+            pr.off = (uint32_t)((y0 * w + x0) * C) * 4u;      // (byte offset of the texel record; the lane adds its quarter)
+            pr.tx = ix - fx0; pr.ty = iy - fy0;
+            pr.bits = (xin0 ? 1u : 0u) | (xin1 ? 2u : 0u) | (yin0 ? 4u : 0u) | (yin1 ? 8u : 0u) | (zz > 0.0f ? 16u : 0u);
+            return pr;
+        };
+        auto gather = [&](int k, const Proj pr) __attribute__((always_inline)) {
+            const bool xin0 = pr.bits & 1u, xin1 = pr.bits & 2u, yin0 = pr.bits & 4u, yin1 = pr.bits & 8u, front = pr.bits & 16u;
+            const float tx = pr.tx, ty = pr.ty;
             float wv[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) wv[r] = 0.0f;
             // wave-uniform map base (SGPR pair) + a 32-bit per-lane byte offset: one address add per tap instead of
             // 64-bit multiply-adds (a source map is far below 4 GB)
             const char* base = (const char*)(srcN + (((size_t)b * K + k) * hw) * C);
-            const uint32_t off0 = (uint32_t)((y0 * w + x0) * C + 4 * c) * 4u;
+            const uint32_t off0 = pr.off + 16u * (uint32_t)c;
 #pragma unroll
             for (int tap = 0; tap < 4; ++tap) {
                 const int ox = tap & 1, oy = tap >> 1;
@@ -377,12 +384,12 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
             // sum over the pixel's four lanes (one quad)
             part += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(part), 0xB1, 0xF, 0xF, true));   // lane ^ 1
             part += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(part), 0x4E, 0xF, 0xF, true));   // lane ^ 2
-            const float dotk = (zz > 0.0f) ? part : 0.0f;                 // cost_volume.py:571-572,589-593
+            const float dotk = front ? part : 0.0f;                       // cost_volume.py:571-572,589-593
             if (SAVE) {
-                flags |= (zz > 0.0f ? 2u : 0u) << (2 * k);
+                flags |= (front ? 2u : 0u) << (2 * k);
                 // in front, some tap inside the source image, and still an exactly zero score (all-zero features): the
                 // backward must re-gather such a source (cost_volume_bwd_kernel); flagged once per call, practically never
-                if (live && zz > 0.0f && dotk == 0.0f && (xin0 || xin1) && (yin0 || yin1) && c == 0) atomicOr(xhdr, 1u);
+                if (live && front && dotk == 0.0f && (xin0 || xin1) && (yin0 || yin1) && c == 0) atomicOr(xhdr, 1u);
             }
             if (dotk != 0.0f) {                                           // :595 (exact zero test)
                 if (SAVE) flags |= 1u << (2 * k);
@@ -392,9 +399,29 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
                 for (int r = 0; r < NR; ++r) favg[r] += wv[r];
             }
         };
-        one_source(0, P0);
-        if (K > 1) one_source(1, P1);
-        for (int k = 2; k < K; ++k) one_source(k, Pmat + ((size_t)b * K + k) * 12);
+        // The four lanes of a pixel's quad used to compute the SAME projection for every source (~50 of the ~125 VALU
+        // operations a source costs).  Now lane c of the quad projects source k0 + c of a group of four and the four results go
+        // round the quad with DPP broadcasts (4 moves per source): config-3 scale K = 2 2.86 -> 2.60 ms, 5 views K = 4 1.19 -> 1.07,
+        // 10 views K = 8 3.76 -> 3.46 (profiles/r4_cv_quadproj_ab.txt).
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            float Pk[12];      // this lane's source of the group: the first group's rows stay in registers for the whole sweep
+#pragma unroll
+            for (int e = 0; e < 12; ++e) Pk[e] = k0 == 0 ? Pq[e] : Pmat[((size_t)b * K + min(k0 + c, K - 1)) * 12 + e];
+            const Proj mine = project(Pk);
+            auto from = [&](auto sel) __attribute__((always_inline)) {
+                constexpr int q = decltype(sel)::value, ctl = q * 0x55;       // quad_perm: every lane reads lane q of its quad
+                Proj pr;
+                pr.off = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine.off, ctl, 0xF, 0xF, true);
+                pr.tx = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.tx), ctl, 0xF, 0xF, true));
+                pr.ty = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.ty), ctl, 0xF, 0xF, true));
+                pr.bits = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine.bits, ctl, 0xF, 0xF, true);
+                return pr;
+            };
+            gather(k0, from(std::integral_constant<int, 0>{}));
+            if (k0 + 1 < K) gather(k0 + 1, from(std::integral_constant<int, 1>{}));
+            if (k0 + 2 < K) gather(k0 + 2, from(std::integral_constant<int, 2>{}));
+            if (k0 + 3 < K) gather(k0 + 3, from(std::integral_constant<int, 3>{}));
+        }
         const float inv = 1.0f / (cnt + 1e-8f);                          // :595-598
         FS_CV_T(t_gath, favg[0] + favg[NR - 1] + inv + dot_sum);
         if (SAVE && live) {
