@@ -146,8 +146,10 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         target = torch.rand(len(mine), 3, H, W, device=dev)
     gather = AsyncViewGather(n_total_views, device=dev) if (cx.dist_on and not args.no_gather and not train) else None
     exchange = GradExchange(args.grad_exchange) if (cx.dist_on and train) else None
+    diag_events = None      # (set for the few extra untimed steps that time the gradient exchange per rank)
 
     def step():
+        nonlocal diag_events
         if train:
             for t in g.values():
                 t.grad = None
@@ -156,7 +158,13 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
             loss = ((color - target) ** 2).mean()
             loss.backward()
             if exchange is not None:
+                if diag_events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 exchange([t.grad for t in g.values()])
+                if diag_events is not None:
+                    e1.record()
+                    diag_events.append((e0, e1))
             return color, depth
         with torch.no_grad():
             # capacity check deferred to the end of the timed region (check_deferred below): the GPU
@@ -275,6 +283,25 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                          "and that wait alone = the part of the gather the rendering did not hide",
                  "gather_bytes_per_rank_per_step": int(n_total_views * H * W * (4 if args.gather_depth else 3)
                                                        * {"fp32": 4, "fp16": 2, "uint8": 1}[args.gather_dtype])}
+    if exchange is not None:
+        # training mode: the gradient exchange runs on the render stream after the backward -- all of it is exposed
+        diag_events, spans = [], []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            spans.append((e0, e1))
+        torch.cuda.synchronize()
+        mean = lambda evs: sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
+        allv = torch.tensor([mean(spans), mean(diag_events)], device=dev, dtype=torch.float64)
+        diag_events = None
+        got = [torch.zeros_like(allv) for _ in range(world)]
+        dist.all_gather(got, allv)
+        multi = {"per_rank": [{"step_ms": round(float(t[0]), 3), "grad_exchange_ms": round(float(t[1]), 3)} for t in got],
+                 "what": "3 extra untimed training steps, event-timed per rank: one whole step (forward + loss + backward + exchange) "
+                         f"and the {args.grad_exchange} of the Gaussian gradients alone (on the render stream: none of it is hidden)",
+                 "exchange_bytes_per_rank_per_step": int(N * 37 * 4)}
     graph_views_per_s = None
     if world == 1 and not cx.dist_on and not train and not args.no_graph:
         # the same step recorded once into a hipGraph (the C ABI never allocates or syncs: framing + 5 kernels per view

@@ -59,3 +59,6 @@ def test_bench_two_ranks_runs_the_sharded_branch(hip_device, mode):
         per = d["multi_gpu"]["per_rank"]
         assert len(per) == 2 and all(r["step_ms"] > 0 and r["gather_ms"] > 0 and 0 <= r["exposed_gather_ms"] <= r["step_ms"] + r["gather_ms"]
                                      for r in per), per
+    else:   # training: the gradient exchange alone, per rank (it runs on the render stream: all of it is exposed)
+        per = d["multi_gpu"]["per_rank"]
+        assert len(per) == 2 and all(0 < r["grad_exchange_ms"] < r["step_ms"] for r in per), per

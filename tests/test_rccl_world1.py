@@ -62,3 +62,6 @@ def test_bench_single_rank_takes_the_rccl_branch(hip_device, mode, extra):
         assert len(per) == 1 and per[0]["step_ms"] > 0 and per[0]["gather_ms"] > 0 and per[0]["exposed_gather_ms"] >= 0, per
         bytes_per = 3 * 256 * 256 * (4 if extra else 3) * (1 if extra else 4)
         assert d["multi_gpu"]["gather_bytes_per_rank_per_step"] == bytes_per, d["multi_gpu"]
+    else:
+        per = d["multi_gpu"]["per_rank"]
+        assert len(per) == 1 and 0 < per[0]["grad_exchange_ms"] < per[0]["step_ms"], per
