@@ -88,6 +88,7 @@ SIGNATURES = {
     "fs_ptf_fold_step": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 14 + [C.c_float] + [_VP] * 10),
     "fs_ptf_fold_bytes": (C.c_size_t, [C.c_int32] * 3),
     "fs_ptf_fold": (C.c_int, [C.c_int32] * 3 + [_VP] * 8 + [C.c_float] + [_VP] * 2 + [C.POINTER(C.c_void_p)] * 2 + [_VP] * 2),
+    "fs_ptf_cameras": (C.c_int, [C.c_int32] * 3 + [_VP] * 5),
     "fs_ptf_fold_step_lists": (C.c_int, [C.c_int32] * 3 + [_VP, C.POINTER(C.c_void_p)]),
     "fs_ptf_write_state_backward": (C.c_int, [C.c_int32] * 3 + [_VP] * 12 + [C.POINTER(C.c_void_p)] * 2 + [_VP] * 6),
     "fs_ptf_gru_inputs_backward": (C.c_int, [C.c_int32] + [_VP] * 14),

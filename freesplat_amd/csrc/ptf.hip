@@ -627,6 +627,21 @@ namespace {
 size_t fold_camera_bytes(int V, int P) { return align_up((size_t)V * 4 * 4, 256) + align_up((size_t)P * 64, 256); }
 }
 
+// The per-view pixel intrinsics kpix [V,4] = (fx w, fy h, cx w, cy h) and the initial per-Gaussian extrinsics E0 [P,16]
+// (view 0's matrix on every row) in one launch: what fs_ptf_fold prepares internally, for callers that drive
+// fs_ptf_fold_step themselves (the training path).  P = h * w.
+FS_API int fs_ptf_cameras(int32_t V, int32_t h, int32_t w, const float* Es, const float* Kn, float* kpix, float* E0,
+                          void* stream_)
+{
+    if (V < 1 || h <= 0 || w <= 0 || !Es || !Kn || !kpix || !E0) return FS_ERR_INVALID_ARG;
+    const long long P = (long long)h * w;
+    const long long nt = P * 4 > V ? P * 4 : V;
+    hipLaunchKernelGGL(ptf_cameras_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, V, (int)P,
+                       h, w, Es, Kn, kpix, E0);
+    FS_CHECK_LAUNCH("ptf_cameras");
+    return FS_OK;
+}
+
 FS_API size_t fs_ptf_fold_bytes(int32_t V, int32_t h, int32_t w)
 {
     if (V < 2 || h <= 0 || w <= 0) return 0;

@@ -217,26 +217,33 @@ def gru_operand_stream(gru: "GRU") -> Tensor:
     return stream
 
 
-def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tensor, g_fused: Tensor):
+def gru_split_rows(n: int):
+    """(S, n_pad): the split-K factor of the weight-gradient GEMMs over n pairs and n rounded up to a multiple of it."""
+    S = max(1, min(256, n // 256))
+    return S, -(-n // S) * S
+
+
+def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tensor, g_fused: Tensor, n: int = None):
     """Backward of the GRU over n materialised input rows: fs_ptf_gru_backward (forward re-run + the six transposed
     layers on the matrix cores) gives dcat [n,176] and the per-pair factors of the weight gradients; the weight and bias
     gradients themselves -- sums over all pairs of outer products -- are six library GEMMs and six column sums.
+    `cat` has n rows, or gru_split_rows(n)[1] rows with zeros past the n-th (then `n` is given and no padded copy is made).
     Returns (dcat, [12 parameter gradients in the order of _gru_params])."""
     L = _lib.lib()
     p = _lib.ptr
-    n = cat.shape[0]
+    n = cat.shape[0] if n is None else n
     dev = cat.device
     # the contraction of the weight gradients runs over the n pairs and their outputs are tiny (64 x 64 .. 128 x 176): as
     # plain GEMMs they fill two workgroups.  Split K: rows padded with zeros to S equal chunks, one batched GEMM of S
     # partial products per matrix, summed afterwards.
-    S = max(1, min(256, n // 256))
-    n_pad = -(-n // S) * S
+    S, n_pad = gru_split_rows(n)
     cols = L.fs_ptf_gru_side_cols()
     dcat = torch.empty(n, 176, dtype=torch.float32, device=dev)
     side = torch.empty(n_pad, cols, dtype=torch.float32, device=dev)
     if n_pad > n:
         side[n:].zero_()
-        cat = torch.cat([cat, cat.new_zeros(n_pad - n, 176)])
+        if cat.shape[0] < n_pad:                       # callers that know n_pad hand the rows over already padded
+            cat = torch.cat([cat, cat.new_zeros(n_pad - n, 176)])
     g_fused = g_fused.contiguous()
     _lib.check(L.fs_ptf_gru_backward(n, p(cat), p(tables), p(operand_stream), p(g_fused), p(dcat), p(side),
                                      _lib.current_stream()), "fs_ptf_gru_backward")
@@ -358,8 +365,9 @@ class _PtfFold(torch.autograd.Function):
         V, P = lat.shape[0], lat.shape[1]
         dev = lat.device
         w2c = world_to_camera(Es)
-        kpix = (Kn.view(V, 3, 3)[:, [0, 1, 0, 1], [0, 1, 2, 2]] * torch.tensor([w, h, w, h], dtype=torch.float32, device=dev)).contiguous()
-        E0 = Es[0].reshape(1, 16).repeat(P, 1)
+        kpix = torch.empty(V, 4, dtype=torch.float32, device=dev)
+        E0 = torch.empty(P, 16, dtype=torch.float32, device=dev)
+        _lib.check(L.fs_ptf_cameras(V, h, w, p(Es), p(Kn), p(kpix), p(E0), _lib.current_stream()), "fs_ptf_cameras")
         counts = torch.empty(V, 4, dtype=torch.int32, device=dev)
         state = (lat[0], xs[0], rho[0], om[0], E0, dep[0])         # G, X, R, O, E, D of the state after view 0
         states, scratches = [state], [None]
@@ -385,13 +393,17 @@ class _PtfFold(torch.autograd.Function):
         # The steps were queued into WORST-CASE buffers ((i + 1) P rows of 86 floats each: O(V^2 P) in total, 2.4 GB at
         # V = 8 and 384x512) because their sizes were still on the device.  Now that the counts are known, keep only the
         # rows that exist (one copy of sum_i n_i rows, ~0.3 ms at 10 views): what the backward holds on to is O(V n).
-        for i in range(1, V):
+        # The LAST state is only returned (the backward reads states 0 .. V-2): its G, X, E, D stay views of the worst-case
+        # buffer unless that would pin more than 256 MB of rows that do not exist.
+        for i in range(1, V - 1):
             states[i] = tuple(t[: cnt[i][3]].clone() for t in states[i])
-        state = states[V - 1]
+        G, X, R, O, E, D = states[V - 1]
+        if (V * P - n) * 84 * 4 > (256 << 20):
+            G, X, E, D = (t[:n].clone() for t in (G, X, E, D))
+        states[V - 1] = None
         ctx.cnt, ctx.hw, ctx.states, ctx.scratches = cnt, (h, w), states, scratches
         ctx.tables, ctx.operand_stream = tables, operand_stream
         ctx.save_for_backward(lat, xs, rho, om, dep, Es, *params)
-        G, X, R, O, E, D = state
         return G[:n], X[:n], E[:n], D[:n, 0]
 
     @staticmethod
@@ -405,7 +417,11 @@ class _PtfFold(torch.autograd.Function):
         cnt = ctx.cnt
         n = cnt[V - 1][3]
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-        g_lat, g_xs, g_rho, g_om, g_dep = z(V, P, 64), z(V, P, 3), z(V, P), z(V, P), z(V, P)
+        # the five view gradients are accumulated into: one zero fill for all of them
+        seg = [-(-V * P * k // 64) * 64 for k in (64, 3, 1, 1, 1)]          # 256-byte aligned segments
+        flat = z(sum(seg)).split(seg)
+        g_lat, g_xs = flat[0][: V * P * 64].view(V, P, 64), flat[1][: V * P * 3].view(V, P, 3)
+        g_rho, g_om, g_dep = (t[: V * P].view(V, P) for t in flat[2:])
         g_params = [None] * len(params)
         # gradient of the current out state: G, X, R, O, E, D (None = zero)
         c = lambda t: None if t is None else t.contiguous()
@@ -418,35 +434,33 @@ class _PtfFold(torch.autograd.Function):
             lists = (C.c_void_p * 4)()
             _lib.check(L.fs_ptf_fold_step_lists(i * P, h, w, p(ctx.scratches[i]), lists), "fs_ptf_fold_step_lists")
             keep, fuse, fpix, app = (C.c_void_p(v) for v in lists)
-            g_in = [torch.empty(M_in, k, dtype=torch.float32, device=dev) for k in (64, 3, 1, 1, 16, 1)]
+            if i == 1:
+                # the state before view 1 IS view 0 (every row of it kept or fused): its gradient is written straight
+                # into view 0's slices (the extrinsics' gradient goes nowhere)
+                g_in = [g_lat[0], g_xs[0], g_rho[0].view(P, 1), g_om[0].view(P, 1),
+                        torch.empty(M_in, 16, dtype=torch.float32, device=dev), g_dep[0].view(P, 1)]
+            else:
+                g_in = [torch.empty(M_in, k, dtype=torch.float32, device=dev) for k in (64, 3, 1, 1, 16, 1)]
             _lib.check(L.fs_ptf_write_state_backward(
                 nk, nf, na, keep, fuse, fpix, app, p(X), p(R), p(E), p(D), p(xs[i]), p(rho[i]), p(dep[i]), p(Es[i]),
                 vp(g_out), vp(g_in), p(g_lat[i]), p(g_xs[i]), p(g_rho[i]), p(g_om[i]), p(g_dep[i]),
                 _lib.current_stream()), "fs_ptf_write_state_backward")
             if nf > 0:
                 # the GRU rows: re-gather their inputs (HIP), GRU backward on the matrix cores (+ the weight-gradient GEMMs)
-                cat = torch.empty(nf, 176, dtype=torch.float32, device=dev)
+                nf_pad = gru_split_rows(nf)[1]
+                cat = torch.empty(nf_pad, 176, dtype=torch.float32, device=dev)
+                if nf_pad > nf:
+                    cat[nf:].zero_()
                 _lib.check(L.fs_ptf_gru_inputs(nf, fuse, fpix, p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]), p(cat),
                                                _lib.current_stream()), "fs_ptf_gru_inputs")
                 g_fused = g_out[0][nk: nk + nf] if g_out[0] is not None else z(nf, 64)
-                dcat, grads = gru_backward(params, ctx.tables, ctx.operand_stream, cat, g_fused)
+                dcat, grads = gru_backward(params, ctx.tables, ctx.operand_stream, cat, g_fused, n=nf)
                 for k, gq in enumerate(grads):
                     g_params[k] = gq if g_params[k] is None else g_params[k] + gq
                 _lib.check(L.fs_ptf_gru_inputs_backward(nf, fuse, fpix, p(R), p(O), p(rho[i]), p(om[i]), p(dcat),
                                                         p(g_in[0]), p(g_in[2]), p(g_in[3]), p(g_lat[i]), p(g_rho[i]),
                                                         p(g_om[i]), _lib.current_stream()), "fs_ptf_gru_inputs_backward")
             g_out = g_in
-        # what is left is the gradient of the state after view 0 = view 0's own arrays (its extrinsics are constants)
-        if g_out[0] is not None:
-            g_lat[0] += g_out[0]
-        if g_out[1] is not None:
-            g_xs[0] += g_out[1]
-        if g_out[2] is not None:
-            g_rho[0] += g_out[2].view(-1)
-        if g_out[3] is not None:
-            g_om[0] += g_out[3].view(-1)
-        if g_out[5] is not None:
-            g_dep[0] += g_out[5].view(-1)
         need = ctx.needs_input_grad
         pick = lambda k, t: t if need[k] else None
         return (pick(0, g_lat), pick(1, g_xs), pick(2, g_rho), pick(3, g_om), pick(4, g_dep), None, None, None, None,

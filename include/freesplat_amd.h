@@ -445,6 +445,10 @@ int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float*
  * The gradient of the GRU output rows is g_out[0] + n_keep*64 (n_fuse contiguous rows).
  * fs_ptf_gru_inputs_backward: dcat [n_fuse,176] -> g_G rows fuse_idx (stored), g_R / g_O (added), view gradients
  * (accumulated) through the gather and the positional encodings (:62-77, 485-486). */
+/* fs_ptf_cameras: kpix [V,4] = (fx w, fy h, cx w, cy h) from the normalised intrinsics Kn [V,9] and E0 [h*w,16] = view 0's
+ * camera-to-world matrix on every row (the initial per-Gaussian extrinsics, encoder_freesplat.py:441), one launch: what
+ * fs_ptf_fold prepares internally, for a caller that drives fs_ptf_fold_step itself (the training path). */
+int fs_ptf_cameras(int32_t V, int32_t h, int32_t w, const float* Es, const float* Kn, float* kpix, float* E0, void* stream);
 int fs_ptf_fold_step_lists(int32_t M_max, int32_t h, int32_t w, void* scratch, int64_t** lists);
 int fs_ptf_write_state_backward(int32_t n_keep, int32_t n_fuse, int32_t n_app, const int64_t* keep_idx,
                                 const int64_t* fuse_idx, const int64_t* fuse_pix, const int64_t* append_pix,
