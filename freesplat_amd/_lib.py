@@ -80,6 +80,9 @@ SIGNATURES = {
     "fs_ptf_gru_stream_rows": (C.c_int32, []),
     "fs_ptf_gru_side_cols": (C.c_int32, []),
     "fs_ptf_gru_backward": (C.c_int, [C.c_int32] + [_VP] * 7),
+    "fs_ptf_gru_grad_floats": (C.c_int32, []),
+    "fs_ptf_gru_weight_grads_bytes": (C.c_size_t, [C.c_int32]),
+    "fs_ptf_gru_weight_grads": (C.c_int, [C.c_int32] + [_VP] * 5),
     "fs_raster_forward_views": (C.c_int, [C.POINTER(RasterDims), C.c_int32] + [_VP] * 15 + [C.POINTER(C.c_size_t), C.c_int64]
                                 + [_VP] * 5 + [C.c_int32, C.POINTER(C.c_void_p), _VP]),
     "fs_raster_backward_views": (C.c_int, [C.POINTER(RasterDims), C.c_int32] + [_VP] * 14 + [C.POINTER(C.c_size_t)] + [_VP] * 9

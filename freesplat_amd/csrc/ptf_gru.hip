@@ -18,6 +18,8 @@
 //     256-byte load per MFMA, L2-resident: 178 KB for all six matrices).
 // 696 MFMAs (exact fp32) per 32 pairs.
 #include "fs_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace fs {
 
@@ -521,6 +523,261 @@ int launch_ptf_gru_bwd(int n, const float* cat, const float* tables, const float
     return FS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradients of the GRU: dW = dY^T X, a contraction over ALL n pairs of the rows the backward kernel left in
+// `side` and of the input rows `cat`.  Both are row-major, so with v_mfma_f32_32x32x2_f32 taking k = 2 ROWS per step the
+// A operand is "lane i reads its columns of the dY block" and the B operand "lane j reads its columns of the X block":
+// coalesced loads straight from L2 / HBM, no LDS, no transposition.  One wavefront owns one quarter of the 46 output tiles
+//   wave 0: dr1 (2 tiles of 32 units) x cat (6 tiles of 32 features, the last one 16 wide)   -> W_r1 [64,176]
+//   wave 1: dz1 x cat                                                                       -> W_z1 [64,176]
+//   wave 2: dn1 x [r*hid (2) | cat[88:176] (3, the last 24 wide)]                             -> W_n1 [64,152]
+//   wave 3: dR x relu(r1), dZ x relu(z1), dN x relu(n1) (2 x 2 tiles each)                    -> W_r2, W_z2, W_n2
+// (192 accumulator registers) and the four wavefronts of a workgroup walk the SAME block of rows, so the rows of `cat`
+// are fetched from L2 once per workgroup and found in the L1 by the other two.  The bias gradients -- column sums of the
+// six dY blocks -- ride along: every A operand is added to a per-lane sum.  Each workgroup (one per CU) writes its partial
+// matrices to the workspace and a second kernel adds them up, in a fixed order, into `grads`: 44 928 floats (parameter
+// order, below), which the caller zeroes once per backward -- the fold steps of a scene accumulate in place.
+// 445 MB of operands per 10^5 pairs: HBM-bound (~95 us + ~20 us for the partial sums).
+// Replaces five split-K batched GEMMs + five chunk sums + a column sum + a concatenation of the host glue
+// (13 launches, ~0.33 ms per 10^5 pairs) by two launches.
+constexpr int kGr1W = 0, kGr1b = kGr1W + 64 * 176, kGr2W = kGr1b + 64, kGr2b = kGr2W + 64 * 64, kGz1W = kGr2b + 64,
+              kGz1b = kGz1W + 64 * 176, kGz2W = kGz1b + 64, kGz2b = kGz2W + 64 * 64, kGn1W = kGz2b + 64,
+              kGn1b = kGn1W + 64 * 152, kGn2W = kGn1b + 64, kGn2b = kGn2W + 64 * 64, kGradFloats = kGn2b + 64;
+static_assert(kGradFloats == 44928, "parameter gradient layout");
+constexpr int kDwU = 4;          // k-steps (2 rows each) per load group; three groups rotate
+constexpr int kDwTiles = 46, kDwRaw = kDwTiles * 1024 + 12 * 32;   // floats of one workgroup's partial sums
+
+// What one wavefront multiplies, as compile-time tables.  A load segment: lane j (= lane & 31) of row-half kk loads
+// `width` consecutive floats at column col + width * j of its row (j < lim) -- so the 64 columns of a dY block arrive
+// as ONE dwordx2 per lane and 128 columns of `cat` as one dwordx4, and MFMA tile e of a segment holds the columns
+// col + width * j + e: the tiles interleave instead of tiling, which only the flush has to know.  (With one dword per
+// tile and lane -- 8 load instructions per k-step -- the 6-bit vmcnt caps a wavefront at 63 loads = 16 KB in flight:
+// too little for one wavefront per SIMD to cover HBM latency.)
+struct DwSeg { int base, col, width, lim, v0; };          // base 0 = side, 1 = cat; v0 = first register of the k-step's set
+struct DwB { int v, col, mul, lim; };                     // B tile: register, output columns col + mul * j for j < lim
+struct DwProd { int a0, nb, t0, w, ldw, bias; DwB b[6]; };   // A tiles = registers a0, a0 + 1 (units 2 i + e); t0 = first accumulator
+
+struct DwJobR1 {   // dr1 x cat -> W_r1 [64,176]
+    static constexpr int NSEG = 3, NV = 8, NP = 1, NT = 12, T0 = 0, B0 = 0;
+    static constexpr DwSeg seg[3] = {{0, 0, 2, 32, 0}, {1, 0, 4, 32, 2}, {1, 128, 2, 24, 6}};
+    static constexpr DwProd prod[1] = {{0, 6, 0, kGr1W, 176, kGr1b,
+                                        {{2, 0, 4, 32}, {3, 1, 4, 32}, {4, 2, 4, 32}, {5, 3, 4, 32}, {6, 128, 2, 24}, {7, 129, 2, 24}}}};
+};
+struct DwJobZ1 {   // dz1 x cat -> W_z1
+    static constexpr int NSEG = 3, NV = 8, NP = 1, NT = 12, T0 = 12, B0 = 2;
+    static constexpr DwSeg seg[3] = {{0, 64, 2, 32, 0}, {1, 0, 4, 32, 2}, {1, 128, 2, 24, 6}};
+    static constexpr DwProd prod[1] = {{0, 6, 0, kGz1W, 176, kGz1b,
+                                        {{2, 0, 4, 32}, {3, 1, 4, 32}, {4, 2, 4, 32}, {5, 3, 4, 32}, {6, 128, 2, 24}, {7, 129, 2, 24}}}};
+};
+struct DwJobN1 {   // dn1 x [r*hid | x | xe] -> W_n1 [64,152]
+    static constexpr int NSEG = 4, NV = 7, NP = 1, NT = 10, T0 = 24, B0 = 4;
+    static constexpr DwSeg seg[4] = {{0, 256, 2, 32, 0}, {0, 576, 2, 32, 2}, {1, 88, 2, 32, 4}, {1, 152, 1, 24, 6}};
+    static constexpr DwProd prod[1] = {{0, 5, 0, kGn1W, 152, kGn1b,
+                                        {{2, 0, 2, 32}, {3, 1, 2, 32}, {4, 64, 2, 32}, {5, 65, 2, 32}, {6, 128, 1, 24}, {0, 0, 0, 0}}}};
+};
+struct DwJob2 {    // the three second layers: dR x relu(r1), dZ x relu(z1), dN x relu(n1) -> W_r2, W_z2, W_n2 [64,64]
+    static constexpr int NSEG = 6, NV = 12, NP = 3, NT = 12, T0 = 34, B0 = 6;
+    static constexpr DwSeg seg[6] = {{0, 128, 2, 32, 0}, {0, 384, 2, 32, 2}, {0, 192, 2, 32, 4}, {0, 448, 2, 32, 6},
+                                     {0, 320, 2, 32, 8}, {0, 512, 2, 32, 10}};
+    static constexpr DwProd prod[3] = {{0, 2, 0, kGr2W, 64, kGr2b, {{2, 0, 2, 32}, {3, 1, 2, 32}}},
+                                       {4, 2, 4, kGz2W, 64, kGz2b, {{6, 0, 2, 32}, {7, 1, 2, 32}}},
+                                       {8, 2, 8, kGn2W, 64, kGn2b, {{10, 0, 2, 32}, {11, 1, 2, 32}}}};
+};
+
+template <class J>
+__device__ __forceinline__ void dw_wave(int r0, int r1, int lane, const float* __restrict__ side,
+                                        const float* __restrict__ cat, float* __restrict__ partial)
+{
+    const int j = lane & 31, kk = lane >> 5;
+    const float* ptr[J::NSEG];
+#pragma unroll
+    for (int s = 0; s < J::NSEG; ++s)
+        ptr[s] = (J::seg[s].base ? cat : side) + J::seg[s].col + (j < J::seg[s].lim ? J::seg[s].width * j : 0);
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[J::NT];
+#pragma unroll
+    for (int t = 0; t < J::NT; ++t) acc[t] = zero16;
+    float bs[J::NP][2];
+#pragma unroll
+    for (int p = 0; p < J::NP; ++p) { bs[p][0] = 0.0f; bs[p][1] = 0.0f; }
+
+    // three load groups rotate: while one is multiplied, two are in flight (one wavefront per SIMD -- 192 accumulator
+    // registers -- has nothing else to hide the HBM latency with)
+    float V0[kDwU][J::NV], V1[kDwU][J::NV], V2[kDwU][J::NV];
+    // Loads are never masked (a select right behind a load makes the scheduler wait for it there and the prefetch is
+    // gone): rows past r1 read row r1 - 1 again and their A operand is zeroed at the MULTIPLY (0 x finite = 0); lanes
+    // whose column does not exist read lane 0's and fill accumulator columns the flush never looks at.
+    auto load = [&](int r, float (&V)[kDwU][J::NV]) {
+#pragma unroll
+        for (int u = 0; u < kDwU; ++u) {
+            const size_t rr = (size_t)min(r + 2 * u + kk, r1 - 1);
+#pragma unroll
+            for (int s = 0; s < J::NSEG; ++s) {
+                const float* q = ptr[s] + rr * (J::seg[s].base ? 176 : kSide);
+                if (J::seg[s].width == 4) {
+                    const float4 x = *(const float4*)q;
+                    V[u][J::seg[s].v0] = x.x; V[u][J::seg[s].v0 + 1] = x.y;
+                    V[u][J::seg[s].v0 + 2] = x.z; V[u][J::seg[s].v0 + 3] = x.w;
+                } else if (J::seg[s].width == 2) {
+                    const float2 x = *(const float2*)q;
+                    V[u][J::seg[s].v0] = x.x; V[u][J::seg[s].v0 + 1] = x.y;
+                } else {
+                    V[u][J::seg[s].v0] = *q;
+                }
+            }
+        }
+    };
+    auto mma = [&](int r, const float (&V)[kDwU][J::NV]) {
+#pragma unroll
+        for (int u = 0; u < kDwU; ++u) {
+            const bool ok = r + 2 * u + kk < r1;
+#pragma unroll
+            for (int p = 0; p < J::NP; ++p)
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia) {
+                    const float a = ok ? V[u][J::prod[p].a0 + ia] : 0.0f;
+                    bs[p][ia] += a;
+#pragma unroll
+                    for (int t = 0; t < J::prod[p].nb; ++t)
+                        acc[J::prod[p].t0 + ia * J::prod[p].nb + t] =
+                            FS_MFMA(a, V[u][J::prod[p].b[t].v], acc[J::prod[p].t0 + ia * J::prod[p].nb + t]);
+                }
+        }
+    };
+    constexpr int g = 2 * kDwU;      // rows per group
+    load(r0, V0);
+    load(r0 + g, V1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int r = r0; r < r1; r += 3 * g) {
+        // (no branches in here; the launch makes a workgroup's block a multiple of 3 g rows, so only the last
+        // workgroup multiplies zero rows)
+        // (the scheduling barriers keep the compiler from sinking each group's loads down to their first use -- it
+        // minimises register pressure that way, and waits for every load right after issuing it)
+        load(r + 2 * g, V2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(r, V0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(r + 3 * g, V0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(r + g, V1);
+        __builtin_amdgcn_sched_barrier(0);
+        load(r + 4 * g, V1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(r + 2 * g, V2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // The workgroup's partial sums go out as they sit in the registers (256-byte stores): [tile][q][lane], then the bias
+    // sums [block][32].  ptf_gru_dw_reduce_kernel adds the workgroups' partials up, in a fixed order.
+    // (Float atomics straight into `grads` from here -- 11.6 M of them from 253 workgroups -- took 146 us of this
+    // kernel's 240; profiles/r4_ptf_dw_trace.txt.)
+    float* P = partial + (size_t)blockIdx.x * kDwRaw;
+#pragma unroll
+    for (int t = 0; t < J::NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) P[((J::T0 + t) * 16 + q) * 64 + lane] = acc[t][q];
+#pragma unroll
+    for (int p = 0; p < J::NP; ++p)
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia) {
+            const float sum = bs[p][ia] + __shfl_xor(bs[p][ia], 32);
+            if (kk == 0) P[kDwTiles * 1024 + (J::B0 + 2 * p + ia) * 32 + j] = sum;
+        }
+}
+
+// raw position (local tile of job J, accumulator q, lane) -> index into `grads`, or -1: accumulator q of lane (j, hf) is
+// D[i = 8 (q / 4) + 4 hf + q % 4][j]; unit = 2 i + ia, column by the tile's map
+template <class J>
+__device__ __forceinline__ int dw_out_index(int local, int q, int lane)
+{
+    const int j = lane & 31, hf = lane >> 5;
+    const int unit2 = 2 * (8 * (q >> 2) + 4 * hf + (q & 3));
+    int out = -1;
+#pragma unroll
+    for (int p = 0; p < J::NP; ++p)
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+            for (int t = 0; t < J::prod[p].nb; ++t)
+                if (local == J::prod[p].t0 + ia * J::prod[p].nb + t && j < J::prod[p].b[t].lim)
+                    out = J::prod[p].w + (unit2 + ia) * J::prod[p].ldw + J::prod[p].b[t].col + J::prod[p].b[t].mul * j;
+    return out;
+}
+template <class J>
+__device__ __forceinline__ int dw_bias_index(int local, int j)      // local = 2 p + ia
+{
+    int out = -1;
+#pragma unroll
+    for (int p = 0; p < J::NP; ++p)
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+            if (local == 2 * p + ia) out = J::prod[p].bias + 2 * j + ia;
+    return out;
+}
+
+// grads += the sum of the `wgs` partial sets.  A workgroup = 64 raw positions x 4 slices of the workgroup list.
+__global__ __launch_bounds__(256) void ptf_gru_dw_reduce_kernel(int wgs, const float* __restrict__ partial,
+                                                                float* __restrict__ grads)
+{
+    __shared__ float s_sum[4][64];
+    const int xl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + xl;                 // < kDwRaw (a multiple of 64)
+    float sum = 0.0f;
+#pragma unroll 8
+    for (int g = sl; g < wgs; g += 4) sum += partial[(size_t)g * kDwRaw + x];
+    s_sum[sl][xl] = sum;
+    __syncthreads();
+    if (sl != 0) return;
+    sum = (s_sum[0][xl] + s_sum[1][xl]) + (s_sum[2][xl] + s_sum[3][xl]);
+    int out;
+    if (x < kDwTiles * 1024) {
+        const int tile = x >> 10, q = (x >> 6) & 15, lane = x & 63;
+        out = tile < DwJobZ1::T0 ? dw_out_index<DwJobR1>(tile, q, lane)
+            : tile < DwJobN1::T0 ? dw_out_index<DwJobZ1>(tile - DwJobZ1::T0, q, lane)
+            : tile < DwJob2::T0 ? dw_out_index<DwJobN1>(tile - DwJobN1::T0, q, lane)
+                                : dw_out_index<DwJob2>(tile - DwJob2::T0, q, lane);
+    } else {
+        const int y = x - kDwTiles * 1024, b = y >> 5, j = y & 31;
+        out = b < DwJobZ1::B0 ? dw_bias_index<DwJobR1>(b, j)
+            : b < DwJobN1::B0 ? dw_bias_index<DwJobZ1>(b - DwJobZ1::B0, j)
+            : b < DwJob2::B0 ? dw_bias_index<DwJobN1>(b - DwJobN1::B0, j)
+                             : dw_bias_index<DwJob2>(b - DwJob2::B0, j);
+    }
+    if (out >= 0) grads[out] += sum;
+}
+
+__global__ __launch_bounds__(256) void ptf_gru_dw_kernel(int n, int rows_per_wg, const float* __restrict__ cat,
+                                                         const float* __restrict__ side, float* __restrict__ partial)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per_wg;
+    const int r1 = min(n, r0 + rows_per_wg);              // (r0 < n: the grid is ceil(n / rows_per_wg))
+    if (wave == 0) dw_wave<DwJobR1>(r0, r1, lane, side, cat, partial);
+    else if (wave == 1) dw_wave<DwJobZ1>(r0, r1, lane, side, cat, partial);
+    else if (wave == 2) dw_wave<DwJobN1>(r0, r1, lane, side, cat, partial);
+    else dw_wave<DwJob2>(r0, r1, lane, side, cat, partial);
+}
+
+void dw_grid(int n, int& wgs, int& rows)
+{
+    const int want = std::min(256, (n + 63) / 64);       // one wavefront per SIMD (~390 registers): one round of workgroups
+    rows = ((n + want - 1) / want + 6 * kDwU - 1) / (6 * kDwU) * (6 * kDwU);   // whole turns of the three load groups
+    wgs = (n + rows - 1) / rows;
+}
+
+int launch_ptf_gru_dw(int n, const float* cat, const float* side, float* grads, float* partial, hipStream_t st)
+{
+    if (n <= 0) return FS_OK;
+    int wgs, rows;
+    dw_grid(n, wgs, rows);
+    hipLaunchKernelGGL(ptf_gru_dw_kernel, dim3(wgs), dim3(256), 0, st, n, rows, cat, side, partial);
+    FS_CHECK_LAUNCH("ptf_gru_weight_grads");
+    static_assert(kDwRaw % 64 == 0, "reduce grid");
+    hipLaunchKernelGGL(ptf_gru_dw_reduce_kernel, dim3(kDwRaw / 64), dim3(256), 0, st, wgs, partial, grads);
+    FS_CHECK_LAUNCH("ptf_gru_weight_grads_reduce");
+    return FS_OK;
+}
+
 }  // namespace fs
 
 using namespace fs;
@@ -551,4 +808,30 @@ FS_API int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables,
     hipStream_t st = (hipStream_t)stream_;
     ScopedStage prof_(kStPtf, st);
     return launch_ptf_gru_bwd(n, cat, tables, operand_stream, g_fused, dcat, side, st);
+}
+
+FS_API int32_t fs_ptf_gru_grad_floats(void) { return kGradFloats; }
+
+// grads [fs_ptf_gru_grad_floats()] += the gradients of the 12 GRU parameters over the n pairs whose rows
+// fs_ptf_gru_backward left in `side` (and whose inputs are `cat`), concatenated in the order
+// mlp_r[0].weight [64,176], .bias, mlp_r[2].weight [64,64], .bias, mlp_z[0] .., mlp_z[2] .., mlp_n[0].weight [64,152],
+// .bias, mlp_n[2].weight, .bias.  ADDED to `grads` (zero it before the first fold step of a backward); the summation
+// order is fixed, so equal inputs give equal bits.  workspace: fs_ptf_gru_weight_grads_bytes(n).
+FS_API size_t fs_ptf_gru_weight_grads_bytes(int32_t n)
+{
+    if (n <= 0) return 0;
+    int wgs, rows;
+    dw_grid(n, wgs, rows);
+    return (size_t)wgs * kDwRaw * sizeof(float);
+}
+
+FS_API int fs_ptf_gru_weight_grads(int32_t n, const float* cat, const float* side, float* grads, void* workspace,
+                                   void* stream_)
+{
+    if (n < 0) return FS_ERR_INVALID_ARG;
+    if (n == 0) return FS_OK;
+    if (!cat || !side || !grads || !workspace) return FS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    ScopedStage prof_(kStPtf, st);
+    return launch_ptf_gru_dw(n, cat, side, grads, (float*)workspace, st);
 }

@@ -22,6 +22,7 @@ The fold is HIP in both modes (b = 1, the only shape the reference's indexing su
 from __future__ import annotations
 
 import ctypes as C
+import math
 import weakref
 
 import torch
@@ -217,47 +218,41 @@ def gru_operand_stream(gru: "GRU") -> Tensor:
     return stream
 
 
-def gru_split_rows(n: int):
-    """(S, n_pad): the split-K factor of the weight-gradient GEMMs over n pairs and n rounded up to a multiple of it."""
-    S = max(1, min(256, n // 256))
-    return S, -(-n // S) * S
+GRU_PARAM_SHAPES = [(64, 176), (64,), (64, 64), (64,), (64, 176), (64,), (64, 64), (64,), (64, 152), (64,), (64, 64), (64,)]
 
 
-def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tensor, g_fused: Tensor, n: int = None):
+def gru_grad_views(flat: Tensor) -> list:
+    """The 12 parameter gradients (order of _gru_params) as views of the flat buffer fs_ptf_gru_weight_grads adds to."""
+    out, o = [], 0
+    for shp in GRU_PARAM_SHAPES:
+        k = math.prod(shp)
+        out.append(flat[o: o + k].view(shp))
+        o += k
+    assert o == flat.numel()
+    return out
+
+
+def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tensor, g_fused: Tensor, grads: Tensor = None):
     """Backward of the GRU over n materialised input rows: fs_ptf_gru_backward (forward re-run + the six transposed
-    layers on the matrix cores) gives dcat [n,176] and the per-pair factors of the weight gradients; the weight and bias
-    gradients themselves -- sums over all pairs of outer products -- are six library GEMMs and six column sums.
-    `cat` has n rows, or gru_split_rows(n)[1] rows with zeros past the n-th (then `n` is given and no padded copy is made).
-    Returns (dcat, [12 parameter gradients in the order of _gru_params])."""
+    layers on the matrix cores) gives dcat [n,176] and the per-pair factors of the weight gradients (`side`);
+    fs_ptf_gru_weight_grads contracts those over the n pairs -- dW = dY^T X and the bias sums, two launches -- ADDING to
+    the flat buffer `grads` (fs_ptf_gru_grad_floats() floats; a zeroed one is made if not given).
+    Returns (dcat, [12 parameter gradients in the order of _gru_params], views of `grads`)."""
     L = _lib.lib()
     p = _lib.ptr
-    n = cat.shape[0] if n is None else n
+    n = cat.shape[0]
     dev = cat.device
-    # the contraction of the weight gradients runs over the n pairs and their outputs are tiny (64 x 64 .. 128 x 176): as
-    # plain GEMMs they fill two workgroups.  Split K: rows padded with zeros to S equal chunks, one batched GEMM of S
-    # partial products per matrix, summed afterwards.
-    S, n_pad = gru_split_rows(n)
-    cols = L.fs_ptf_gru_side_cols()
+    if grads is None:
+        grads = torch.zeros(L.fs_ptf_gru_grad_floats(), dtype=torch.float32, device=dev)
     dcat = torch.empty(n, 176, dtype=torch.float32, device=dev)
-    side = torch.empty(n_pad, cols, dtype=torch.float32, device=dev)
-    if n_pad > n:
-        side[n:].zero_()
-        if cat.shape[0] < n_pad:                       # callers that know n_pad hand the rows over already padded
-            cat = torch.cat([cat, cat.new_zeros(n_pad - n, 176)])
+    side = torch.empty(n, L.fs_ptf_gru_side_cols(), dtype=torch.float32, device=dev)
     g_fused = g_fused.contiguous()
-    _lib.check(L.fs_ptf_gru_backward(n, p(cat), p(tables), p(operand_stream), p(g_fused), p(dcat), p(side),
-                                     _lib.current_stream()), "fs_ptf_gru_backward")
-    sv, cv = side.view(S, n_pad // S, cols), cat.view(S, n_pad // S, 176)
-    blk = lambda k, m=1: sv[:, :, 64 * k: 64 * (k + m)]
-    tmm = lambda a, b: torch.bmm(a.transpose(1, 2), b).sum(dim=0)      # sum over chunks of a_chunk^T b_chunk
-    dr1, dz1, dR, dZ, dn1, dN, r1a, z1a, n1a, rh = (blk(k) for k in range(10))
-    g1 = tmm(blk(0, 2), cv)                            # [dr1 | dz1]^T cat: first layers of r and z in one product
-    gn1 = torch.cat([tmm(dn1, rh), tmm(dn1, cv[:, :, 88:])], dim=1)
-    bsum = side[:, :384].sum(dim=0)                    # the six bias gradients
-    grads = [g1[:64], bsum[0:64], tmm(dR, r1a), bsum[128:192],
-             g1[64:], bsum[64:128], tmm(dZ, z1a), bsum[192:256],
-             gn1, bsum[256:320], tmm(dN, n1a), bsum[320:384]]
-    return dcat, grads
+    st = _lib.current_stream()
+    _lib.check(L.fs_ptf_gru_backward(n, p(cat), p(tables), p(operand_stream), p(g_fused), p(dcat), p(side), st),
+               "fs_ptf_gru_backward")
+    ws = torch.empty(L.fs_ptf_gru_weight_grads_bytes(n), dtype=torch.uint8, device=dev)
+    _lib.check(L.fs_ptf_gru_weight_grads(n, p(cat), p(side), p(grads), p(ws), st), "fs_ptf_gru_weight_grads")
+    return dcat, gru_grad_views(grads)
 
 
 _fold_scratch: dict = {}       # (device, stream, V, h, w) -> the inference fold's internal scratch (reuse is ordered by the
@@ -422,7 +417,7 @@ class _PtfFold(torch.autograd.Function):
         flat = z(sum(seg)).split(seg)
         g_lat, g_xs = flat[0][: V * P * 64].view(V, P, 64), flat[1][: V * P * 3].view(V, P, 3)
         g_rho, g_om, g_dep = (t[: V * P].view(V, P) for t in flat[2:])
-        g_params = [None] * len(params)
+        g_params, g_flat = [None] * len(params), None       # the fold steps' weight gradients accumulate in g_flat
         # gradient of the current out state: G, X, R, O, E, D (None = zero)
         c = lambda t: None if t is None else t.contiguous()
         g_out = [c(gG), c(gX), None, None, c(gE), None if gD is None else gD.contiguous().view(n, 1)]
@@ -447,16 +442,13 @@ class _PtfFold(torch.autograd.Function):
                 _lib.current_stream()), "fs_ptf_write_state_backward")
             if nf > 0:
                 # the GRU rows: re-gather their inputs (HIP), GRU backward on the matrix cores (+ the weight-gradient GEMMs)
-                nf_pad = gru_split_rows(nf)[1]
-                cat = torch.empty(nf_pad, 176, dtype=torch.float32, device=dev)
-                if nf_pad > nf:
-                    cat[nf:].zero_()
+                cat = torch.empty(nf, 176, dtype=torch.float32, device=dev)
                 _lib.check(L.fs_ptf_gru_inputs(nf, fuse, fpix, p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]), p(cat),
                                                _lib.current_stream()), "fs_ptf_gru_inputs")
                 g_fused = g_out[0][nk: nk + nf] if g_out[0] is not None else z(nf, 64)
-                dcat, grads = gru_backward(params, ctx.tables, ctx.operand_stream, cat, g_fused, n=nf)
-                for k, gq in enumerate(grads):
-                    g_params[k] = gq if g_params[k] is None else g_params[k] + gq
+                if g_flat is None:
+                    g_flat = z(L.fs_ptf_gru_grad_floats())
+                dcat, g_params = gru_backward(params, ctx.tables, ctx.operand_stream, cat, g_fused, g_flat)
                 _lib.check(L.fs_ptf_gru_inputs_backward(nf, fuse, fpix, p(R), p(O), p(rho[i]), p(om[i]), p(dcat),
                                                         p(g_in[0]), p(g_in[2]), p(g_in[3]), p(g_lat[i]), p(g_rho[i]),
                                                         p(g_om[i]), _lib.current_stream()), "fs_ptf_gru_inputs_backward")

@@ -341,13 +341,21 @@ int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, float* 
  * g_fused[n,64] = gradient of the GRU output -> dcat[n,176] = gradient of the input rows (fed to
  * fs_ptf_gru_inputs_backward), and side[n, fs_ptf_gru_side_cols()] =
  *   [dr1 | dz1 | dR | dZ | dn1 | dN | relu(r1) | relu(z1) | relu(n1) | r*hid]   (64 floats each)
- * the pre-activation gradients of the six layers and the hidden activations they pair with: the weight gradients
- * dW = dY^T X (contraction over the n pairs) are left to the caller's GEMM library. */
+ * the pre-activation gradients of the six layers and the hidden activations they pair with.
+ * fs_ptf_gru_weight_grads contracts them over the n pairs, one launch: grads [fs_ptf_gru_grad_floats() = 44928] +=
+ * dW = dY^T X and the bias sums of the 12 parameters, concatenated in the order mlp_r[0].weight [64,176], .bias [64],
+ * mlp_r[2].weight [64,64], .bias, mlp_z[0] .., mlp_z[2] .., mlp_n[0].weight [64,152], .bias, mlp_n[2].weight, .bias
+ * (networks.py:188-199).  ADDED to `grads` (zero it before the first fold step of a backward pass); the summation order
+ * over the pairs is fixed.  workspace: fs_ptf_gru_weight_grads_bytes(n) bytes of device memory (per-workgroup partial
+ * sums, reduced by a second launch). */
 int32_t fs_ptf_gru_table_t_rows(void);
 int32_t fs_ptf_gru_stream_rows(void);
 int32_t fs_ptf_gru_side_cols(void);
 int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables, const float* operand_stream,
                         const float* g_fused, float* dcat, float* side, void* stream);
+int32_t fs_ptf_gru_grad_floats(void);
+size_t fs_ptf_gru_weight_grads_bytes(int32_t n);
+int fs_ptf_gru_weight_grads(int32_t n, const float* cat, const float* side, float* grads, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * Gaussian adapter steps either side of PTF                                             *
