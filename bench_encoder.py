@@ -175,10 +175,16 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
         _lib.profile_enable(False)
         ms, cnt = _lib.profile_collect()["ptf"]
     # training step of the fold (forward + backward, every differentiable input and the GRU parameters): the HIP path (_PtfFold)
+    # (the differentiable inputs are made ONCE; a step = forward, loss, backward, then dropping the gradients)
+    ins = [t.detach().clone().requires_grad_(True) for t in (a[0][0], a[1][0], a[2], a[3], a[4])]
+
     def train_step(fn):
-        ins = [t.detach().clone().requires_grad_(True) for t in (a[0][0], a[1][0], a[2], a[3], a[4])]
         out = fn([ins[0]], [ins[1]], ins[2], ins[3], ins[4], *a[5:])
         sum(o.sum() for o in out).backward()
+        for t in ins:
+            t.grad = None
+        for q in m.gru.parameters():
+            q.grad = None
     n_tr = max(2, steps // 4)
     dt_train = timed(lambda: train_step(m.fuse_gaussians), n_tr, 2) if train else float("nan")
     with torch.no_grad():

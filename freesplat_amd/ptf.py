@@ -97,9 +97,7 @@ def gru_tables(gru: "GRU") -> Tensor:
     """The GRU's weights and biases as MFMA operands of csrc/ptf_gru.hip: rows of 64 lanes, lane l = (p = l & 31,
     hf = l >> 5), one row per MFMA in the order the kernel consumes them, then the bias rows.  Cached per parameter
     version."""
-    params = [gru.mlp_r[0].weight, gru.mlp_r[0].bias, gru.mlp_r[2].weight, gru.mlp_r[2].bias,
-              gru.mlp_z[0].weight, gru.mlp_z[0].bias, gru.mlp_z[2].weight, gru.mlp_z[2].bias,
-              gru.mlp_n[0].weight, gru.mlp_n[0].bias, gru.mlp_n[2].weight, gru.mlp_n[2].bias]
+    params = _gru_params(gru)
     key = tuple((q.data_ptr(), q._version) for q in params)
     hit = _table_cache.get(gru)
     if hit is not None and hit[0] == key:
@@ -273,6 +271,26 @@ def world_to_camera(Es: Tensor) -> Tensor:
     return out
 
 
+def _f32c(t: Tensor) -> Tensor:
+    return t if (t.dtype is torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _fold_inputs(gaussians, coords, densities, weight_emb, depths, extrinsics, V, P, detach):
+    """The reference's tensors (encoder_freesplat.py:431-440: latents [1,V,P,64], coords [1,V,P,srf,spp,3], densities /
+    weights [1,V,P,srf,spp], depths [V,1,h,w], extrinsics [1,V,4,4]) as the fold's arrays lat [V,P,64], xs [V,P,3],
+    rho / om / dep [V,P], Es [V,16] -- views when they already are fp32 and contiguous.  With one surface and one sample
+    per pixel (what FreeSplat uses) `[0, :, :, 0, 0]` is a reshape: the five-index slice costs 18 us of host time each."""
+    d = (lambda t: t.detach()) if detach else (lambda t: t)
+    c, rh, om = coords[0], densities, weight_emb
+    if (c.numel() == 3 * V * P and rh.numel() == V * P and om.numel() == V * P and c.is_contiguous() and rh.is_contiguous()
+            and om.is_contiguous()):
+        xs, rho, om = c.view(V, P, 3), rh.view(V, P), om.view(V, P)
+    else:
+        xs, rho, om = c[0, :, :, 0, 0], rh[0, :, :, 0, 0], om[0, :, :, 0, 0]
+    return (_f32c(d(gaussians[0][0])), _f32c(d(xs)), _f32c(d(rho)), _f32c(d(om)), _f32c(d(depths.reshape(V, -1))),
+            _f32c(extrinsics[0].detach()).reshape(V, 16))
+
+
 def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
                           depth_thres):
     """Inference path (no autograd): ONE library call (fs_ptf_fold) folds all views -- per view match -> GRU inputs ->
@@ -283,57 +301,67 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
     p = _lib.ptr
     h, w = image_shape
     V = gaussians[0].shape[1]
-    f = lambda t: t.detach().float().contiguous()
-    lat = f(gaussians[0][0])                      # [V,P,64]
-    xs = f(coords[0][0, :, :, 0, 0])              # [V,P,3]
-    rho = f(densities[0, :, :, 0, 0])             # [V,P]
-    om = f(weight_emb[0, :, :, 0, 0])
-    dep = f(depths.reshape(V, -1))
-    Es = f(extrinsics[0]).reshape(V, 16)          # [V,16]
-    dev = lat.device
     P = h * w
+    lat, xs, rho, om, dep, Es = _fold_inputs(gaussians, coords, densities, weight_emb, depths, extrinsics, V, P, detach=True)
+    dev = lat.device
     if V == 1:
         return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
     tables = gru_tables(gru)
     # the state after view 0 is view 0 itself; fs_ptf_fold folds views 1 .. V-1 into it, writing the successive states
     # alternately into two sets of buffers -- one library call (camera constants included), one host sync afterwards
-    Kn = f(intrinsics[0]).reshape(V, 9)
+    Kn = _f32c(intrinsics[0]).reshape(V, 9)
     w2c = world_to_camera(Es)
     rows = 2 * P if V == 2 else V * P
-    # the call is HOST-bound at two views (0.19 ms of kernels): one allocation for the state buffers (carved into the six
-    # arrays of each set) instead of 6 - 12, and the fold's internal scratch is kept per (device, V, h, w) -- it is dead
-    # when the call returns (the count read-back below waits for the fold)
+    # The call is HOST-bound at two views (0.19 ms of kernels; profiles/r4_ptf_call_breakdown.txt: 85 us of Python ran
+    # BEFORE the first launch): one allocation for the state buffers, the six arrays of each set addressed by pointer
+    # arithmetic for the call -- the tensor views of the final state are made AFTER the launches, while the GPU works --
+    # and the fold's internal scratch is kept per (device, stream, V, h, w): it is dead when the call returns (the count
+    # read-back below waits for the fold).
     widths = (64, 3, 1, 1, 16, 1)
     n_sets = 1 if V == 2 else 2
-    big = torch.empty(n_sets * rows * sum(widths), device=dev)
-    bufs, off = [], 0
-    for _ in range(n_sets):
-        one = []
-        for n_ in widths:
-            one.append(big[off: off + rows * n_].view(rows, n_))
+    big = torch.empty(n_sets * rows * 86, device=dev)
+    base = big.data_ptr()
+    ptrs = []
+    for k in range(n_sets):
+        arr, off = (C.c_void_p * 6)(), k * rows * 86
+        for q, n_ in enumerate(widths):
+            arr[q] = base + 4 * off
             off += rows * n_
-        bufs.append(one)
-    ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in b]) for b in bufs]
+        ptrs.append(arr)
     counts = torch.empty(V, 4, dtype=torch.int32, device=dev)
-    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream, V, h, w)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, stream, V, h, w)
     scratch = _fold_scratch.get(key)
     if scratch is None:
         while len(_fold_scratch) >= 8:                          # (oldest entry first: dicts keep insertion order)
             _fold_scratch.pop(next(iter(_fold_scratch)))
         scratch = _fold_scratch[key] = torch.empty(L.fs_ptf_fold_bytes(V, h, w), dtype=torch.uint8, device=dev)
     _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), p(w2c), p(Kn), C.c_float(depth_thres),
-                             p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts), _lib.current_stream()), "fs_ptf_fold")
+                             p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts), C.c_void_p(stream)), "fs_ptf_fold")
     global LAST_FOLD_COUNTS
     LAST_FOLD_COUNTS = counts
-    n = int(counts[V - 1, 3].item())               # the only host sync of the fold
-    G, X, _, _, E, D = bufs[0] if ((V - 1) & 1 or V == 2) else bufs[1]
-    return G[None, :n], X[None, :n], E[:n].view(1, n, 4, 4), D[None, :n, 0]
+    last = counts[V - 1, 3]
+    off = 0 if ((V - 1) & 1 or V == 2) else rows * 86        # the set that holds the final state
+    G = big[off: off + rows * 64].view(rows, 64)
+    X = big[off + rows * 64: off + rows * 67].view(rows, 3)
+    E = big[off + rows * 69: off + rows * 85].view(rows, 4, 4)
+    D = big[off + rows * 85: off + rows * 86]
+    n = int(last.item())                           # the only host sync of the fold
+    return G[None, :n], X[None, :n], E[None, :n], D[None, :n]
 
 
 def _gru_params(gru: "GRU") -> list:
-    return [gru.mlp_r[0].weight, gru.mlp_r[0].bias, gru.mlp_r[2].weight, gru.mlp_r[2].bias,
-            gru.mlp_z[0].weight, gru.mlp_z[0].bias, gru.mlp_z[2].weight, gru.mlp_z[2].bias,
-            gru.mlp_n[0].weight, gru.mlp_n[0].bias, gru.mlp_n[2].weight, gru.mlp_n[2].bias]
+    """[mlp_r[0].weight, .bias, mlp_r[2].weight, .bias, mlp_z .., mlp_n ..] -- through the modules' dicts: as attribute
+    chains (gru.mlp_r[0].weight: Module.__getattr__ + Sequential.__getitem__) the twelve look-ups cost 24 us of a 2-view
+    call that is host-bound."""
+    out = []
+    for name in ("mlp_r", "mlp_z", "mlp_n"):
+        layers = gru._modules[name]._modules
+        for k in ("0", "2"):
+            pr = layers[k]._parameters
+            out.append(pr["weight"])
+            out.append(pr["bias"])
+    return out
 
 
 def _gru_from_cat(params: list, cat: Tensor) -> Tensor:
@@ -464,14 +492,9 @@ def _fuse_gaussians_train(gru, gaussians, coords, densities, weight_emb, depths,
     """Training path (autograd): the same HIP fold as inference, with a HIP backward (_PtfFold)."""
     h, w = image_shape
     V = gaussians[0].shape[1]
-    f32 = lambda t: t.float().contiguous()
-    lat = f32(gaussians[0][0])                    # [V,P,64]
-    xs = f32(coords[0][0, :, :, 0, 0])            # [V,P,3]
-    rho = f32(densities[0, :, :, 0, 0])           # [V,P]
-    om = f32(weight_emb[0, :, :, 0, 0])
-    dep = f32(depths.reshape(V, -1))
-    Es = f32(extrinsics[0].detach()).reshape(V, 16)
+    f32 = _f32c
     P = h * w
+    lat, xs, rho, om, dep, Es = _fold_inputs(gaussians, coords, densities, weight_emb, depths, extrinsics, V, P, detach=False)
     if V == 1:
         return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
     Kn = f32(intrinsics[0].detach()).reshape(V, 9)

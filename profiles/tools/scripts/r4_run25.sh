@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python profiles/tools/ptf_call_breakdown.py 2>&1 | tail -3 | tee gpurun_out/r4_ptf_call_breakdown.txt
+code="import bench_encoder as b, torch, json; r = b.bench_ptf(torch.device('cuda:0'), 20, 3, cpu=False); print(json.dumps({'fold_ms': r['ms_per_call'], 'train_ms': r['train_fwd_bwd']['hip_ms']}))"
+python -c "$code" 2>&1 | grep "^{" | tail -1
