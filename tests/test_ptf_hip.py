@@ -180,10 +180,11 @@ def test_fold_backward_with_tied_winners(hip_device):
         assert (a - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-20)
 
 
-@pytest.mark.parametrize("n", [1, 31, 32, 33, 130, 5000])
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 130, 5000, 16411])
 def test_gru_backward_kernel_vs_autograd(hip_device, n):
     """fs_ptf_gru_backward (forward re-run + the six transposed layers on the matrix cores, ragged last group of 32) and
-    the weight-gradient GEMMs on its per-pair factors, against torch autograd of the same GRU (networks.py:201-214) on
+    fs_ptf_gru_weight_grads (dW = dY^T X over the pairs on the matrix cores: one workgroup at n <= 64, a ragged last
+    workgroup, the full 256-workgroup grid at 16411) against torch autograd of the same GRU (networks.py:201-214) on
     the same rows: input-row gradient and all 12 parameter gradients within 1e-4 of each one's max-abs."""
     from freesplat_amd import ptf as P
     torch.manual_seed(100 + n)
@@ -206,6 +207,28 @@ def test_gru_backward_kernel_vs_autograd(hip_device, n):
         assert a.shape == b.shape, k
         worst[f"param{k}"] = rel(a, b)
     assert max(worst.values()) < 1e-4, worst
+
+
+def test_gru_weight_grads_accumulate_in_a_fixed_order(hip_device):
+    """fs_ptf_gru_weight_grads ADDS to `grads` (the fold steps of a scene accumulate in one buffer) and sums the
+    workgroups' partials in a fixed order: two runs on the same rows give the same bits, a second call into the same
+    buffer doubles every entry exactly."""
+    from freesplat_amd import ptf as P
+    torch.manual_seed(7)
+    gru = P.GRU().to(hip_device)
+    n = 9000
+    cat = torch.randn(n, 176, device=hip_device)
+    g = torch.randn(n, 64, device=hip_device)
+    params, tab, stream = P._gru_params(gru), P.gru_tables(gru), P.gru_operand_stream(gru)
+    from freesplat_amd import _lib
+    flat = torch.zeros(_lib.lib().fs_ptf_gru_grad_floats(), device=hip_device)
+    d1, g1 = P.gru_backward(params, tab, stream, cat, g, flat)
+    once = flat.clone()
+    d2, g2 = P.gru_backward(params, tab, stream, cat, g)                  # fresh zeroed buffer
+    assert torch.equal(torch.cat([t.reshape(-1) for t in g2]), once) and torch.equal(d1, d2)
+    P.gru_backward(params, tab, stream, cat, g, flat)                     # second step into the same buffer
+    assert torch.equal(flat, 2 * once)
+    assert [tuple(t.shape) for t in g1] == [tuple(q.shape) for q in params]
 
 
 @pytest.mark.parametrize("n", [1, 33, 4097])
