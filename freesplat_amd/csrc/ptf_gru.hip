@@ -31,10 +31,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   [pad to whole LDS chunks: 704][b_r1: 2*16][b_z1][b_r2][b_z2][b_n1][b_n2]                                   896 rows
 // All four wavefronts of a workgroup consume the same rows in the same order, so they reach the matrix pipe through a
 // two-chunk LDS ring: every wavefront fetches a quarter of the NEXT chunk (kCh rows) from L2 into kCh/4 registers while
-// the current chunk is being multiplied -- a prefetch distance of kCh MFMAs (2 k cycles), one barrier per chunk, a
+// the current chunk is being multiplied -- a prefetch distance of kCh MFMAs (4 k cycles), one barrier per chunk, a
 // quarter of the L2 traffic.  (With each wavefront streaming its own rows from L2 -- one 256-byte load per MFMA, issued
 // a few MFMAs ahead -- the matrix pipe waited half of the time or more: backward 749 -> 324 us per 157 k pairs.)
-constexpr int kCh = 32;
+#ifndef FS_GRU_CH
+#define FS_GRU_CH 64     // (32 and 16 measured: the forward is indifferent, the one-wavefront-per-SIMD backward ~5 % slower; profiles/r4_gru_chunk_ab.txt)
+#endif
+constexpr int kCh = FS_GRU_CH;
 constexpr int kP0 = 0, kP1 = kP0 + 4 * 88, kP2 = kP1 + 4 * 32, kP3 = kP2 + 2 * 76, kFwdUsed = kP3 + 2 * 32,
               kFwdChunks = (kFwdUsed + kCh - 1) / kCh;
 constexpr int kBias = kFwdChunks * kCh, kRows = kBias + 6 * 32;
