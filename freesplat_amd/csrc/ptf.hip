@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void ptf_emit_kernel(int M, const int32_t* __r
 //                   [kept (copied) | fused (GRU output + density-weighted blends) | appended pixels]
 //                   -- replaces ~40 boolean-mask / cat launches and O(M) temporaries per field.
 // ------------------------------------------------------------------------------------------
-// one 16-lane group per fused pair: lanes 0..15 move the two 64-float latents as float4, lane 0/1 the encodings
+// one 16-lane group per fused pair: lanes 0..15 move the two 64-float latents as float4 and share the 24 encodings
 __global__ __launch_bounds__(256) void ptf_gru_inputs_kernel(int n_fuse, const int32_t* __restrict__ counts,
                                                             const long long* __restrict__ fuse_idx,
                                                             const long long* __restrict__ fuse_pix,
@@ -237,8 +237,24 @@ __global__ __launch_bounds__(256) void ptf_gru_inputs_kernel(int n_fuse, const i
     float* row = cat + (size_t)t * 176;
     ((float4*)row)[c] = ((const float4*)(G + m * 64))[c];                 // hid      [0,64)
     ((float4*)(row + 88))[c] = ((const float4*)(g_i + p * 64))[c];        // x        [88,152)
-    if (c == 0) pos_enc2(rho_i[p], O[m], row + 64);                        // he       [64,88)   :486
-    if (c == 1) pos_enc2(R[m], om_i[p], row + 152);                        // xe       [152,176) :485
+    // he = PE(rho_i[p], O[m]) [64,88) :486, xe = PE(R[m], om_i[p]) [152,176) :485 -- four scalars x six octaves, spread
+    // over the 16 lanes (lane c: scalar c >> 2, octaves c & 3 and (c & 3) + 4), the same arithmetic per term as
+    // fs_common.h:pos_enc2 (which the fused GRU kernel uses), one 8-byte store per (sin, cos) pair
+    const int sc = c >> 2, kq = c & 3;
+    const float v = sc == 0 ? rho_i[p] : sc == 1 ? O[m] : sc == 2 ? R[m] : om_i[p];
+    float* out = row + (sc < 2 ? 64 : 152) + 12 * (sc & 1);
+    float rv, ev;
+    rev2pi(v, rv, ev);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = kq + 4 * j;
+        if (k < 6) {
+            const float f = (float)(1 << k);
+            const float tt = rv * f;                                       // (exact)
+            const float ph = (tt - rintf(tt)) + ev * f;
+            *(float2*)(out + 2 * k) = make_float2(__builtin_amdgcn_sinf(ph), __builtin_amdgcn_cosf(ph));
+        }
+    }
 }
 
 struct PtfState { float *G, *X, *R, *O, *E, *D; };
@@ -388,15 +404,29 @@ __global__ __launch_bounds__(256) void ptf_write_state_bwd_kernel(
     }
 }
 
-__device__ __forceinline__ void pos_enc2_bwd(float a, float b, const float* __restrict__ g, float& da, float& db)
-{   // out[2k] = sin(a f), out[2k+1] = cos(a f), out[12+2k] = sin(b f), out[12+2k+1] = cos(b f), f = 2^k
-    da = 0.0f; db = 0.0f;
+// Backward of the positional encodings of a fused pair, spread over its 16 lanes: four scalars (rho_i[p], O[m] of he; R[m],
+// om_i[p] of xe) x six octaves = 24 (sin, cos) pairs.  Lane c works for scalar c >> 2 on the octaves c & 3 and (c & 3) + 4;
+// the quad sums its lanes.  d/dv of out[2k] = sin(v f), out[2k+1] = cos(v f), f = 2^k: f (g[2k] cos(v f) - g[2k+1] sin(v f)),
+// with the forward's phase reduction (fs_common.h:rev2pi) and the hardware v_sin_f32 / v_cos_f32.
+// (Rounds 2 - 3 called cosf / sinf 24 times on each of lanes 0 and 1 -- libm's full-range forms, ~1350 VALU instructions
+// per wavefront of 4 pairs, half of this kernel's 116 us.)
+__device__ __forceinline__ float pos_enc_bwd_lane(float v, const float* __restrict__ g, int kq)
+{
+    float rv, ev;
+    rev2pi(v, rv, ev);
+    float d = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const float f = (float)(1 << k);
-        da += f * (g[2 * k] * cosf(a * f) - g[2 * k + 1] * sinf(a * f));
-        db += f * (g[12 + 2 * k] * cosf(b * f) - g[12 + 2 * k + 1] * sinf(b * f));
+    for (int j = 0; j < 2; ++j) {
+        const int k = kq + 4 * j;
+        if (k < 6) {
+            const float f = (float)(1 << k);
+            const float t = rv * f;                                    // (exact)
+            const float ph = (t - rintf(t)) + ev * f;
+            d += f * (g[2 * k] * __builtin_amdgcn_cosf(ph) - g[2 * k + 1] * __builtin_amdgcn_sinf(ph));
+        }
     }
+    d += __shfl_xor(d, 1);
+    return d + __shfl_xor(d, 2);
 }
 
 __global__ __launch_bounds__(256) void ptf_gru_inputs_bwd_kernel(int n_fuse, const long long* __restrict__ fuse_idx,
@@ -410,24 +440,24 @@ __global__ __launch_bounds__(256) void ptf_gru_inputs_bwd_kernel(int n_fuse, con
                                                                 float* __restrict__ g_om_i)
 {
     const int t = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
-    if (t >= n_fuse) return;
+    if (t >= n_fuse) return;                       // (whole 16-lane groups leave: the quad shuffles below stay inside one)
     const long long m = fuse_idx[t], p = fuse_pix[t];
     const float* row = dcat + (size_t)t * 176;
     ((float4*)(gG + m * 64))[c] = ((const float4*)row)[c];                    // hid: in-row m is fused exactly once
-    const float4 gx = ((const float4*)(row + 88))[c];                         // x: several tied rows may share pixel p
-    float* q = g_lat_i + p * 64 + 4 * c;
-    atomicAdd(q, gx.x); atomicAdd(q + 1, gx.y); atomicAdd(q + 2, gx.z); atomicAdd(q + 3, gx.w);
-    if (c == 0) {   // he = PE(rho_i[p], O[m])
-        float da, db;
-        pos_enc2_bwd(rho_i[p], O[m], row + 64, da, db);
-        atomicAdd(&g_rho_i[p], da);
-        gO[m] += db;
-    }
-    if (c == 1) {   // xe = PE(R[m], om_i[p])
-        float da, db;
-        pos_enc2_bwd(R[m], om_i[p], row + 152, da, db);
-        gR[m] += da;
-        atomicAdd(&g_om_i[p], db);
+    // x: several tied rows may share pixel p -> atomics; lane c takes floats c, c + 16, c + 32, c + 48, so that one atomic
+    // instruction covers 64 CONTIGUOUS bytes of the pixel's row (with 4 c + e it touched every fourth float of all 256)
+    float* q = g_lat_i + p * 64 + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(q + 16 * j, row[88 + 16 * j + c]);
+    // he = PE(rho_i[p], O[m]) at [64,88), xe = PE(R[m], om_i[p]) at [152,176)
+    const int sc = c >> 2;
+    const float v = sc == 0 ? rho_i[p] : sc == 1 ? O[m] : sc == 2 ? R[m] : om_i[p];
+    const float d = pos_enc_bwd_lane(v, row + (sc < 2 ? 64 : 152) + 12 * (sc & 1), c & 3);
+    if ((c & 3) == 0) {
+        if (sc == 0) atomicAdd(&g_rho_i[p], d);
+        else if (sc == 1) gO[m] += d;
+        else if (sc == 2) gR[m] += d;
+        else atomicAdd(&g_om_i[p], d);
     }
 }
 

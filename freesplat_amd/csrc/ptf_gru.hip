@@ -35,7 +35,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // quarter of the L2 traffic.  (With each wavefront streaming its own rows from L2 -- one 256-byte load per MFMA, issued
 // a few MFMAs ahead -- the matrix pipe waited half of the time or more: backward 749 -> 324 us per 157 k pairs.)
 #ifndef FS_GRU_CH
-#define FS_GRU_CH 64     // (32 and 16 measured: the forward is indifferent, the one-wavefront-per-SIMD backward ~5 % slower; profiles/r4_gru_chunk_ab.txt)
+#define FS_GRU_CH 64     // (16 / 32 / 64 measured: both kernels indifferent -- forward 117 - 119 us, backward 309 - 310 us per 103 k pairs; profiles/r4_gru_chunk_ab.txt)
 #endif
 constexpr int kCh = FS_GRU_CH;
 constexpr int kP0 = 0, kP1 = kP0 + 4 * 88, kP2 = kP1 + 4 * 32, kP3 = kP2 + 2 * 76, kFwdUsed = kP3 + 2 * 32,

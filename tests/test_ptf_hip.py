@@ -209,6 +209,55 @@ def test_gru_backward_kernel_vs_autograd(hip_device, n):
     assert max(worst.values()) < 1e-4, worst
 
 
+@pytest.mark.parametrize("n", [1, 5, 1000])
+def test_gru_inputs_rows_and_their_backward(hip_device, n):
+    """fs_ptf_gru_inputs (the materialised rows [hid | PE(rho_i, O) | x | PE(R, om_i)] the training backward re-gathers,
+    encoder_freesplat.py:485-486; every lane of a pair's group computes some of the 24 (sin, cos) pairs) against the torch
+    formulation, values up to the hundreds (a long fold's accumulated densities); fs_ptf_gru_inputs_backward (lanes share
+    the encodings' derivative, contiguous atomics into the view's latent gradient) against torch autograd of the same
+    rows, with two pairs TIED on one pixel."""
+    from freesplat_amd import _lib, ptf as P
+    L, p = _lib.lib(), _lib.ptr
+    g = torch.Generator().manual_seed(n)
+    M, Pn = 3 * n + 2, 2 * n + 3
+    G = torch.randn(M, 64, generator=g).to(hip_device)
+    R = (torch.rand(M, generator=g) * 300).to(hip_device)
+    O = (torch.rand(M, generator=g) * 40).to(hip_device)
+    lat = torch.randn(Pn, 64, generator=g).to(hip_device)
+    rho = torch.rand(Pn, generator=g).to(hip_device)
+    om = (torch.rand(Pn, generator=g) * 3).to(hip_device)
+    fuse = torch.randperm(M, generator=g)[:n].sort().values.to(hip_device)
+    fpix = torch.randperm(Pn, generator=g)[:n].to(hip_device)
+    if n > 1:
+        fpix[1] = fpix[0]                                    # z-tied Gaussians fused with the same pixel
+    cat = torch.empty(n, 176, device=hip_device)
+    _lib.check(L.fs_ptf_gru_inputs(n, p(fuse), p(fpix), p(G), p(R), p(O), p(lat), p(rho), p(om), p(cat),
+                                   _lib.current_stream()), "fs_ptf_gru_inputs")
+
+    def rows(G, R, O, lat, rho, om):
+        he = P.positional_encoding(torch.stack([rho[fpix], O[fuse]], -1).double(), 6)
+        xe = P.positional_encoding(torch.stack([R[fuse], om[fpix]], -1).double(), 6)
+        return torch.cat([G[fuse].double(), he, lat[fpix].double(), xe], -1)
+    ins = [t.detach().clone().requires_grad_(True) for t in (G, R, O, lat, rho, om)]
+    ref = rows(*ins)
+    assert (cat.double() - ref).abs().max().item() < 5e-6
+    dcat = torch.randn(n, 176, generator=g).to(hip_device)
+    gG, gR, gO, gl, gr, go = torch.autograd.grad(ref, ins, dcat.double())
+    # the kernel STORES g_G rows fuse_idx, ADDS to g_R / g_O (what fs_ptf_write_state_backward stored) and accumulates the
+    # view's gradients
+    hG = torch.full((M, 64), 7.0, device=hip_device)
+    hR, hO = torch.ones(M, device=hip_device), torch.ones(M, device=hip_device)
+    hl, hr, ho = torch.zeros(Pn, 64, device=hip_device), torch.zeros(Pn, device=hip_device), torch.zeros(Pn, device=hip_device)
+    _lib.check(L.fs_ptf_gru_inputs_backward(n, p(fuse), p(fpix), p(R), p(O), p(rho), p(om), p(dcat), p(hG), p(hR), p(hO),
+                                            p(hl), p(hr), p(ho), _lib.current_stream()), "fs_ptf_gru_inputs_backward")
+    rel = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-20))
+    assert torch.equal(hG[fuse], dcat[:, :64]) and rel(hl, gl) < 1e-6
+    keep = torch.ones(M, dtype=torch.bool, device=hip_device)
+    keep[fuse] = False
+    assert bool((hG[keep] == 7.0).all())
+    assert rel(hR - 1, gR) < 2e-5 and rel(hO - 1, gO) < 2e-5 and rel(hr, gr) < 2e-5 and rel(ho, go) < 2e-5
+
+
 def test_gru_weight_grads_accumulate_in_a_fixed_order(hip_device):
     """fs_ptf_gru_weight_grads ADDS to `grads` (the fold steps of a scene accumulate in one buffer) and sums the
     workgroups' partials in a fixed order: two runs on the same rows give the same bits, a second call into the same
