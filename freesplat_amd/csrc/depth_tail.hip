@@ -14,30 +14,60 @@
 
 namespace fs {
 
-// one thread per coarse pixel: online softmax statistics (m, s) and expectation
+// Softmax statistics (m, s) and the expectation of 64 consecutive coarse pixels per workgroup: lane = pixel, wavefront w
+// takes the planes d = w (mod 4) in batches of 8 independent loads (one rescaling exponential per batch), the four partial
+// (m, s, acc) triples meet in LDS.  (Rounds 2 - 3: one thread per pixel walking all D planes through a branchy online
+// update -- 384 workgroups, one dependent load at a time: 63 us for 50 MB, 0.8 TB/s.)
 __global__ __launch_bounds__(256) void depth_expect_kernel(int B, int D, int hw, const float* __restrict__ logits,
                                                            const float* __restrict__ cand, int log_planes,
                                                            float* __restrict__ stats, float* __restrict__ coarse,
                                                            float* __restrict__ depth)
 {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)B * hw) return;
-    const int b = (int)(e / hw), p = (int)(e % hw);
+    __shared__ float s_m[4][64], s_s[4][64], s_a[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long e = (long long)blockIdx.x * 64 + lane;
+    const bool live = e < (long long)B * hw;
+    const long long ee = live ? e : 0;           // (a dead lane works on pixel 0 and stores nothing)
+    const int b = (int)(ee / hw), p = (int)(ee % hw);
     const float* l = logits + (size_t)b * D * hw + p;
     float m = -3.0e38f, s = 0.0f, acc = 0.0f;
-    for (int d = 0; d < D; ++d) {
-        const float v = l[(size_t)d * hw];
-        if (v > m) {
-            const float r = expf(m - v);
-            s *= r; acc *= r; m = v;
+    for (int d0 = w; d0 < D; d0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = d0 + 4 * i;
+            v[i] = d < D ? l[(size_t)d * hw] : -3.0e38f;
         }
-        const float ex = expf(v - m);
-        s += ex;
-        acc += cand[d] * ex;
+        float mb = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mb = fmaxf(mb, v[i]);
+        const float mn = fmaxf(m, mb);
+        const float r = expf(m - mn);
+        s *= r; acc *= r; m = mn;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = d0 + 4 * i;
+            if (d < D) {                          // (wave-uniform)
+                const float ex = expf(v[i] - m);
+                s += ex;
+                acc += cand[d] * ex;
+            }
+        }
     }
-    const float E = acc / s;
-    stats[(size_t)b * 2 * hw + p] = m;
-    stats[(size_t)b * 2 * hw + hw + p] = s;
+    s_m[w][lane] = m; s_s[w][lane] = s; s_a[w][lane] = acc;
+    __syncthreads();
+    if (w != 0 || !live) return;
+    const float M = fmaxf(fmaxf(s_m[0][lane], s_m[1][lane]), fmaxf(s_m[2][lane], s_m[3][lane]));
+    float S = 0.0f, A = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float r = expf(s_m[k][lane] - M);   // (a wavefront without planes: exp(-huge) = 0 times its zeros)
+        S += s_s[k][lane] * r;
+        A += s_a[k][lane] * r;
+    }
+    const float E = A / S;
+    stats[(size_t)b * 2 * hw + p] = M;
+    stats[(size_t)b * 2 * hw + hw + p] = S;
     coarse[e] = E;
     depth[e] = log_planes ? expf(E) : 1.0f / E;
 }
@@ -61,7 +91,7 @@ __device__ __forceinline__ Bilin bilin_x2(int y, int x, int h2, int w2)
 // probabilities exp(l - m) / s formed ONCE per plane in LDS, 16 planes at a time, and every fine pixel then takes its
 // bilinear combination from LDS: 0.4 exponentials per fine pixel and plane instead of 4, and the logits are read
 // once per tile footprint instead of four times per fine pixel.
-constexpr int kUpW = 32, kUpH = 8, kUpPlanes = 16, kUpPatch = 18 * 6;
+constexpr int kUpW = 32, kUpH = 8, kUpPlanes = 32, kUpPatch = 18 * 6;
 __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h2, int w2,
                                                              const float* __restrict__ logits,
                                                              const float* __restrict__ stats,
@@ -70,7 +100,6 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
                                                              float* __restrict__ depth_w, int32_t* __restrict__ argmax)
 {
     __shared__ float s_p[kUpPlanes][kUpPatch];
-    __shared__ float s_m[kUpPatch], s_rs[kUpPatch];
     const int H = 2 * h2, W = 2 * w2, hw = h2 * w2;
     const int b = blockIdx.z, t = threadIdx.x;
     const int X0 = blockIdx.x * kUpW, Y0 = blockIdx.y * kUpH;
@@ -82,13 +111,13 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
     const int cy1 = min(min((int)((float)min(Y0 + kUpH - 1, H - 1) * ry), h2 - 1) + 1, h2 - 1);
     const int cx1 = min(min((int)((float)min(X0 + kUpW - 1, W - 1) * rx), w2 - 1) + 1, w2 - 1);
     const int pw = cx1 - cx0 + 1, ph = cy1 - cy0 + 1, np = pw * ph;  // <= 18 x 6
-    const float* m = stats + (size_t)b * 2 * hw;
-    const float* s = m + hw;
-    for (int k = t; k < np; k += 256) {
-        const int ci = (cy0 + k / pw) * w2 + cx0 + k % pw;
-        s_m[k] = m[ci];
-        s_rs[k] = 1.0f / s[ci];
-    }
+    // patch fill: thread t forms the probabilities of patch pixel t & 127 (< np <= 108) for the planes of parity t >> 7 --
+    // its coarse index and softmax statistics are found ONCE (the first version recomputed k / np, c / pw, c % pw for each
+    // of its 7 elements of every 16-plane chunk: ~170 integer divisions per thread, most of the kernel's 67 us)
+    const int pc = t & 127, par = t >> 7;
+    const bool fill = pc < np;
+    const int pci = fill ? (cy0 + pc / pw) * w2 + cx0 + pc % pw : 0;
+    const float pm = stats[(size_t)b * 2 * hw + pci], prs = 1.0f / stats[(size_t)b * 2 * hw + hw + pci];
     // (threads past the image edge take the taps of the nearest inside pixel of THIS tile: their patch-local
     // indices must stay inside the LDS patch; their results are never stored)
     const Bilin q = bilin_x2(min(y, H - 1), min(x, W - 1), h2, w2);
@@ -99,12 +128,11 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
     float best = -1.0f;
     int bi = 0;
     for (int d0 = 0; d0 < D; d0 += kUpPlanes) {
-        __syncthreads();  // (also orders the s_m / s_rs fill before their first use)
+        __syncthreads();  // (the previous chunk's taps are read)
         const int nd = min(kUpPlanes, D - d0);
-        for (int k = t; k < nd * np; k += 256) {
-            const int dd = k / np, c = k % np;
-            const int ci = (cy0 + c / pw) * w2 + cx0 + c % pw;
-            s_p[dd][c] = expf(l[(size_t)(d0 + dd) * hw + ci] - s_m[c]) * s_rs[c];
+        if (fill) {
+#pragma unroll 8
+            for (int dd = par; dd < nd; dd += 2) s_p[dd][pc] = expf(l[(size_t)(d0 + dd) * hw + pci] - pm) * prs;
         }
         __syncthreads();
         for (int dd = 0; dd < nd; ++dd) {
@@ -123,64 +151,110 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
 }
 
 // ---- backward ----
-// fine pixels: d depth_map -> d fine -> 4 coarse neighbours; d depth_weights -> probabilities (arg max plane)
-__global__ __launch_bounds__(256) void depth_upsample_bwd_kernel(int B, int D, int h2, int w2,
-                                                                 const float* __restrict__ depth_map,
-                                                                 const int32_t* __restrict__ argmax, int log_planes,
-                                                                 const float* __restrict__ g_map,
-                                                                 const float* __restrict__ g_w,
-                                                                 float* __restrict__ gE, float* __restrict__ g_prob)
+// One kernel, 64 consecutive coarse pixels per workgroup (lane = pixel, wavefront w = planes d = w (mod 4), as the forward).
+//   dl_d = p_d [ (cand_d - E) gE + g_prob_d - sum_j p_j g_prob_j ],
+// gE = d coarse + d depth through exp / reciprocal + what the x2 map sends back through its bilinear taps; g_prob = what
+// depth_weights sends back: every FINE pixel contributes to ONE plane (its arg max) at its four taps, so a coarse pixel
+// collects at most 6 x 6 fine pixels (rows 2 Y - 2 .. 2 Y + 3: the align_corners source coordinate is fine * (n - 1) /
+// (2 n - 1)).  Each workgroup GATHERS those into an LDS array g_prob[128 planes][64 pixels] (LDS float atomics: two fine
+// pixels of a coarse pixel may share their plane; 36 of them per pixel, not per plane) -- the dense [B,D,h2,w2] gradient of
+// the probabilities is never in HBM.  D > 128: the planes are walked in chunks of 128, gathering per chunk (twice: once
+// for the dot product, once for the output).
+// (Rounds 2 - 3: memset of a dense g_prob, a scatter kernel with 8 global atomics per fine pixel, then one thread per
+// coarse pixel reading logits and g_prob twice: 12 + 89 + 103 us for 2 x 128 x 192 x 256.)
+constexpr int kBwdPlanes = 128;
+__global__ __launch_bounds__(256) void depth_tail_bwd_kernel(int B, int D, int h2, int w2, const float* __restrict__ logits,
+                                                             const float* __restrict__ cand, int log_planes,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ coarse,
+                                                             const float* __restrict__ depth,
+                                                             const float* __restrict__ depth_map,
+                                                             const int32_t* __restrict__ argmax,
+                                                             const float* __restrict__ g_coarse,
+                                                             const float* __restrict__ g_depth,
+                                                             const float* __restrict__ g_map,
+                                                             const float* __restrict__ g_w, float* __restrict__ g_logits)
 {
-    const int H = 2 * h2, W = 2 * w2, hw = h2 * w2;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)B * H * W) return;
-    const int b = (int)(e / ((long long)H * W)), r = (int)(e % ((long long)H * W));
-    const Bilin q = bilin_x2(r / W, r % W, h2, w2);
-    if (g_map) {
-        const float dm = depth_map[e];
-        const float gf = log_planes ? g_map[e] * dm : -g_map[e] * dm * dm;  // d exp(f) = exp(f); d(1/f) = -1/f^2
-        float* g = gE + (size_t)b * hw;
-        atomicAdd(g + q.i00, q.w00 * gf); atomicAdd(g + q.i01, q.w01 * gf);
-        atomicAdd(g + q.i10, q.w10 * gf); atomicAdd(g + q.i11, q.w11 * gf);
-    }
-    if (g_w) {
-        float* gp = g_prob + ((size_t)b * D + argmax[e]) * hw;
-        const float gw = g_w[e];
-        atomicAdd(gp + q.i00, q.w00 * gw); atomicAdd(gp + q.i01, q.w01 * gw);
-        atomicAdd(gp + q.i10, q.w10 * gw); atomicAdd(gp + q.i11, q.w11 * gw);
-    }
-}
+    __shared__ float s_gp[kBwdPlanes * 64];
+    __shared__ float s_gE[64], s_dot[4][64];
+    const int hw = h2 * w2, H = 2 * h2, W = 2 * w2;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long e = (long long)blockIdx.x * 64 + lane;
+    const bool live = e < (long long)B * hw;
+    const long long ee = live ? e : 0;
+    const int b = (int)(ee / hw), p = (int)(ee % hw);
+    const int Y = p / w2, X = p % w2;
+    if (threadIdx.x < 64) s_gE[threadIdx.x] = 0.0f;
 
-// coarse pixels: softmax-expectation backward, dl_d = p_d [ (cand_d - E) gE + g_prob_d - sum_j p_j g_prob_j ]
-__global__ __launch_bounds__(256) void depth_expect_bwd_kernel(int B, int D, int hw, const float* __restrict__ logits,
-                                                               const float* __restrict__ cand, int log_planes,
-                                                               const float* __restrict__ stats,
-                                                               const float* __restrict__ coarse,
-                                                               const float* __restrict__ depth,
-                                                               const float* __restrict__ g_coarse,
-                                                               const float* __restrict__ g_depth,
-                                                               const float* __restrict__ gE_up,
-                                                               const float* __restrict__ g_prob,
-                                                               float* __restrict__ g_logits)
-{
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)B * hw) return;
-    const int b = (int)(e / hw), p = (int)(e % hw);
-    const float m = stats[(size_t)b * 2 * hw + p], s = stats[(size_t)b * 2 * hw + hw + p];
-    const float E = coarse[e];
-    float gE = gE_up ? gE_up[e] : 0.0f;
-    if (g_coarse) gE += g_coarse[e];
-    if (g_depth) gE += log_planes ? g_depth[e] * depth[e] : -g_depth[e] * depth[e] * depth[e];
+    // the fine pixels that tap this coarse pixel: wavefront w looks at 9 of the 36 candidates
+    auto gather = [&](int c0, bool with_map) {
+        for (int k = threadIdx.x; k < kBwdPlanes * 64; k += 256) s_gp[k] = 0.0f;
+        __syncthreads();
+        if (live) {
+            float gEacc = 0.0f;
+            for (int i = 0; i < 9; ++i) {
+                const int idx = 9 * w + i;
+                const int fy = 2 * Y + idx / 6 - 2, fx = 2 * X + idx % 6 - 2;
+                if (fy < 0 || fy >= H || fx < 0 || fx >= W) continue;
+                const Bilin q = bilin_x2(fy, fx, h2, w2);
+                const float wt = (q.i00 == p ? q.w00 : 0.0f) + (q.i01 == p ? q.w01 : 0.0f) + (q.i10 == p ? q.w10 : 0.0f) +
+                                 (q.i11 == p ? q.w11 : 0.0f);
+                if (wt == 0.0f) continue;
+                const size_t f = ((size_t)b * H + fy) * W + fx;
+                if (with_map && g_map) {
+                    const float dm = depth_map[f];
+                    gEacc += wt * (log_planes ? g_map[f] * dm : -g_map[f] * dm * dm);   // d exp(f) = exp(f); d(1/f) = -1/f^2
+                }
+                if (g_w) {
+                    const int d = argmax[f] - c0;
+                    if (d >= 0 && d < kBwdPlanes) atomicAdd(&s_gp[d * 64 + lane], wt * g_w[f]);
+                }
+            }
+            if (with_map && g_map) atomicAdd(&s_gE[lane], gEacc);
+        }
+        __syncthreads();
+    };
+
+    const bool up = g_map || g_w;
+    const float m = stats[(size_t)b * 2 * hw + p], rs = 1.0f / stats[(size_t)b * 2 * hw + hw + p];
     const float* l = logits + (size_t)b * D * hw + p;
-    const float* gp = g_prob ? g_prob + (size_t)b * D * hw + p : nullptr;
-    float dotp = 0.0f;
-    if (gp)
-        for (int d = 0; d < D; ++d) dotp += expf(l[(size_t)d * hw] - m) / s * gp[(size_t)d * hw];
+    const int nchunks = (D + kBwdPlanes - 1) / kBwdPlanes;
+    float dot = 0.0f;
+    if (up) {
+        for (int c = 0; c < nchunks; ++c) {
+            gather(c * kBwdPlanes, c == 0);
+            if (g_w) {
+                const int dend = min(D, (c + 1) * kBwdPlanes);
+#pragma unroll 8
+                for (int d = c * kBwdPlanes + w; d < dend; d += 4)
+                    dot += expf(l[(size_t)d * hw] - m) * rs * s_gp[(d - c * kBwdPlanes) * 64 + lane];
+            }
+        }
+        if (g_w) {
+            s_dot[w][lane] = dot;
+            __syncthreads();
+            dot = (s_dot[0][lane] + s_dot[1][lane]) + (s_dot[2][lane] + s_dot[3][lane]);
+        }
+    } else {
+        __syncthreads();     // (s_gE's zeros)
+    }
+    const float E = coarse[ee];
+    float gE = s_gE[lane];
+    if (g_coarse) gE += g_coarse[ee];
+    if (g_depth) gE += log_planes ? g_depth[ee] * depth[ee] : -g_depth[ee] * depth[ee] * depth[ee];
     float* go = g_logits + (size_t)b * D * hw + p;
-    for (int d = 0; d < D; ++d) {
-        const float pd = expf(l[(size_t)d * hw] - m) / s;
-        const float gpd = gp ? gp[(size_t)d * hw] : 0.0f;
-        go[(size_t)d * hw] = pd * ((cand[d] - E) * gE + gpd - dotp);
+    for (int c = 0; c < nchunks; ++c) {
+        if (up && nchunks > 1) gather(c * kBwdPlanes, false);      // (one chunk: the gather above is still in LDS)
+        const int dend = min(D, (c + 1) * kBwdPlanes);
+        if (live) {
+#pragma unroll 8
+            for (int d = c * kBwdPlanes + w; d < dend; d += 4) {
+                const float pd = expf(l[(size_t)d * hw] - m) * rs;
+                const float gpd = g_w ? s_gp[(d - c * kBwdPlanes) * 64 + lane] : 0.0f;
+                go[(size_t)d * hw] = pd * ((cand[d] - E) * gE + gpd - dot);
+            }
+        }
+        if (up && nchunks > 1) __syncthreads();                    // (the next gather clears s_gp)
     }
 }
 
@@ -198,7 +272,7 @@ FS_API int fs_depth_tail_forward(int32_t B, int32_t D, int32_t h2, int32_t w2, c
         return FS_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream_;
     const long long n = (long long)B * h2 * w2;
-    hipLaunchKernelGGL(depth_expect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, D, h2 * w2, logits,
+    hipLaunchKernelGGL(depth_expect_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, B, D, h2 * w2, logits,
                        candidates, log_planes, stats, coarse, depth);
     if (depth_map)
         hipLaunchKernelGGL(depth_upsample_kernel, dim3((2 * w2 + kUpW - 1) / kUpW, (2 * h2 + kUpH - 1) / kUpH, B), dim3(256),
@@ -216,21 +290,13 @@ FS_API int fs_depth_tail_backward(int32_t B, int32_t D, int32_t h2, int32_t w2, 
 {
     if (B <= 0 || D <= 0 || h2 <= 0 || w2 <= 0 || !logits || !candidates || !stats || !coarse || !depth || !g_logits)
         return FS_ERR_INVALID_ARG;
-    if ((g_map || g_weights) && (!depth_map || !argmax || !scratch_gE)) return FS_ERR_INVALID_ARG;
-    if (g_weights && !scratch_gprob) return FS_ERR_INVALID_ARG;
+    if ((g_map || g_weights) && (!depth_map || !argmax)) return FS_ERR_INVALID_ARG;
+    (void)scratch_gE; (void)scratch_gprob;      // (ABI 1 - 3 scratch of the scatter form: unused since the gather form, may be NULL)
     hipStream_t st = (hipStream_t)stream_;
     const long long n = (long long)B * h2 * w2;
-    const bool up = g_map || g_weights;
-    if (up) {
-        bool ok = hipMemsetAsync(scratch_gE, 0, (size_t)n * 4, st) == hipSuccess;
-        if (g_weights) ok = ok && hipMemsetAsync(scratch_gprob, 0, (size_t)n * D * 4, st) == hipSuccess;
-        if (!ok) { set_last_error("depth tail memset", hipGetLastError()); return FS_ERR_LAUNCH; }
-        hipLaunchKernelGGL(depth_upsample_bwd_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, st, B, D, h2,
-                           w2, depth_map, argmax, log_planes, g_map, g_weights, scratch_gE, scratch_gprob);
-    }
-    hipLaunchKernelGGL(depth_expect_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, D, h2 * w2,
-                       logits, candidates, log_planes, stats, coarse, depth, g_coarse, g_depth,
-                       up ? scratch_gE : nullptr, g_weights ? scratch_gprob : nullptr, g_logits);
+    hipLaunchKernelGGL(depth_tail_bwd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, B, D, h2, w2, logits,
+                       candidates, log_planes, stats, coarse, depth, depth_map, argmax, g_coarse, g_depth, g_map, g_weights,
+                       g_logits);
     FS_CHECK_LAUNCH("depth_tail_backward");
     return FS_OK;
 }

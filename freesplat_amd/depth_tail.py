@@ -46,8 +46,7 @@ class _DepthTail(torch.autograd.Function):
         if all(g is None for g in (g_coarse, g_depth, g_map, g_w)):
             return None, None, None, None
         c = lambda t: None if t is None else t.contiguous()
-        sE = torch.empty(B, h2, w2, device=dev) if (g_map is not None or g_w is not None) else None
-        sP = torch.empty(B, D, h2, w2, device=dev) if g_w is not None else None
+        sE = sP = None        # (scratch of the round 2 - 3 scatter form; the gather form of round 4 keeps both in LDS)
         g_logits = torch.empty_like(logits)
         p = _lib.ptr
         gc_, gd_, gm_, gw_ = c(g_coarse), c(g_depth), c(g_map), c(g_w)   # (kept alive until the launch is queued)

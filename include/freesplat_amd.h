@@ -419,7 +419,9 @@ int fs_depth_tail_forward(int32_t B, int32_t D, int32_t h2, int32_t w2, const fl
                           const float* candidates, int32_t log_planes, float* stats, float* coarse,
                           float* depth, float* depth_map, float* depth_weights, int32_t* argmax, void* stream);
 /* g_coarse / g_depth [B,h2*w2], g_map / g_weights [B,2h2,2w2] (each may be NULL) -> g_logits[B,D,h2,w2].
- * scratch_gE [B,h2*w2] is needed with g_map or g_weights, scratch_gprob [B,D,h2*w2] with g_weights. */
+ * One launch: every coarse pixel gathers the fine pixels that tap it (the gradient of the upsampled probabilities lives in
+ * LDS only).  scratch_gE / scratch_gprob: unused since ABI revision 4 (the scatter form of revisions 1 - 3 needed
+ * [B,h2*w2] and [B,D,h2*w2] floats); pass NULL. */
 int fs_depth_tail_backward(int32_t B, int32_t D, int32_t h2, int32_t w2, const float* logits,
                            const float* candidates, int32_t log_planes, const float* stats,
                            const float* coarse, const float* depth, const float* depth_map,

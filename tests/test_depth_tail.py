@@ -52,6 +52,48 @@ def test_hip_matches_reference_and_autograd(hip_device, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,D,h2,w2,log_planes,which", [
+    (1, 7, 5, 9, True, "all"),            # D not a multiple of the four plane classes, a ragged 64-pixel workgroup
+    (2, 130, 13, 21, True, "all"),        # D > 128: the backward walks two plane chunks
+    (1, 300, 6, 11, False, "all"),        # three chunks, inverse-depth planes
+    (3, 32, 1, 1, True, "all"),           # one coarse pixel per image: every fine pixel taps it
+    (2, 64, 17, 40, True, "weights"),     # only depth_weights has a gradient (no bilinear-map term)
+    (2, 64, 17, 40, False, "map"),        # only the x2 map
+    (2, 64, 17, 40, True, "coarse"),      # no gradient through the upsampled outputs at all
+])
+def test_hip_forward_and_backward_on_seeded_shapes(hip_device, B, D, h2, w2, log_planes, which):
+    """Forward outputs and the gradient of the logits against the float64 oracle's autograd on shapes the goldens do not
+    cover (fs_depth_tail_forward: 4 plane classes x batches of 8; fs_depth_tail_backward: the 6 x 6 gather of fine pixels
+    per coarse pixel, plane chunks of 128, every subset of output gradients the C ABI allows).  Fine pixels whose arg max
+    over the planes is a near-tie may pick another plane: such pixels are masked out of the depth_weights gradient."""
+    from oracle.depth_tail_oracle import depth_tail
+    from freesplat_amd.depth_tail import depth_regression_tail
+    gen = torch.Generator().manual_seed(B * 1000 + D)
+    logits = 2.0 * torch.randn(B, D, h2, w2, generator=gen)
+    lo, hi = (0.5, 15.0)
+    cand = (torch.log(torch.tensor(lo)) + torch.linspace(0, 1, D) * torch.log(torch.tensor(hi / lo))) if log_planes \
+        else (1.0 / hi + torch.linspace(0, 1, D) * (1.0 / lo - 1.0 / hi))
+    lg = logits.to(hip_device).requires_grad_(True)
+    o = depth_regression_tail(lg, cand.to(hip_device), log_planes)
+    lc = logits.double().clone().requires_grad_(True)
+    r = depth_tail(lc, cand.double(), log_planes)
+    for k in ("coarse", "depth", "depth_map", "depth_weights"):
+        assert (o[k].detach().cpu().double() - r[k].detach()).abs().max().item() <= 2e-5 * max(1.0, r[k].abs().max().item()), k
+    # near-ties of the upsampled probabilities: the two largest planes within 1e-5 of each other
+    up = torch.nn.functional.interpolate(torch.softmax(logits.double(), 1), scale_factor=2, mode="bilinear", align_corners=True)
+    top2 = up.topk(2, dim=1).values if D > 1 else None
+    clear = ((top2[:, 0] - top2[:, 1]) > 1e-5)[:, None] if D > 1 else torch.ones_like(r["depth_weights"], dtype=torch.bool)
+    gs = {k: torch.randn(r[k].shape, generator=gen) for k in ("coarse", "depth", "depth_map", "depth_weights")}
+    gs["depth_weights"] = gs["depth_weights"] * clear
+    keys = {"all": ("coarse", "depth", "depth_map", "depth_weights"), "weights": ("depth_weights",), "map": ("depth_map",),
+            "coarse": ("coarse", "depth")}[which]
+    sum((o[k] * gs[k].to(hip_device)).sum() for k in keys).backward()
+    sum((r[k] * gs[k].double()).sum() for k in keys).backward()
+    e = (lg.grad.cpu().double() - lc.grad).abs()
+    assert e.max().item() <= 2e-5 * lc.grad.abs().max().item(), (e.max().item(), lc.grad.abs().max().item())
+
+
+@pytest.mark.gpu
 def test_hip_native_size_and_coarse_only(hip_device):
     from oracle.depth_tail_oracle import depth_tail
     from freesplat_amd.depth_tail import apply_to_depth_outputs, depth_regression_tail
