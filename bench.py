@@ -24,6 +24,7 @@ carries sub-objects measured in the same run, each with its own roofline / cpu_b
   "cost_volume"  plane-sweep cost volume: native 96x128 K=1 and config-3 scale 242x324 K=2 (roofline: fp32 MFMA)
   "c3_fp16_sh"   the headline workload with the SH coefficients stored in fp16 (BASELINE config 5's storage option)
   "ptf"          Pixel-wise Triplet Fusion folds: 2, 10 and 30 views at 384x512, 3 views at 968x1296 (roofline: HBM)
+  "encoder_tail" the depth-regression tail of the DepthDecoder and the latent -> Gaussian head at the native size (roofline: HBM)
 (`--sections raster` restricts the run to the top-level metric.)
 """
 from __future__ import annotations
@@ -53,7 +54,7 @@ def parse():
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
                     help="top-level measurement. fwd: forward rendering (the metric); train: fwd + bwd (+ grad exchange)")
     ap.add_argument("--sections", default="all",
-                    help="N=1 only: comma list of extra sub-objects (train,c2,cost_volume,ptf), 'all', or 'raster' for none")
+                    help="N=1 only: comma list of extra sub-objects (train,c2,c5,cost_volume,ptf,encoder_tail), 'all', or 'raster' for none")
     ap.add_argument("--grad-exchange", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
                     help="N>1 train mode: how the per-Gaussian gradients of the view shards are summed")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image all-gather")
@@ -516,7 +517,7 @@ def main():
     out = bench_raster(cx, args.workload, args.mode, args.views, args.steps, args.warmup, cpu)
     sections = []
     if cx.world == 1 and args.sections != "raster":
-        sections = ["train", "c2", "c5", "cost_volume", "ptf"] if args.sections == "all" else args.sections.split(",")
+        sections = ["train", "c2", "c5", "cost_volume", "ptf", "encoder_tail"] if args.sections == "all" else args.sections.split(",")
 
     def section(fn):
         """A secondary measurement must never take the headline line down with it."""
@@ -546,8 +547,14 @@ def main():
     if "c5" in sections and args.mode == "fwd":
         # BASELINE config 5's storage option on the headline workload: SH coefficients held in fp16
         out["c3_fp16_sh"] = section(lambda: bench_raster(cx, args.workload, "fwd", args.views, args.steps, args.warmup, cpu, sh_fp16=True))
-    if "cost_volume" in sections or "ptf" in sections:
+    if "cost_volume" in sections or "ptf" in sections or "encoder_tail" in sections:
         import bench_encoder as be
+        if "encoder_tail" in sections:
+            # the rows SURVEY.md 8(f) marks "next": the DepthDecoder's regression tail and the latent -> Gaussian head
+            out["encoder_tail"] = {
+                "depth_tail": section(lambda: be.bench_depth_tail(cx.dev, args.steps, args.warmup)),
+                "gaussian_head": section(lambda: be.bench_gaussian_head(cx.dev, args.steps, args.warmup, cpu=cpu)),
+            }
         if "cost_volume" in sections:
             out["cost_volume"] = {
                 "native_96x128_K1": section(lambda: be.bench_cost_volume(cx.dev, args.steps, args.warmup, cpu=cpu)),

@@ -282,6 +282,53 @@ def bench_depth_tail(dev, steps, warmup, V=2, D=128, h2=192, w2=256):
             "parity": {"max_abs_err_vs_oracle": err}}
 
 
+def bench_gaussian_head(dev, steps, warmup, M=290044, cpu=True):
+    """Latent -> Gaussian head (gaussian_adapter.py:151-172) on the fused set of the native 2-view scene: forward and
+    forward + backward, against the oracle on the host."""
+    from freesplat_amd.gaussian_adapter import _Head
+    from oracle import adapter_oracle as ao
+    g = torch.Generator().manual_seed(3)
+    raw = torch.randn(M, 34, generator=g)
+    dep = 1.0 + torch.rand(M, generator=g)
+    E = torch.eye(4).repeat(M, 1, 1) + 0.1 * torch.randn(M, 4, 4, generator=g)
+    mult = torch.tensor([0.0123])
+    mask = torch.tensor([1.0, .025, .025, .025, .00625, .00625, .00625, .00625, .00625])
+    d = lambda t: t.to(dev)
+    rg, dg, eg = d(raw).requires_grad_(True), d(dep).requires_grad_(True), d(E).requires_grad_(True)
+    mg, kg = d(mult), d(mask)
+    gs = [d(torch.randn(M, 3, 3, generator=g)), d(torch.randn(M, 3, 9, generator=g)), d(torch.randn(M, 3, generator=g)),
+          d(torch.randn(M, 4, generator=g))]
+
+    def both():
+        o = _Head.apply(rg, dg, eg, mg, kg, 0.5, 15.0)
+        torch.autograd.backward(list(o), gs)
+        rg.grad = dg.grad = eg.grad = None
+
+    with torch.no_grad():
+        dt = timed(lambda: _Head.apply(rg, dg, eg, mg, kg, 0.5, 15.0), steps, warmup)
+        got = _Head.apply(rg, dg, eg, mg, kg, 0.5, 15.0)
+    dt_fb = timed(both, steps, warmup)
+    nbytes = M * (34 + 1 + 16 + 9 + 27 + 3 + 4) * 4        # read raw, depth, extrinsics; write cov, sh, scales, rotations
+    extra = {}
+    if cpu:
+        cores = min(64, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref = ao.gaussian_head(raw, dep, E, mult[0], mask)
+            t_cpu = time.perf_counter() - t0
+        torch.set_num_threads(8)
+        err = max(float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-20)) for a, b in zip(got, ref))
+        extra = {"cpu_baseline": {"value": 1.0 / t_cpu, "unit": "calls/s", "cores": cores, "kind": "port",
+                                  "sample": "1 call of oracle/adapter_oracle.py:gaussian_head (torch CPU)"},
+                 "parity": {"max_rel_err_vs_oracle": err}}
+    return dict({"metric": f"Gaussian-head calls/sec, {M} Gaussians", "value": 1.0 / dt, "unit": "calls/s",
+                 "ms_per_call": dt * 1e3, "ms_fwd_bwd": dt_fb * 1e3, "dtype": "f32", "data": "synthetic",
+                 "config": {"workload": "gaussian_head_native", "gaussians": M},
+                 "roofline": {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": nbytes / dt / 8e12, "traffic": None, "note": "wall clock per call, 1 kernel"}}, **extra)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -293,3 +340,4 @@ if __name__ == "__main__":
     print(json.dumps(bench_ptf(dev, a.steps, a.warmup)), flush=True)
     print(json.dumps(bench_ptf(dev, max(2, a.steps // 4), 1, V=10)), flush=True)
     print(json.dumps(bench_depth_tail(dev, a.steps, a.warmup)), flush=True)
+    print(json.dumps(bench_gaussian_head(dev, a.steps, a.warmup)), flush=True)

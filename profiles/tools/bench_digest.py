@@ -28,7 +28,7 @@ def show(k, v, ind=0):
         line += " parity=" + json.dumps(v["parity"])[:170]
     print(line)
     for kk, vv in v.items():
-        if isinstance(vv, dict) and (kk in ("train", "c2", "c3_fp16_sh", "fast_exp", "cost_volume", "ptf", "multi_gpu") or "metric" in vv):
+        if isinstance(vv, dict) and (kk in ("train", "c2", "c3_fp16_sh", "fast_exp", "cost_volume", "ptf", "encoder_tail", "multi_gpu") or "metric" in vv):
             show(kk, vv, ind + 2)
 
 
