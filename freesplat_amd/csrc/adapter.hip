@@ -107,6 +107,35 @@ __device__ __forceinline__ void mat3_mul_at(const float* X, const float* Y, floa
         for (int b = 0; b < 3; ++b) Z[3 * a + b] = X[a] * Y[b] + X[3 + a] * Y[3 + b] + X[6 + a] * Y[6 + b];
 }
 
+// The [M, PER] arrays of this step are arrays of structures: thread m touching raw[m * 34 + c] makes every load
+// instruction of a wavefront span 64 x 136 bytes (2.5 - 3.5 TB/s of the algorithmic bytes in rounds 2 - 3).  A workgroup's 256
+// consecutive rows are ONE contiguous slab, so they cross HBM as 16-byte coalesced accesses and meet their threads in LDS
+// (row strides 34 / 27 / 9 words: at most 2-way bank conflicts).
+template <int PER>
+__device__ __forceinline__ void rows_in(float* __restrict__ lds, const float* __restrict__ src, long long m0, int cnt)
+{
+    const float* g = src + m0 * PER;
+    const int total = cnt * PER;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        for (int k = 4 * threadIdx.x; k + 3 < total; k += 1024) *(float4*)(lds + k) = *(const float4*)(g + k);
+        for (int k = (total & ~3) + threadIdx.x; k < total; k += 256) lds[k] = g[k];
+    } else {
+        for (int k = threadIdx.x; k < total; k += 256) lds[k] = g[k];
+    }
+}
+template <int PER>
+__device__ __forceinline__ void rows_out(float* __restrict__ dst, const float* __restrict__ lds, long long m0, int cnt)
+{
+    float* g = dst + m0 * PER;
+    const int total = cnt * PER;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        for (int k = 4 * threadIdx.x; k + 3 < total; k += 1024) *(float4*)(g + k) = *(const float4*)(lds + k);
+        for (int k = (total & ~3) + threadIdx.x; k < total; k += 256) g[k] = lds[k];
+    } else {
+        for (int k = threadIdx.x; k < total; k += 256) g[k] = lds[k];
+    }
+}
+
 __global__ __launch_bounds__(256) void head_fwd_kernel(long long M, const float* __restrict__ raw,
                                                        const float* __restrict__ depths,
                                                        const float* __restrict__ E,
@@ -115,28 +144,46 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(long long M, const float*
                                                        float* __restrict__ cov, float* __restrict__ sh,
                                                        float* __restrict__ scales, float* __restrict__ rot)
 {
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
+    __shared__ float s_rows[256 * 43];          // in: 34 raw floats per row; out: sh 27 | cov 9 | scales 3 | rotation 4
+    const long long m0 = (long long)blockIdx.x * 256;
+    const int cnt = (int)min((long long)256, M - m0), t = threadIdx.x;
+    const long long m = m0 + t;
+    const bool live = t < cnt;
+    rows_in<34>(s_rows, raw, m0, cnt);
+    __syncthreads();
     float rw[34];
 #pragma unroll
-    for (int c = 0; c < 34; ++c) rw[c] = raw[m * 34 + c];
-    HeadFwd f;
-    head_forward(rw, depths[m], mult[m * mult_stride], smin, smax, f);
-    float Rc[9], B[9], S[9];
+    for (int c = 0; c < 34; ++c) rw[c] = live ? s_rows[t * 34 + c] : 1.0f;
+    __syncthreads();                             // (the outputs below reuse the rows' LDS)
+    if (live) {
+        HeadFwd f;
+        head_forward(rw, depths[m], mult[m * mult_stride], smin, smax, f);
+        float Rc[9], B[9], S[9];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 3; ++a) {
+            const float4 er = ((const float4*)(E + m * 16))[a];
+            Rc[3 * a] = er.x; Rc[3 * a + 1] = er.y; Rc[3 * a + 2] = er.z;
+        }
+        mat3_mul(Rc, f.A, B);        // c2w @ cov
+        mat3_mul_bt(B, Rc, S);       // ... @ c2w^T                 gaussian_adapter.py:171-172
+        float* o_sh = s_rows + t * 27;
+        float* o_cov = s_rows + 256 * 27 + t * 9;
+        float* o_sc = s_rows + 256 * 36 + t * 3;
+        float* o_rot = s_rows + 256 * 39 + t * 4;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) Rc[3 * a + b] = E[m * 16 + 4 * a + b];
-    mat3_mul(Rc, f.A, B);        // c2w @ cov
-    mat3_mul_bt(B, Rc, S);       // ... @ c2w^T                 gaussian_adapter.py:171-172
+        for (int c = 0; c < 27; ++c) o_sh[c] = rw[7 + c] * sh_mask[c % 9];   // "(xyz d_sh)" * mask :166-167
 #pragma unroll
-    for (int c = 0; c < 9; ++c) cov[m * 9 + c] = S[c];
+        for (int c = 0; c < 9; ++c) o_cov[c] = S[c];
 #pragma unroll
-    for (int c = 0; c < 27; ++c) sh[m * 27 + c] = rw[7 + c] * sh_mask[c % 9];   // "(xyz d_sh)" * mask :166-167
+        for (int c = 0; c < 3; ++c) o_sc[c] = f.sc[c];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) scales[m * 3 + c] = f.sc[c];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) rot[m * 4 + c] = f.q[c];
+        for (int c = 0; c < 4; ++c) o_rot[c] = f.q[c];
+    }
+    __syncthreads();
+    rows_out<27>(sh, s_rows, m0, cnt);
+    rows_out<9>(cov, s_rows + 256 * 27, m0, cnt);
+    rows_out<3>(scales, s_rows + 256 * 36, m0, cnt);
+    rows_out<4>(rot, s_rows + 256 * 39, m0, cnt);
 }
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(long long M, const float* __restrict__ raw,
@@ -150,19 +197,39 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(long long M, const float*
                                                        const float* __restrict__ g_rot, float* __restrict__ g_raw,
                                                        float* __restrict__ g_depths, float* __restrict__ g_E)
 {
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
+    __shared__ float s_rows[256 * 34];          // raw rows in, then g_sh rows in, then g_raw rows out
+    const long long m0 = (long long)blockIdx.x * 256;
+    const int cnt = (int)min((long long)256, M - m0), t = threadIdx.x;
+    const bool live = t < cnt;
+    const long long m = live ? m0 + t : m0;     // (a dead thread works on the workgroup's first row and stores nothing)
+    rows_in<34>(s_rows, raw, m0, cnt);
+    __syncthreads();
     float rw[34];
 #pragma unroll
-    for (int c = 0; c < 34; ++c) rw[c] = raw[m * 34 + c];
+    for (int c = 0; c < 34; ++c) rw[c] = s_rows[(live ? t : 0) * 34 + c];
+    __syncthreads();
+    float gsh[27];
+    if (g_sh) {
+        rows_in<27>(s_rows, g_sh, m0, cnt);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 27; ++c) gsh[c] = s_rows[(live ? t : 0) * 27 + c];
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int c = 0; c < 27; ++c) gsh[c] = 0.0f;
+    }
     const float depth = depths[m], mu = mult[m * mult_stride];
     HeadFwd f;
     head_forward(rw, depth, mu, smin, smax, f);
     float Rc[9], G[9], B[9];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a) {
+        const float4 er = ((const float4*)(E + m * 16))[a];
+        Rc[3 * a] = er.x; Rc[3 * a + 1] = er.y; Rc[3 * a + 2] = er.z;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) { Rc[3 * a + b] = E[m * 16 + 4 * a + b]; G[3 * a + b] = g_cov ? g_cov[m * 9 + 3 * a + b] : 0.0f; }
+        for (int b = 0; b < 3; ++b) G[3 * a + b] = g_cov ? g_cov[m * 9 + 3 * a + b] : 0.0f;
+    }
     mat3_mul(Rc, f.A, B);
     // Sigma = B Rc^T, B = Rc A
     float dB[9], dRc[9], dA[9], t1[9];
@@ -224,14 +291,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(long long M, const float*
         gdepth += dsc[b] * (smin + (smax - smin) * f.sig[b]) * mu;
     }
 #pragma unroll
-    for (int c = 0; c < 27; ++c) gr[7 + c] = g_sh ? g_sh[m * 27 + c] * sh_mask[c % 9] : 0.0f;
+    for (int c = 0; c < 27; ++c) gr[7 + c] = gsh[c] * sh_mask[c % 9];
+    if (live) {
 #pragma unroll
-    for (int c = 0; c < 34; ++c) g_raw[m * 34 + c] = gr[c];
-    g_depths[m] = gdepth;
+        for (int c = 0; c < 34; ++c) s_rows[t * 34 + c] = gr[c];
+        g_depths[m] = gdepth;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) g_E[m * 16 + 4 * a + b] = (a < 3 && b < 3) ? dRc[3 * a + b] : 0.0f;
+        for (int a = 0; a < 4; ++a)
+            ((float4*)(g_E + m * 16))[a] = a < 3 ? make_float4(dRc[3 * a], dRc[3 * a + 1], dRc[3 * a + 2], 0.0f)
+                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    rows_out<34>(g_raw, s_rows, m0, cnt);
 }
 
 }  // namespace fs
