@@ -72,9 +72,11 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
     args = {k: v.to(dev) for k, v in kw.items()}
     with torch.no_grad():
         out = mg(**args).cpu()
-        timed(lambda: mg(**args), 0, warmup)             # (allocator growth and first-use effects stay out of the events)
+        # the call rate is timed with the stage events OFF (two hipEventRecords per stage of every call are host work the
+        # product does not do); a second loop of the same length, events on, gives the kernels' durations
+        dt = timed(lambda: mg(**args), steps, warmup)
         _lib.profile_collect(); _lib.profile_enable(True)
-        dt = timed(lambda: mg(**args), steps, 0)
+        timed(lambda: mg(**args), steps, 0)
         _lib.profile_enable(False)
         ms, cnt = _lib.profile_collect()["cost_volume"]
     flops = V * h4 * w4 * D * (480 * K + 5248)
@@ -169,9 +171,9 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
     a = ([d(lat)], [d(coords)], d(dens), d(wts), d(depths), d(E)[None], d(Kn)[None], (h, w))
     with torch.no_grad():
         out = [x.cpu() for x in m.fuse_gaussians(*a)]
-        timed(lambda: m.fuse_gaussians(*a), 0, warmup + 1)    # (allocator growth and first-use effects stay out of the events)
+        dt = timed(lambda: m.fuse_gaussians(*a), steps, warmup + 1)    # (stage events off: see bench_cost_volume)
         _lib.profile_collect(); _lib.profile_enable(True)
-        dt = timed(lambda: m.fuse_gaussians(*a), steps, 0)
+        timed(lambda: m.fuse_gaussians(*a), steps, 0)
         _lib.profile_enable(False)
         ms, cnt = _lib.profile_collect()["ptf"]
     # training step of the fold (forward + backward, every differentiable input and the GRU parameters): the HIP path (_PtfFold)

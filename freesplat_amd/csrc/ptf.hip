@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void ptf_cameras_kernel(int V, int P, int h, i
 }
 
 namespace {
-size_t fold_camera_bytes(int V, int P) { return align_up((size_t)V * 4 * 4, 256) + align_up((size_t)P * 64, 256); }
+size_t fold_camera_bytes(int V, int P) { return align_up((size_t)V * 4 * 4, 256) + align_up((size_t)P * 64, 256) + align_up((size_t)V * 64, 256); }
 }
 
 // The per-view pixel intrinsics kpix [V,4] = (fx w, fy h, cx w, cy h) and the initial per-Gaussian extrinsics E0 [P,16]
@@ -679,7 +679,7 @@ FS_API size_t fs_ptf_fold_bytes(int32_t V, int32_t h, int32_t w)
 }
 
 // All fold steps of one scene in one host call: views 1 .. V-1 are folded into the state that starts as view 0.
-// lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es [V,16] (camera-to-world), w2c [V,16] (its inverse), Kn [V,9]
+// lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es [V,16] (camera-to-world), w2c [V,16] (its inverse; NULL: computed here), Kn [V,9]
 // (normalised intrinsics);
 // bufA / bufB: two sets of 6 state arrays (G, X, R, O, E, D) with V*P rows each (2*P for V == 2, bufB unused), written
 // alternately; counts [V,4].  The final state is in set A if (V - 1) is odd, else B, with counts[V-1][3] rows.
@@ -689,7 +689,7 @@ FS_API int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const 
                        float depth_thres, const float* gru_tables, void* scratch, float* const* bufA, float* const* bufB,
                        int32_t* counts, void* stream_)
 {
-    if (V < 2 || h <= 0 || w <= 0 || !lat || !xs || !rho || !om || !dep || !Es || !w2c || !Kn || !gru_tables || !scratch ||
+    if (V < 2 || h <= 0 || w <= 0 || !lat || !xs || !rho || !om || !dep || !Es || !Kn || !gru_tables || !scratch ||
         !bufA || !bufB || !counts)
         return FS_ERR_INVALID_ARG;
     const size_t P = (size_t)h * w;
@@ -697,6 +697,12 @@ FS_API int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const 
     char* cam = (char*)scratch + fold_layout((int)((V - 1) * P), (int)P).total;
     float* kpix = (float*)cam;
     float* E0 = (float*)(cam + align_up((size_t)V * 4 * 4, 256));
+    if (!w2c) {     // the world-to-camera matrices are formed here (fs_invert_4x4, into the scratch): one launch, no extra call
+        float* inv = (float*)(cam + align_up((size_t)V * 4 * 4, 256) + align_up(P * 64, 256));
+        const int rc = fs_invert_4x4(V, Es, inv, stream_);
+        if (rc != FS_OK) return rc;
+        w2c = inv;
+    }
     {
         const long long nt = (long long)P * 4 > V ? (long long)P * 4 : V;
         hipLaunchKernelGGL(ptf_cameras_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, V, (int)P, h, w, Es,

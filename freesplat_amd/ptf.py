@@ -302,15 +302,15 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
     h, w = image_shape
     V = gaussians[0].shape[1]
     P = h * w
-    lat, xs, rho, om, dep, Es = _fold_inputs(gaussians, coords, densities, weight_emb, depths, extrinsics, V, P, detach=True)
+    # (no detach: this path runs without autograd -- fuse_gaussians checked -- and hands raw pointers to the library)
+    lat, xs, rho, om, dep, Es = _fold_inputs(gaussians, coords, densities, weight_emb, depths, extrinsics, V, P, detach=False)
     dev = lat.device
     if V == 1:
-        return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
+        return lat[:1].detach(), xs[:1].detach(), Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1].detach()
     tables = gru_tables(gru)
     # the state after view 0 is view 0 itself; fs_ptf_fold folds views 1 .. V-1 into it, writing the successive states
     # alternately into two sets of buffers -- one library call (camera constants included), one host sync afterwards
     Kn = _f32c(intrinsics[0]).reshape(V, 9)
-    w2c = world_to_camera(Es)
     rows = 2 * P if V == 2 else V * P
     # The call is HOST-bound at two views (0.19 ms of kernels; profiles/r4_ptf_call_breakdown.txt: 85 us of Python ran
     # BEFORE the first launch): one allocation for the state buffers, the six arrays of each set addressed by pointer
@@ -336,7 +336,8 @@ def _fuse_gaussians_fused(gru, gaussians, coords, densities, weight_emb, depths,
         while len(_fold_scratch) >= 8:                          # (oldest entry first: dicts keep insertion order)
             _fold_scratch.pop(next(iter(_fold_scratch)))
         scratch = _fold_scratch[key] = torch.empty(L.fs_ptf_fold_bytes(V, h, w), dtype=torch.uint8, device=dev)
-    _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), p(w2c), p(Kn), C.c_float(depth_thres),
+    # (w2c = NULL: the library inverts the extrinsics itself, with the kernel world_to_camera() uses -- one call less)
+    _lib.check(L.fs_ptf_fold(V, h, w, p(lat), p(xs), p(rho), p(om), p(dep), p(Es), None, p(Kn), C.c_float(depth_thres),
                              p(tables), p(scratch), ptrs[0], ptrs[-1], p(counts), C.c_void_p(stream)), "fs_ptf_fold")
     global LAST_FOLD_COUNTS
     LAST_FOLD_COUNTS = counts

@@ -315,8 +315,8 @@ int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, 
 
 /* All fold steps of one scene in one host call (no host sync, no allocation): views 1 .. V-1 are folded into the state
  * that starts as view 0.  lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es [V,16] (camera-to-world), w2c [V,16]
- * (its inverse, from the caller: a pixel's rounding can hinge on its last bit, so it must be the reference's own
- * torch inverse), Kn [V,9] (normalised intrinsics; scaled to pixels on the device, encoder_freesplat.py:445-448).  bufA / bufB: two sets of 6 state arrays {G [.,64], X [.,3], R, O, E [.,16], D} with V*P rows
+ * (its inverse; NULL = formed here by fs_invert_4x4 -- a pixel's rounding can hinge on the inverse's last bit, so a caller
+ * that must reproduce another inverse bit for bit, e.g. torch's, hands its own matrices over), Kn [V,9] (normalised intrinsics; scaled to pixels on the device, encoder_freesplat.py:445-448).  bufA / bufB: two sets of 6 state arrays {G [.,64], X [.,3], R, O, E [.,16], D} with V*P rows
  * each (2*P for V == 2, where bufB is unused), written alternately; counts [V,4].  The final state is set A if
  * (V - 1) is odd, else B, with counts[V-1][3] rows.  scratch: fs_ptf_fold_bytes(V, h, w). */
 size_t fs_ptf_fold_bytes(int32_t V, int32_t h, int32_t w);
