@@ -88,10 +88,14 @@ __device__ __forceinline__ Bilin bilin_x2(int y, int x, int h2, int w2)
 }
 
 // One workgroup per 32 x 8 tile of fine pixels.  The tile's coarse footprint (<= 18 x 6 pixels) has its
-// probabilities exp(l - m) / s formed ONCE per plane in LDS, 16 planes at a time, and every fine pixel then takes its
+// probabilities exp(l - m) / s formed ONCE per plane in LDS, 32 planes at a time, and every fine pixel then takes its
 // bilinear combination from LDS: 0.4 exponentials per fine pixel and plane instead of 4, and the logits are read
-// once per tile footprint instead of four times per fine pixel.
-constexpr int kUpW = 32, kUpH = 8, kUpPlanes = 32, kUpPatch = 18 * 6;
+// once per tile footprint instead of four times per fine pixel.  The patch is stored PIXEL-major ([pixel][plane], rows of
+// 32 + 4 words): a thread fills four consecutive planes of its patch pixel with one ds_write_b128 and reads four planes of
+// a tap with one ds_read_b128 -- 8 instead of 11 instructions per plane and fine pixel in the loop that bounds the kernel
+// (VALU issue: 128 planes x 393 k fine pixels).  Probabilities through v_exp_f32: |error| <= 2e-8 (the argument
+// (l - m) log2 e <= 0 carries a relative rounding of 2^-24, which matters only where e^t is tiny).
+constexpr int kUpW = 32, kUpH = 8, kUpPlanes = 32, kUpRow = kUpPlanes + 4, kUpPatch = 18 * 6;
 __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h2, int w2,
                                                              const float* __restrict__ logits,
                                                              const float* __restrict__ stats,
@@ -99,10 +103,19 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
                                                              float* __restrict__ depth_map,
                                                              float* __restrict__ depth_w, int32_t* __restrict__ argmax)
 {
-    __shared__ float s_p[kUpPlanes][kUpPatch];
+    __shared__ __attribute__((aligned(16))) float s_p[kUpPatch * kUpRow];
     const int H = 2 * h2, W = 2 * w2, hw = h2 * w2;
-    const int b = blockIdx.z, t = threadIdx.x;
-    const int X0 = blockIdx.x * kUpW, Y0 = blockIdx.y * kUpH;
+    const int t = threadIdx.x;
+    // XCD-banded tile order: workgroup n runs on XCD n % 8; neighbouring tiles share cache lines of every plane (footprints
+    // overlap, 18-float rows straddle 128-byte lines), so each XCD gets a band of consecutive tile rows and finds its
+    // neighbours' lines in ITS L2 instead of fetching them again
+    const int tiles_x = (W + kUpW - 1) / kUpW, tiles_y = (H + kUpH - 1) / kUpH;
+    const int rows_total = tiles_y * B, rows_per_xcd = (rows_total + 7) / 8;
+    const int xcd = blockIdx.x & 7, in_xcd = blockIdx.x >> 3;
+    const int trow = xcd * rows_per_xcd + in_xcd / tiles_x;
+    if (trow >= rows_total || in_xcd / tiles_x >= rows_per_xcd) return;      // (workgroup-uniform)
+    const int b = trow / tiles_y;
+    const int X0 = (in_xcd % tiles_x) * kUpW, Y0 = (trow % tiles_y) * kUpH;
     const int x = X0 + (t & 31), y = Y0 + (t >> 5);
     const bool in = x < W && y < H;
     // coarse footprint of the tile (same source-coordinate arithmetic as bilin_x2)
@@ -111,33 +124,51 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
     const int cy1 = min(min((int)((float)min(Y0 + kUpH - 1, H - 1) * ry), h2 - 1) + 1, h2 - 1);
     const int cx1 = min(min((int)((float)min(X0 + kUpW - 1, W - 1) * rx), w2 - 1) + 1, w2 - 1);
     const int pw = cx1 - cx0 + 1, ph = cy1 - cy0 + 1, np = pw * ph;  // <= 18 x 6
-    // patch fill: thread t forms the probabilities of patch pixel t & 127 (< np <= 108) for the planes of parity t >> 7 --
-    // its coarse index and softmax statistics are found ONCE (the first version recomputed k / np, c / pw, c % pw for each
-    // of its 7 elements of every 16-plane chunk: ~170 integer divisions per thread, most of the kernel's 67 us)
+    // patch fill: thread t forms the probabilities of patch pixel t & 127 (< np <= 108) for the plane quads of parity
+    // t >> 7 -- its coarse index and softmax statistics are found ONCE (the first version recomputed k / np, c / pw, c % pw
+    // for each of its 7 elements of every 16-plane chunk: ~170 integer divisions per thread, most of the kernel's 67 us)
     const int pc = t & 127, par = t >> 7;
     const bool fill = pc < np;
     const int pci = fill ? (cy0 + pc / pw) * w2 + cx0 + pc % pw : 0;
+    constexpr float kLog2e = 1.44269504088896341f;
     const float pm = stats[(size_t)b * 2 * hw + pci], prs = 1.0f / stats[(size_t)b * 2 * hw + hw + pci];
     // (threads past the image edge take the taps of the nearest inside pixel of THIS tile: their patch-local
     // indices must stay inside the LDS patch; their results are never stored)
     const Bilin q = bilin_x2(min(y, H - 1), min(x, W - 1), h2, w2);
-    // patch-local indices of the four taps
-    const int l00 = (q.i00 / w2 - cy0) * pw + (q.i00 % w2 - cx0), l01 = (q.i01 / w2 - cy0) * pw + (q.i01 % w2 - cx0);
-    const int l10 = (q.i10 / w2 - cy0) * pw + (q.i10 % w2 - cx0), l11 = (q.i11 / w2 - cy0) * pw + (q.i11 % w2 - cx0);
-    const float* l = logits + (size_t)b * D * hw;
+    // patch-local rows of the four taps
+    const float* t00 = s_p + ((q.i00 / w2 - cy0) * pw + (q.i00 % w2 - cx0)) * kUpRow;
+    const float* t01 = s_p + ((q.i01 / w2 - cy0) * pw + (q.i01 % w2 - cx0)) * kUpRow;
+    const float* t10 = s_p + ((q.i10 / w2 - cy0) * pw + (q.i10 % w2 - cx0)) * kUpRow;
+    const float* t11 = s_p + ((q.i11 / w2 - cy0) * pw + (q.i11 % w2 - cx0)) * kUpRow;
+    const float* l = logits + (size_t)b * D * hw + pci;
     float best = -1.0f;
     int bi = 0;
     for (int d0 = 0; d0 < D; d0 += kUpPlanes) {
         __syncthreads();  // (the previous chunk's taps are read)
         const int nd = min(kUpPlanes, D - d0);
         if (fill) {
-#pragma unroll 8
-            for (int dd = par; dd < nd; dd += 2) s_p[dd][pc] = expf(l[(size_t)(d0 + dd) * hw + pci] - pm) * prs;
+#pragma unroll
+            for (int k = 0; k < kUpPlanes / 8; ++k) {
+                const int dd = 4 * (2 * k + par);          // planes dd .. dd + 3 of the chunk
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = dd + e < nd ? __builtin_amdgcn_exp2f((l[(size_t)(d0 + dd + e) * hw] - pm) * kLog2e) * prs : 0.0f;
+                *(float4*)(s_p + pc * kUpRow + dd) = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
         __syncthreads();
-        for (int dd = 0; dd < nd; ++dd) {
-            const float v = q.w00 * s_p[dd][l00] + q.w01 * s_p[dd][l01] + q.w10 * s_p[dd][l10] + q.w11 * s_p[dd][l11];
-            if (v > best) { best = v; bi = d0 + dd; }
+        for (int dd = 0; dd < nd; dd += 4) {           // (planes past nd hold zeros: never a new maximum)
+            const float4 a = *(const float4*)(t00 + dd), bq = *(const float4*)(t01 + dd);
+            const float4 c = *(const float4*)(t10 + dd), e = *(const float4*)(t11 + dd);
+            const float v0 = q.w00 * a.x + q.w01 * bq.x + q.w10 * c.x + q.w11 * e.x;
+            const float v1 = q.w00 * a.y + q.w01 * bq.y + q.w10 * c.y + q.w11 * e.y;
+            const float v2 = q.w00 * a.z + q.w01 * bq.z + q.w10 * c.z + q.w11 * e.z;
+            const float v3 = q.w00 * a.w + q.w01 * bq.w + q.w10 * c.w + q.w11 * e.w;
+            if (v0 > best) { best = v0; bi = d0 + dd; }
+            if (v1 > best) { best = v1; bi = d0 + dd + 1; }
+            if (v2 > best) { best = v2; bi = d0 + dd + 2; }
+            if (v3 > best) { best = v3; bi = d0 + dd + 3; }
         }
     }
     if (in) {
@@ -275,8 +306,12 @@ FS_API int fs_depth_tail_forward(int32_t B, int32_t D, int32_t h2, int32_t w2, c
     hipLaunchKernelGGL(depth_expect_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, B, D, h2 * w2, logits,
                        candidates, log_planes, stats, coarse, depth);
     if (depth_map)
-        hipLaunchKernelGGL(depth_upsample_kernel, dim3((2 * w2 + kUpW - 1) / kUpW, (2 * h2 + kUpH - 1) / kUpH, B), dim3(256),
-                           0, st, B, D, h2, w2, logits, stats, coarse, log_planes, depth_map, depth_weights, argmax);
+    {
+        const int tiles_x = (2 * w2 + kUpW - 1) / kUpW, tiles_y = (2 * h2 + kUpH - 1) / kUpH;
+        const int rows_per_xcd = (tiles_y * B + 7) / 8;
+        hipLaunchKernelGGL(depth_upsample_kernel, dim3((unsigned)(8 * rows_per_xcd * tiles_x)), dim3(256), 0, st, B, D, h2, w2,
+                           logits, stats, coarse, log_planes, depth_map, depth_weights, argmax);
+    }
     FS_CHECK_LAUNCH("depth_tail_forward");
     return FS_OK;
 }
