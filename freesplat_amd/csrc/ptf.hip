@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void ptf_write_state_kernel(
     } else if (row < n_keep + n_fuse) {                                     // fused entries          :493-506
         const int t = row - n_keep;
         const long long m = fuse_idx[t], p = fuse_pix[t];
-        oG[c] = ((const float4*)(fused + (size_t)t * 64))[c];
+        if (fused) oG[c] = ((const float4*)(fused + (size_t)t * 64))[c];      // (NULL: the GRU kernel wrote the row itself)
         const float w0 = s.R[m], w1 = rho_i[p], ws = w0 + w1;
         if (c < 4) {
             const float4 a = ((const float4*)(s.E + m * 16))[c], b = ((const float4*)E_i)[c];
@@ -622,9 +622,9 @@ FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int3
     if (rc != FS_OK) return rc;
     const int nf_max = M_max < P ? M_max : P;
     ScopedStage prof_(kStPtf, st);
-    (void)cat;  // (the GRU gathers and encodes its input rows itself: no [n,176] intermediate)
+    (void)cat; (void)fused;  // (the GRU gathers and encodes its input rows itself and writes its rows into the out state)
     rc = launch_ptf_gru_gather(nf_max, counts, (const long long*)fuse, (const long long*)fpix, G, R, O, g_i, rho_i, om_i,
-                               gru_tables, fused, st);
+                               gru_tables, oG, true, st);
     if (rc != FS_OK) return rc;
     PtfState si{const_cast<float*>(G), const_cast<float*>(X), const_cast<float*>(R), const_cast<float*>(O),
                 const_cast<float*>(E), const_cast<float*>(D)};
@@ -632,7 +632,7 @@ FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int3
     const long long n_out_max = (long long)M_max + P;
     hipLaunchKernelGGL(ptf_write_state_kernel, dim3((unsigned)((n_out_max + 15) / 16)), dim3(256), 0, st, 0, 0, 0,
                        (const int32_t*)counts, (const long long*)keep, (const long long*)fuse, (const long long*)fpix,
-                       (const long long*)app, si, g_i, x_i, rho_i, om_i, d_i, E_i, fused, so);
+                       (const long long*)app, si, g_i, x_i, rho_i, om_i, d_i, E_i, (const float*)nullptr, so);
     FS_CHECK_LAUNCH("ptf_write_state");
     return FS_OK;
 }

@@ -82,8 +82,12 @@ struct GruGather {
 template <bool GATHER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ptf_gru_kernel(int n, const int32_t* __restrict__ counts,
                                                       const float* __restrict__ cat, GruGather ga,
-                                                      const float* __restrict__ tab, float* __restrict__ fused)
+                                                      const float* __restrict__ tab, float* __restrict__ fused,
+                                                      int out_after_keep)
 {
+    // out_after_keep: `fused` is the step's OUT state G and pair t goes to row counts[0] + t (behind the kept rows), where
+    // fs_ptf_write_state would have copied it from a scratch array: 52 MB less traffic per 10^5 pairs
+    const size_t out_row0 = (out_after_keep && counts) ? (size_t)counts[0] : 0;
     if (counts) n = counts[1];  // (device-resident pair count: fs_ptf_fold_step)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = blockIdx.x * 4 + wave;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // ---- gates: out = (1 - z) * hid + z * tanh(q), lane holds 32 units of its pair ----
     if (live) {
-        float* o = fused + (size_t)t * 64;
+        float* o = fused + (out_row0 + (size_t)t) * 64;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -228,20 +232,20 @@ int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const flo
     if (n_max <= 0) return FS_OK;
     const int groups = (n_max + 31) / 32;
     hipLaunchKernelGGL(ptf_gru_kernel<false>, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, cat, GruGather{}, tables,
-                       fused);
+                       fused, 0);
     FS_CHECK_LAUNCH("ptf_gru_forward");
     return FS_OK;
 }
 
 int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fuse_idx, const long long* fuse_pix,
                           const float* G, const float* R, const float* O, const float* g_i, const float* rho_i,
-                          const float* om_i, const float* tables, float* fused, hipStream_t st)
+                          const float* om_i, const float* tables, float* fused, bool out_after_keep, hipStream_t st)
 {
     if (n_max <= 0) return FS_OK;
     const int groups = (n_max + 31) / 32;
     const GruGather ga{fuse_idx, fuse_pix, G, R, O, g_i, rho_i, om_i};
     hipLaunchKernelGGL(ptf_gru_kernel<true>, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, (const float*)nullptr, ga,
-                       tables, fused);
+                       tables, fused, out_after_keep ? 1 : 0);
     FS_CHECK_LAUNCH("ptf_gru_gather");
     return FS_OK;
 }
