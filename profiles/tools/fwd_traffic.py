@@ -103,6 +103,11 @@ def summarize(tag):
             "kernels": {k: {"bytes_per_unit": (v["read"] + v["write"]) / n, "launches_per_unit": v["launches"] / n,
                             "bytes_per_launch": (v["read"] + v["write"]) / max(v["launches"], 1)} for k, v in sorted(per.items())}}
     path = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
+    if os.path.exists(path):
+        # a run over SOME workloads must not drop the others from the tracked file (bench.py reads its traffic rows from it:
+        # a partial rewrite on the GPU box once left the cost-volume backward rows of a bench line empty)
+        old = json.load(open(path)).get("workloads", {})
+        out["workloads"] = {**old, **out["workloads"]}
     json.dump(out, open(path, "w"), indent=1)
     for k, v in out["workloads"].items():
         print(f"{k:16s} {v['hbm_bytes_per_unit'] / 1e6:9.1f} MB per {v['unit']}  (rd {v['read_bytes_per_unit'] / 1e6:.1f}, wr {v['write_bytes_per_unit'] / 1e6:.1f})")
