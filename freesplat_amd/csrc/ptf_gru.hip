@@ -70,6 +70,12 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 
 #define FS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// The six bias vectors (192 table rows, one per accumulator register and block) initialise the accumulators at the six layer
+// starts: T[r * 64] = row r of the tables for this lane.  (Staging them in LDS once per workgroup -- 32 ds_reads instead of 32 L2
+// round trips in front of a layer's first MFMA -- measured no different: profiles/r4_gru_bias_lds_ab.txt.)
+#define FS_BIAS_SETUP(TAB) const float* T = (TAB) + lane;
+#define FS_BIAS(r) T[(kBias + (r)) * 64]
+
 // GATHER: the input row [hid | he | x | xe] of pair t is not read from a materialised `cat` array but assembled here:
 // hid = G[fuse_idx[t]], x = g_i[fuse_pix[t]] (the half of the lanes that owns them loads them), he / xe = the positional
 // encodings of the densities and weights (encoder_freesplat.py:485-486) -- 24 sin/cos per lane, every lane busy, instead
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int p = lane & 31, hf = lane >> 5;
     const int t = grp * 32 + p;
     const bool live = t < n;
-    const float* T = tab + lane;  // T[r * 64] = row r of the tables for this lane (biases)
+    FS_BIAS_SETUP(tab)
     FS_RING_SETUP(tab, kFwdChunks)
     // sources of this pair: `row` = a materialised row, or (GATHER) the state latent / the view latent
     const float* row = GATHER ? nullptr : cat + (size_t)(live ? t : 0) * 176;
@@ -134,8 +140,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x16 r0, r1, z0, z1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        r0[q] = T[(kBias + 0 * 32 + q) * 64]; r1[q] = T[(kBias + 0 * 32 + 16 + q) * 64];
-        z0[q] = T[(kBias + 1 * 32 + q) * 64]; z1[q] = T[(kBias + 1 * 32 + 16 + q) * 64];
+        r0[q] = FS_BIAS(0 * 32 + q); r1[q] = FS_BIAS(0 * 32 + 16 + q);
+        z0[q] = FS_BIAS(1 * 32 + q); z1[q] = FS_BIAS(1 * 32 + 16 + q);
     }
     // ---- layer 1 of r and z: 88 k-steps, one shared B operand ----
 #pragma unroll
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x16 R0, R1, Z0, Z1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        R0[q] = T[(kBias + 2 * 32 + q) * 64]; R1[q] = T[(kBias + 2 * 32 + 16 + q) * 64];
-        Z0[q] = T[(kBias + 3 * 32 + q) * 64]; Z1[q] = T[(kBias + 3 * 32 + 16 + q) * 64];
+        R0[q] = FS_BIAS(2 * 32 + q); R1[q] = FS_BIAS(2 * 32 + 16 + q);
+        Z0[q] = FS_BIAS(3 * 32 + q); Z1[q] = FS_BIAS(3 * 32 + 16 + q);
     }
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x16 n0, n1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        n0[q] = T[(kBias + 4 * 32 + q) * 64]; n1[q] = T[(kBias + 4 * 32 + 16 + q) * 64];
+        n0[q] = FS_BIAS(4 * 32 + q); n1[q] = FS_BIAS(4 * 32 + 16 + q);
     }
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x16 N0, N1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        N0[q] = T[(kBias + 5 * 32 + q) * 64]; N1[q] = T[(kBias + 5 * 32 + 16 + q) * 64];
+        N0[q] = FS_BIAS(5 * 32 + q); N1[q] = FS_BIAS(5 * 32 + 16 + q);
     }
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256) void ptf_gru_bwd_kernel(int n, const float* __
     const int t = grp * 32 + p;
     const bool live = t < n;             // (a wavefront beyond n stays for the barriers, computes on row 0, stores nothing)
     const size_t tr = (size_t)(live ? t : 0);
-    const float* T = tab + lane;         // biases
+    FS_BIAS_SETUP(tab)
     FS_RING_SETUP(stream, kStreamChunks)
     const float* row = cat + tr * 176;
     float* sd = side + tr * kSide;       // (dead pairs compute on row 0 and store nothing)
@@ -314,8 +320,8 @@ __global__ __launch_bounds__(256) void ptf_gru_bwd_kernel(int n, const float* __
         f32x16 r0, r1, z0, z1;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            r0[q] = T[(kBias + 0 * 32 + q) * 64]; r1[q] = T[(kBias + 0 * 32 + 16 + q) * 64];
-            z0[q] = T[(kBias + 1 * 32 + q) * 64]; z1[q] = T[(kBias + 1 * 32 + 16 + q) * 64];
+            r0[q] = FS_BIAS(0 * 32 + q); r1[q] = FS_BIAS(0 * 32 + 16 + q);
+            z0[q] = FS_BIAS(1 * 32 + q); z1[q] = FS_BIAS(1 * 32 + 16 + q);
         }
         {
             float xh[88];
@@ -347,8 +353,8 @@ __global__ __launch_bounds__(256) void ptf_gru_bwd_kernel(int n, const float* __
         f32x16 R0, R1, Z0, Z1;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            R0[q] = T[(kBias + 2 * 32 + q) * 64]; R1[q] = T[(kBias + 2 * 32 + 16 + q) * 64];
-            Z0[q] = T[(kBias + 3 * 32 + q) * 64]; Z1[q] = T[(kBias + 3 * 32 + 16 + q) * 64];
+            R0[q] = FS_BIAS(2 * 32 + q); R1[q] = FS_BIAS(2 * 32 + 16 + q);
+            Z0[q] = FS_BIAS(3 * 32 + q); Z1[q] = FS_BIAS(3 * 32 + 16 + q);
         }
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void ptf_gru_bwd_kernel(int n, const float* __
     {   // mlp_n layer 1
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            n0[q] = T[(kBias + 4 * 32 + q) * 64]; n1[q] = T[(kBias + 4 * 32 + 16 + q) * 64];
+            n0[q] = FS_BIAS(4 * 32 + q); n1[q] = FS_BIAS(4 * 32 + 16 + q);
         }
         f32x16 h0, h1;   // r * hid, stored for the weight gradient of mlp_n layer 1
 #pragma unroll
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void ptf_gru_bwd_kernel(int n, const float* __
         f32x16 N0, N1;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            N0[q] = T[(kBias + 5 * 32 + q) * 64]; N1[q] = T[(kBias + 5 * 32 + 16 + q) * 64];
+            N0[q] = FS_BIAS(5 * 32 + q); N1[q] = FS_BIAS(5 * 32 + 16 + q);
         }
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
