@@ -66,25 +66,82 @@ __device__ __forceinline__ bool fusion_mask(uint32_t zb, float d, float depth_th
     return fabsf(__uint_as_float(zb) - d) < fmaxf(d * 0.05f, depth_thres);
 }
 
-__global__ __launch_bounds__(256) void ptf_flags_kernel(int M, const int32_t* __restrict__ Mp, int P,
-                                                        const int32_t* __restrict__ pix_of,
-                                                        const uint32_t* __restrict__ zbits_of,
-                                                        const uint32_t* __restrict__ zbuf,
-                                                        const float* __restrict__ depth_i, float depth_thres,
-                                                        uint8_t* __restrict__ win, uint8_t* __restrict__ app)
+// Flags AND their per-block counts in one launch (rounds 1 - 3: ptf_flags_kernel, one thread per element, then
+// ptf_count_kernel re-reading the bytes): workgroup b < nbM decides `win` for the 1024 Gaussians [1024 b, +1024), workgroup
+// nbM + b decides `app` for 1024 pixels; a thread owns 4 consecutive elements (one 4-byte store of its flags).
+__global__ __launch_bounds__(256) void ptf_flags_count_kernel(int M, const int32_t* __restrict__ Mp, int P, int nbM,
+                                                              const int32_t* __restrict__ pix_of,
+                                                              const uint32_t* __restrict__ zbits_of,
+                                                              const uint32_t* __restrict__ zbuf,
+                                                              const float* __restrict__ depth_i, float depth_thres,
+                                                              uint8_t* __restrict__ win, uint8_t* __restrict__ app,
+                                                              uint32_t* __restrict__ block_counts)
 {
+    __shared__ uint32_t s_w[4];
     if (Mp) M = *Mp;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < M) {
-        const int pix = pix_of[e];
-        bool wflag = false;
-        if (pix >= 0) {
-            const uint32_t zb = zbuf[pix];
-            wflag = zb == zbits_of[e] && fusion_mask(zb, depth_i[pix], depth_thres);
+    const bool second = (int)blockIdx.x >= nbM;
+    const int n = second ? P : M;
+    const int blk = second ? blockIdx.x - nbM : blockIdx.x;
+    const int base = blk * kScanBlock + threadIdx.x * 4;
+    uint32_t v = 0;
+    if (base + 3 < n) {
+        // a full quad: the four elements' loads are issued together (a loop that may leave early serialises the dependent
+        // gathers pix_of -> zbuf / depth_i: 192 workgroups of latency instead of 768)
+        if (second) {
+            const uint4 zb = *(const uint4*)(zbuf + base);
+            const float4 dd = *(const float4*)(depth_i + base);
+            v = (fusion_mask(zb.x, dd.x, depth_thres) ? 0u : 1u) | (fusion_mask(zb.y, dd.y, depth_thres) ? 0u : 1u << 8) |
+                (fusion_mask(zb.z, dd.z, depth_thres) ? 0u : 1u << 16) | (fusion_mask(zb.w, dd.w, depth_thres) ? 0u : 1u << 24);
+        } else {
+            const int4 px = *(const int4*)(pix_of + base);
+            const uint4 zo = *(const uint4*)(zbits_of + base);
+            const int pix[4] = {px.x, px.y, px.z, px.w};
+            const uint32_t own[4] = {zo.x, zo.y, zo.z, zo.w};
+            uint32_t zb[4];
+            float dd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = pix[k] >= 0 ? pix[k] : 0;
+                zb[k] = zbuf[q];
+                dd[k] = depth_i[q];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v |= ((pix[k] >= 0 && zb[k] == own[k] && fusion_mask(zb[k], dd[k], depth_thres)) ? 1u : 0u) << (8 * k);
         }
-        win[e] = wflag ? 1 : 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = base + k;
+            if (e >= n) break;
+            bool on;
+            if (second) {
+                on = !fusion_mask(zbuf[e], depth_i[e], depth_thres);
+            } else {
+                const int pix = pix_of[e];
+                on = false;
+                if (pix >= 0) {
+                    const uint32_t zb = zbuf[pix];
+                    on = zb == zbits_of[e] && fusion_mask(zb, depth_i[pix], depth_thres);
+                }
+            }
+            v |= (on ? 1u : 0u) << (8 * k);
+        }
     }
-    if (e < P) app[e] = fusion_mask(zbuf[e], depth_i[e], depth_thres) ? 0 : 1;
+    uint8_t* f = second ? app : win;
+    if (base + 3 < n && ((((uintptr_t)(f + base)) & 3) == 0)) {
+        *(uint32_t*)(f + base) = v;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (base + k < n) f[base + k] = (uint8_t)((v >> (8 * k)) & 1u);
+    }
+    uint32_t c = __popc(v);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // ---- order-preserving compaction -----------------------------------------------------------------
@@ -100,27 +157,6 @@ __device__ __forceinline__ uint32_t load4(const uint8_t* __restrict__ f, int bas
             if (base + k < n) v |= (uint32_t)f[base + k] << (8 * k);
     }
     return v;
-}
-
-// blocks [0, nbM) count `win` over M, blocks [nbM, nbM+nbP) count `app` over P
-__global__ __launch_bounds__(256) void ptf_count_kernel(int M, const int32_t* __restrict__ Mp, int P, int nbM,
-                                                        const uint8_t* __restrict__ win,
-                                                        const uint8_t* __restrict__ app,
-                                                        uint32_t* __restrict__ block_counts)
-{
-    __shared__ uint32_t s_w[4];
-    if (Mp) M = *Mp;
-    const bool second = (int)blockIdx.x >= nbM;
-    const uint8_t* f = second ? app : win;
-    const int n = second ? P : M;
-    const int blk = second ? blockIdx.x - nbM : blockIdx.x;
-    const uint32_t v = load4(f, blk * kScanBlock + threadIdx.x * 4, n);
-    uint32_t c = __popc(v);
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // exclusive scan of the two block-count ranges (one workgroup); counts = {n_keep, n_fuse, n_append}
@@ -168,7 +204,7 @@ __global__ __launch_bounds__(256) void ptf_emit_kernel(int M, const int32_t* __r
                                                        long long* __restrict__ keep_idx,
                                                        long long* __restrict__ fuse_idx,
                                                        long long* __restrict__ fuse_pix,
-                                                       long long* __restrict__ append_pix)
+                                                       long long* __restrict__ append_pix, uint32_t* __restrict__ zbuf)
 {
     __shared__ uint32_t s_w[4];
     if (Mp) M = *Mp;
@@ -178,6 +214,13 @@ __global__ __launch_bounds__(256) void ptf_emit_kernel(int M, const int32_t* __r
     const int blk = second ? blockIdx.x - nbM : blockIdx.x;
     const int base = blk * kScanBlock + threadIdx.x * 4;
     const uint32_t v = load4(f, base, n);
+    if (second) {
+        // the z-buffer's last reader (the flags) is done: leave it cleared for the next fold step of this scratch, which
+        // then needs no fill launch of its own (fs_ptf_fold)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (base + k < n) zbuf[base + k] = 0xFFFFFFFFu;
+    }
     const uint32_t c = __popc(v);
     // exclusive scan of c over the 256 threads: wave inclusive scan, then 4 wave totals via LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -487,10 +530,12 @@ FS_API size_t fs_ptf_scratch_bytes(int32_t M, int32_t h, int32_t w)
 }
 
 // M: number of state rows, or (Mp != NULL) an upper bound of *Mp used for sizing grids and the scratch layout
+// zbuf_clean: the z-buffer (the first P words of the scratch) already holds 0xFFFFFFFF -- the previous step's emit kernel
+// leaves it so -- and the fill launch is skipped
 static int ptf_match_impl(int32_t M, const int32_t* Mp, int32_t h, int32_t w, const float* xyz, const float* w2c,
                           const float* kpix, const float* depth_i, float depth_thres, void* scratch,
                           int64_t* keep_idx, int64_t* fuse_idx, int64_t* fuse_pix, int64_t* append_pix,
-                          int32_t* counts, void* stream_)
+                          int32_t* counts, void* stream_, bool zbuf_clean = false)
 {
     if (M < 0 || h <= 0 || w <= 0 || !w2c || !kpix || !depth_i || !scratch || !append_pix || !counts)
         return FS_ERR_INVALID_ARG;
@@ -508,17 +553,15 @@ static int ptf_match_impl(int32_t M, const int32_t* Mp, int32_t h, int32_t w, co
     uint32_t* blocks = (uint32_t*)(s + off[5]);
     const int nbM = (M + kScanBlock - 1) / kScanBlock, nbP = (P + kScanBlock - 1) / kScanBlock;
     ScopedStage prof_(kStPtf, st);
-    hipLaunchKernelGGL(ptf_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, st, zbuf, P);
+    if (!zbuf_clean) hipLaunchKernelGGL(ptf_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, st, zbuf, P);
     if (M > 0)
         hipLaunchKernelGGL(ptf_project_kernel, dim3((M + 255) / 256), dim3(256), 0, st, M, Mp, h, w, xyz, w2c, kpix,
                            pix_of, zbits_of, zbuf);
-    const int E = M > P ? M : P;
-    hipLaunchKernelGGL(ptf_flags_kernel, dim3((E + 255) / 256), dim3(256), 0, st, M, Mp, P, pix_of, zbits_of, zbuf,
-                       depth_i, depth_thres, win, app);
-    hipLaunchKernelGGL(ptf_count_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, Mp, P, nbM, win, app, blocks);
+    hipLaunchKernelGGL(ptf_flags_count_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, Mp, P, nbM, pix_of, zbits_of, zbuf,
+                       depth_i, depth_thres, win, app, blocks);
     hipLaunchKernelGGL(ptf_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, M, Mp, nbM, nbP, blocks, counts);
     hipLaunchKernelGGL(ptf_emit_kernel, dim3(nbM + nbP), dim3(256), 0, st, M, Mp, P, nbM, win, app, pix_of, blocks,
-                       (long long*)keep_idx, (long long*)fuse_idx, (long long*)fuse_pix, (long long*)append_pix);
+                       (long long*)keep_idx, (long long*)fuse_idx, (long long*)fuse_pix, (long long*)append_pix, zbuf);
     FS_CHECK_LAUNCH("ptf_match");
     return FS_OK;
 }
@@ -600,12 +643,12 @@ FS_API size_t fs_ptf_fold_scratch_bytes(int32_t M_max, int32_t h, int32_t w)
     return fold_layout(M_max, h * w).total;
 }
 
-FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, const float* G, const float* X,
-                            const float* R, const float* O, const float* E, const float* D, const float* g_i,
-                            const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
-                            const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
-                            void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
-                            int32_t* counts, void* stream_)
+static int fold_step_impl(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, const float* G, const float* X,
+                          const float* R, const float* O, const float* E, const float* D, const float* g_i,
+                          const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
+                          const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
+                          void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
+                          int32_t* counts, void* stream_, bool zbuf_clean)
 {
     if (M_max <= 0 || h <= 0 || w <= 0 || !G || !X || !R || !O || !E || !D || !g_i || !x_i || !rho_i || !om_i || !d_i ||
         !E_i || !w2c || !kpix || !gru_tables || !scratch || !oG || !oX || !oR || !oO || !oE || !oD || !counts)
@@ -618,7 +661,7 @@ FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int3
               *app = (long long*)(s + L.app);
     float *cat = (float*)(s + L.cat), *fused = (float*)(s + L.fused);
     int rc = ptf_match_impl(M_max, M_dev, h, w, X, w2c, kpix, d_i, depth_thres, s + L.match, (int64_t*)keep,
-                            (int64_t*)fuse, (int64_t*)fpix, (int64_t*)app, counts, stream_);
+                            (int64_t*)fuse, (int64_t*)fpix, (int64_t*)app, counts, stream_, zbuf_clean);
     if (rc != FS_OK) return rc;
     const int nf_max = M_max < P ? M_max : P;
     ScopedStage prof_(kStPtf, st);
@@ -637,16 +680,28 @@ FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int3
     return FS_OK;
 }
 
+FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, const float* G, const float* X,
+                            const float* R, const float* O, const float* E, const float* D, const float* g_i,
+                            const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
+                            const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
+                            void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
+                            int32_t* counts, void* stream_)
+{
+    return fold_step_impl(M_max, M_dev, h, w, G, X, R, O, E, D, g_i, x_i, rho_i, om_i, d_i, E_i, w2c, kpix, depth_thres,
+                          gru_tables, scratch, oG, oX, oR, oO, oE, oD, counts, stream_, false);
+}
+
 // Camera constants of the fold in one launch: thread i scales the normalised intrinsics of view i to pixels
 // (encoder_freesplat.py:445-448, one multiply each: same bits as torch); all threads replicate view 0's extrinsics per
 // pixel (the initial per-Gaussian extrinsics, :441).  The world-to-camera matrices are NOT formed here: a pixel's
 // round-half-even decision can hinge on their last bit, so they come from the same torch inverse the reference uses.
 __global__ __launch_bounds__(256) void ptf_cameras_kernel(int V, int P, int h, int w, const float* __restrict__ Es,
                                                           const float* __restrict__ Kn, float* __restrict__ kpix,
-                                                          float* __restrict__ E0)
+                                                          float* __restrict__ E0, uint32_t* __restrict__ zbuf)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t < (long long)P * 4) ((float4*)E0)[t] = ((const float4*)Es)[t & 3];
+    if (zbuf && t < P) zbuf[t] = 0xFFFFFFFFu;      // (fs_ptf_fold: the first step's z-buffer, cleared here)
     if (t >= V) return;
     const float* K = Kn + 9 * t;
     kpix[4 * t] = K[0] * (float)w; kpix[4 * t + 1] = K[4] * (float)h;
@@ -667,7 +722,7 @@ FS_API int fs_ptf_cameras(int32_t V, int32_t h, int32_t w, const float* Es, cons
     const long long P = (long long)h * w;
     const long long nt = P * 4 > V ? P * 4 : V;
     hipLaunchKernelGGL(ptf_cameras_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, V, (int)P,
-                       h, w, Es, Kn, kpix, E0);
+                       h, w, Es, Kn, kpix, E0, (uint32_t*)nullptr);
     FS_CHECK_LAUNCH("ptf_cameras");
     return FS_OK;
 }
@@ -705,18 +760,20 @@ FS_API int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const 
     }
     {
         const long long nt = (long long)P * 4 > V ? (long long)P * 4 : V;
+        // (the z-buffer is the first P words of the scratch for every step's layout; cleared here for step 1, by each
+        //  step's emit kernel for the next)
         hipLaunchKernelGGL(ptf_cameras_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, V, (int)P, h, w, Es,
-                           Kn, kpix, E0);
+                           Kn, kpix, E0, (uint32_t*)scratch);
         FS_CHECK_LAUNCH("ptf_cameras");
     }
     const float* cur[6] = {lat, xs, rho, om, E0, dep};
     for (int i = 1; i < V; ++i) {
         float* const* out = (i & 1) ? bufA : bufB;
-        const int rc = fs_ptf_fold_step((int32_t)(i * P), i == 1 ? nullptr : counts + 4 * (i - 1) + 3, h, w, cur[0], cur[1],
+        const int rc = fold_step_impl((int32_t)(i * P), i == 1 ? nullptr : counts + 4 * (i - 1) + 3, h, w, cur[0], cur[1],
                                         cur[2], cur[3], cur[4], cur[5], lat + i * P * 64, xs + i * P * 3, rho + i * P,
                                         om + i * P, dep + i * P, Es + 16 * (size_t)i, w2c + 16 * (size_t)i,
                                         kpix + 4 * (size_t)i, depth_thres, gru_tables, scratch, out[0], out[1], out[2],
-                                        out[3], out[4], out[5], counts + 4 * i, stream_);
+                                        out[3], out[4], out[5], counts + 4 * i, stream_, true);
         if (rc != FS_OK) return rc;
         for (int k = 0; k < 6; ++k) cur[k] = out[k];
     }
