@@ -51,6 +51,26 @@ def test_hip_matches_reference_and_autograd(hip_device, name):
     assert e.flatten().kthvalue(int(e.numel() * 0.999)).values.item() <= 2e-4 * s and e.mean().item() <= 1e-5 * s
 
 
+def test_backward_gather_window_covers_every_tap():
+    """CPU check of the assumption behind fs_depth_tail_backward's gather (csrc/depth_tail.hip:depth_tail_bwd_kernel): a fine
+    pixel f of the x2 align_corners upsampling takes its taps from coarse rows floor(f (n - 1) / (2 n - 1)) and + 1, computed
+    in float32 exactly as bilin_x2 does; coarse pixel Y looks for its contributors among the fine rows 2 Y - 2 .. 2 Y + 3.
+    Every tap with a non-zero weight of every fine index must fall inside that window, for every size up to 1500 (968 x 1296
+    images have 484 x 648 logits) -- per axis, which is all the separable kernel needs."""
+    for n in list(range(1, 130)) + [192, 256, 324, 484, 648, 1023, 1500]:
+        f = np.arange(2 * n, dtype=np.float32)
+        r = np.float32(n - 1) / np.float32(2 * n - 1) if n > 1 else np.float32(0)
+        src = f * r
+        y0 = np.minimum(src.astype(np.int32), n - 1)
+        y1 = np.minimum(y0 + 1, n - 1)
+        fy = src - y0.astype(np.float32)
+        for taps, wts in ((y0, 1.0 - fy), (y1, fy)):
+            live = wts != 0
+            fi = np.arange(2 * n)[live]
+            Y = taps[live]
+            assert np.all(fi >= 2 * Y - 2) and np.all(fi <= 2 * Y + 3), n
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,D,h2,w2,log_planes,which", [
     (1, 7, 5, 9, True, "all"),            # D not a multiple of the four plane classes, a ragged 64-pixel workgroup
