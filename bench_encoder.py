@@ -189,6 +189,13 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
             q.grad = None
     n_tr = max(2, steps // 4)
     dt_train = timed(lambda: train_step(m.fuse_gaussians), n_tr, 2) if train else float("nan")
+    ms_tr_stage = float("nan")
+    if train:
+        # the library kernels of a training step, event-timed through the stage hooks (a second loop: events off above)
+        _lib.profile_collect(); _lib.profile_enable(True)
+        timed(lambda: train_step(m.fuse_gaussians), n_tr, 0)
+        _lib.profile_enable(False)
+        ms_tr_stage = _lib.profile_collect()["ptf"][0] / n_tr
     with torch.no_grad():
         m.fuse_gaussians(*a)            # (LAST_FOLD_COUNTS of the inference fold)
     from freesplat_amd import ptf as _ptf
@@ -233,6 +240,19 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
                  "config": {"workload": f"ptf_{V}_views_{h}x{w}", "views": V, "gaussians_in": M_in, "gaussians_out": M_out,
                             "fused_pairs_per_step": [c[1] for c in steps_counts[1:]]},
                  "train_fwd_bwd": {"hip_ms": dt_train * 1e3 if train else None,
+                                   "roofline": None if not train else {
+                                       "bound": "mfma", "kernel": "PTF training step: every library kernel of the fold and its "
+                                       "backward (match, GRU, state movement; ptf_gru_bwd_kernel, ptf_gru_dw_kernel, "
+                                       "ptf_gru_inputs*, ptf_write_state_bwd)",
+                                       "algorithmic_flops_per_step": 3 * 2 * 44928 * sum(c[1] for c in steps_counts[1:]),
+                                       "kernel_ms_per_step": ms_tr_stage,
+                                       "achieved": 3 * 2 * 44928 * sum(c[1] for c in steps_counts[1:]) / (ms_tr_stage * 1e-3) / 1e12,
+                                       "peak": 157.3, "unit": "TFLOP/s",
+                                       "frac": 3 * 2 * 44928 * sum(c[1] for c in steps_counts[1:]) / (ms_tr_stage * 1e-3) / 1e12 / 157.3,
+                                       "flops_note": "the GRU's 44 928 MACs per fused pair, priced once for the forward and twice for "
+                                                     "the backward (input and weight gradients); the step's HBM-bound kernels (state "
+                                                     "movement, index lists, 264 MB of per-pair factors per 10^5 pairs) are in the "
+                                                     "denominator -- per-kernel traffic: profiles/r4_ptf_hbm_traffic.json"},
 
                                    "what": "forward + backward of the fold w.r.t. latents, coords, densities, weights, "
                                            "depths and the GRU parameters; gradients checked against the oracle's "
