@@ -20,8 +20,12 @@ def show(k, v, ind=0):
     t = v.get("train_fwd_bwd")
     if isinstance(t, dict):
         line += " train_ms=" + str(t.get("ms", t.get("hip_ms")))
-        if "roofline" in t:
-            line += f" bwd_frac={t['roofline']['frac']:.4g} bwd_ms={t['roofline']['avg_launch_ms']:.4g}"
+        r = t.get("roofline")
+        if isinstance(r, dict):
+            if "avg_launch_ms" in r:
+                line += f" bwd_frac={r['frac']:.4g} bwd_ms={r['avg_launch_ms']:.4g}"
+            else:
+                line += f" step_frac={r['frac']:.4g} step_kernel_ms={r['kernel_ms_per_step']:.4g}"
     if "cpu_baseline" in v:
         line += f" cpu={v['cpu_baseline']['value']:.4g} ({v['cpu_baseline']['cores']} cores)"
     if "parity" in v:

@@ -253,3 +253,9 @@ def test_committed_bench_line_honours_the_contract():
     assert set(d["ptf"]) == {"fold_2_views", "fold_10_views", "fold_3_views_968x1296", "fold_30_views"}
     for name, v in d["ptf"].items():
         assert v["parity"]["same_count_and_order"] is True and v["roofline"]["bound"] == "hbm" and v["cpu_baseline"]["cores"] <= 16, name
+        tr = v["train_fwd_bwd"]
+        if tr["hip_ms"] is not None:       # the training step's own roofline block ("missing" item 6)
+            assert tr["roofline"]["bound"] == "mfma" and 0 < tr["roofline"]["frac"] < 1, name
+            assert tr["roofline"]["kernel_ms_per_step"] <= tr["hip_ms"], name
+    assert d["ptf"]["fold_2_views"]["ms_per_call"] <= 0.23 and d["ptf"]["fold_2_views"]["train_fwd_bwd"]["hip_ms"] <= 1.6   # item 7
+    assert set(d["encoder_tail"]) == {"depth_tail", "gaussian_head"}
