@@ -9,5 +9,5 @@ for tag, lib in variants * 2:
     if lib:
         env["FREESPLAT_LIB"] = os.path.join(os.getcwd(), lib)
     out = subprocess.run([sys.executable, "bench.py", "--sections", "raster", "--no-cpu-baseline", "--no-graph"] + mode, env=env, capture_output=True, text=True).stdout
-    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-2])   # the full line (the compact one follows it)
     print(tag, round(d["value"], 1), {k: round(v, 4) for k, v in d["kernel_ms_per_view"].items()}, flush=True)

@@ -259,3 +259,30 @@ def test_committed_bench_line_honours_the_contract():
             assert tr["roofline"]["kernel_ms_per_step"] <= tr["hip_ms"], name
     assert d["ptf"]["fold_2_views"]["ms_per_call"] <= 0.23 and d["ptf"]["fold_2_views"]["train_fwd_bwd"]["hip_ms"] <= 1.6   # item 7
     assert set(d["encoder_tail"]) == {"depth_tail", "gaussian_head"}
+
+
+def test_compact_headline_fits_the_driver_window():
+    """bench.py prints the full sectioned object first and, as the LAST line, a compact object the driver can parse (round 4's
+    single 28 KB line came back `parsed: null`): <= 4 KB with every contract key, `roofline`, `cpu_baseline`, `parity` and one
+    digest per section -- checked on the largest committed full line; digests are dropped, never the contract keys, when a
+    line would not fit."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    full = json.load(open(os.path.join(root, "profiles", "r4_bench.json")))
+    h = bench.headline(full)
+    line = json.dumps(h)
+    assert len(line) <= bench.HEADLINE_MAX_BYTES <= 8192
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "sections"):
+        assert k in h, k
+    assert h["config"]["workload"] == "c3_968x1296_1M" and abs(h["value"] - full["value"]) < 1e-3 * full["value"]
+    assert abs(h["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4 and h["cpu_baseline"]["kind"] == "port"
+    assert {"train", "c2", "cost_volume.fvt10_96x128_K8", "ptf.fold_30_views", "encoder_tail.gaussian_head"} <= set(h["sections"])
+    # a pathological full line (hundreds of sections) still yields a line inside the window, contract keys intact
+    fat = dict(full, ptf={f"fold_{i}": full["ptf"]["fold_2_views"] for i in range(300)})
+    h2 = bench.headline(fat)
+    assert len(json.dumps(h2)) <= bench.HEADLINE_MAX_BYTES and h2["sections_truncated"] and "roofline" in h2 and "cpu_baseline" in h2

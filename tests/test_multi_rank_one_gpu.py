@@ -47,8 +47,10 @@ def test_bench_two_ranks_runs_the_sharded_branch(hip_device, mode):
     (fwd) / reduce-scatter gradient exchange (train), max-over-ranks timing, one JSON line from rank 0."""
     out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--views", "3",
                      "--workload", "c1_256x256_plumbing", "--mode", mode])
-    line = [l for l in out.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    d, compact = json.loads(lines[-2]), json.loads(lines[-1])      # the full line, then the compact one the driver parses
+    assert len(lines[-1]) <= 4096 and compact["value"] == pytest.approx(d["value"], rel=1e-4) and compact["n_gpus"] == 2
+    assert "roofline" in compact and set(compact["multi_gpu"]) == set(d["multi_gpu"]["per_rank"][0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     want = "reduce_scatter(gaussian grads)" if mode == "train" else "all_gather(color)"
     assert d["config"]["parallelism"] == f"view-sharded x2 + {want}", d["config"]
@@ -62,3 +64,17 @@ def test_bench_two_ranks_runs_the_sharded_branch(hip_device, mode):
     else:   # training: the gradient exchange alone, per rank (it runs on the render stream: all of it is exposed)
         per = d["multi_gpu"]["per_rank"]
         assert len(per) == 2 and all(0 < r["grad_exchange_ms"] < r["step_ms"] for r in per), per
+
+
+def test_bench_gpus_2_launches_itself(hip_device):
+    """`python bench.py --gpus 2` with no launcher environment (the driver's command shape) re-launches itself under
+    torch.distributed.run with two ranks: same two lines from rank 0, exit status 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FS_DIST_BACKEND="gloo", FS_SHARE_GPU="1", OMP_NUM_THREADS="8")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--views", "2",
+                        "--workload", "c1_256x256_plumbing"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    compact = json.loads(lines[-1])
+    assert compact["n_gpus"] == 2 and compact["value"] > 0 and compact["config"]["parallelism"].startswith("view-sharded x2")
+    assert len(lines[-1]) <= 4096 and json.loads(lines[-2])["n_gpus"] == 2

@@ -53,7 +53,7 @@ def test_bench_single_rank_takes_the_rccl_branch(hip_device, mode, extra):
     out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--views", "3",
                      "--workload", "c1_256x256_plumbing", "--mode", mode, "--sections", "raster", "--single-rank-collectives",
                      "--no-cpu-baseline", "--min-time", "0"] + extra)
-    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-2])      # (the full line; the compact one follows it)
     assert d["n_gpus"] == 1 and d["value"] > 0
     want = "reduce_scatter(gaussian grads)" if mode == "train" else ("all_gather(color,depth)[uint8]" if extra else "all_gather(color)")
     assert d["config"]["parallelism"] == f"view-sharded x1 + {want}", d["config"]
