@@ -208,7 +208,11 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
         k, f, n_app, m_out = steps_counts[i]
         alg += M * 12 + P * 4 + (k + 2 * f + n_app) * REC + (k + f + n_app) * REC
         M = m_out
-    kern_ms = ms / steps   # every launch of the library's ptf stage (event-bracketed), per fold call
+    # every launch of the library's ptf stage (event-bracketed), per fold call.  The event pairs themselves cost time inside the
+    # bracketed spans (a 30-view fold has 58 of them): the roofline's denominator is never more than the un-instrumented wall
+    # time of the call (fold_30_views reported kernel_ms_per_fold > ms_per_call)
+    kern_ms_events = ms / steps
+    kern_ms = min(kern_ms_events, dt * 1e3)
     extra = {}
     if cpu:
         cores = min(16, os.cpu_count() or 1)     # (the fold is many small operations: on all 256 host threads their
@@ -260,7 +264,8 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
                  "roofline": {"bound": "hbm", "kernel": "ptf fold (match + gru_inputs + gru + write_state, all steps)",
                               "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                               "frac": alg / (kern_ms * 1e-3) / 8e12, "algorithmic_bytes_per_fold": alg,
-                              "kernel_ms_per_fold": kern_ms, "launches": cnt // max(steps, 1),
+                              "kernel_ms_per_fold": kern_ms, "kernel_ms_per_fold_event_timed": kern_ms_events,
+                              "launches": cnt // max(steps, 1),
                               "traffic": _traffic(f"ptf_{V}_views")[0], "traffic_source": _traffic(f"ptf_{V}_views")[1]}}, **extra)
 
 

@@ -3,8 +3,8 @@
 Mirrors /root/reference/src/model/encoder/encoder_freesplat.py:431-522 (same signature, same four
 outputs in the same ORDER) together with the modules it needs: `GRU`
 (src/model/encoder/modules/networks.py:188-214, parameter names mlp_{z,r,n}.{0,2}.{weight,bias} and
-construction order kept so checkpoints and seeded inits carry over) and `positional_encoding`
-(encoder_freesplat.py:62-77).
+construction order kept so checkpoints and seeded inits carry over); the positional encodings
+(encoder_freesplat.py:62-77) are computed inside the kernels (fs_ptf_gru_inputs).
 
 The fold is HIP in both modes (b = 1, the only shape the reference's indexing supports):
   * forward (inference AND training): per view fs_ptf_fold_step = match (projection of the M global Gaussians,
@@ -31,36 +31,55 @@ from torch import Tensor, nn
 from . import _lib
 
 
-def positional_encoding(positions: Tensor, freqs: int, ori: bool = False) -> Tensor:
-    bands = (2 ** torch.arange(freqs).float()).to(positions.device)
-    ori_c = positions.shape[-1]
-    pts = (positions[..., None] * bands).reshape(positions.shape[:-1] + (freqs * positions.shape[-1],))
-    if ori:
-        return torch.cat([positions, torch.sin(pts), torch.cos(pts)], dim=-1).reshape(
-            pts.shape[:-1] + (pts.shape[-1] * 2 + ori_c,))
-    return torch.stack([torch.sin(pts), torch.cos(pts)], dim=-1).reshape(pts.shape[:-1] + (pts.shape[-1] * 2,))
+class _GruRows(torch.autograd.Function):
+    """The GRU on materialised rows [hid(64) | he(24) | x(64) | xe(24)]: fs_ptf_gru_forward, and for the backward
+    fs_ptf_gru_backward + fs_ptf_gru_weight_grads (gru_backward below).  What GRU.forward runs when the module is called on
+    its own; the fold uses the gathering variants of the same kernels."""
+
+    @staticmethod
+    def forward(ctx, cat, gru, *params):
+        n = cat.shape[0]
+        tab = gru_tables(gru)
+        out = torch.empty(n, 64, device=cat.device)
+        if n:
+            _lib.check(_lib.lib().fs_ptf_gru_forward(n, _lib.ptr(cat), _lib.ptr(tab), _lib.ptr(out), _lib.current_stream()),
+                       "fs_ptf_gru_forward")
+        ctx.gru = gru
+        ctx.save_for_backward(cat)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (cat,) = ctx.saved_tensors
+        gru = ctx.gru
+        dcat, grads = gru_backward(_gru_params(gru), gru_tables(gru), gru_operand_stream(gru), cat, g.float().contiguous())
+        return (dcat, None) + tuple(grads)
 
 
 class GRU(nn.Module):
+    """networks.py:188-214: same constructor, parameter names and call signature.  `forward` runs on the HIP kernels (rows
+    through fs_ptf_gru_forward / fs_ptf_gru_backward on the fp32 matrix cores); there is no CPU path (the
+    reference-pinned restatement the tests compare against lives with the test infrastructure, not in this package)."""
+
     def __init__(self, input_channel=64, hidden_channel=64, weights_dim=24):
         super().__init__()
+        if (input_channel, hidden_channel, weights_dim) != (64, 64, 24):
+            raise ValueError("freesplat_amd GRU: the kernels are built for 64 / 64 / 24 channels (the reference's only use, "
+                             "encoder_freesplat.py:163)")
         mk = lambda d: nn.Sequential(nn.Linear(d, hidden_channel), nn.ReLU(), nn.Linear(hidden_channel, hidden_channel))
         self.mlp_z = mk(hidden_channel + input_channel + 2 * weights_dim)
         self.mlp_r = mk(hidden_channel + input_channel + 2 * weights_dim)
         self.mlp_n = mk(hidden_channel + input_channel + 1 * weights_dim)
 
     def forward(self, input_feat, hidden_feat, input_weights_emb, hidden_weights_emb):
-        if len(input_feat.size()) == 2 and input_feat.size(0) == 1:
-            input_feat = input_feat.unsqueeze(1)
+        if input_feat.device.type != "cuda":
+            raise RuntimeError(f"freesplat_amd GRU: tensors must live on a HIP device (got {input_feat.device}); no CPU path")
         if hidden_feat is None:
             hidden_feat = torch.zeros_like(input_feat)
-        x1 = torch.cat((input_feat, input_weights_emb), dim=-1)
-        h1 = torch.cat((hidden_feat, hidden_weights_emb), dim=-1)
-        cat = torch.cat((h1, x1), dim=-1)
-        r = torch.sigmoid(self.mlp_r(cat))
-        z = torch.sigmoid(self.mlp_z(cat))
-        q = torch.tanh(self.mlp_n(torch.cat((r * hidden_feat, x1), dim=-1)))
-        return (1 - z) * hidden_feat + z * q
+        lead = input_feat.shape[:-1]
+        rows = [t.reshape(-1, t.shape[-1]).float() for t in (hidden_feat, hidden_weights_emb, input_feat, input_weights_emb)]
+        cat = torch.cat(rows, dim=-1).contiguous()                 # [n, 176] = [hid | he | x | xe]
+        return _GruRows.apply(cat, self, *_gru_params(self)).reshape(lead + (64,))
 
 
 def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, w: int, depth_thres: float = 0.1):
@@ -363,18 +382,6 @@ def _gru_params(gru: "GRU") -> list:
             out.append(pr["weight"])
             out.append(pr["bias"])
     return out
-
-
-def _gru_from_cat(params: list, cat: Tensor) -> Tensor:
-    """The GRU (networks.py:201-214) on concatenated rows cat = [hid(64) | he(24) | x(64) | xe(24)] with explicit
-    parameters (so torch.autograd.grad can be asked for exactly these)."""
-    F = torch.nn.functional
-    Wr1, br1, Wr2, br2, Wz1, bz1, Wz2, bz2, Wn1, bn1, Wn2, bn2 = params
-    hid = cat[:, :64]
-    r = torch.sigmoid(F.linear(F.relu(F.linear(cat, Wr1, br1)), Wr2, br2))
-    z = torch.sigmoid(F.linear(F.relu(F.linear(cat, Wz1, bz1)), Wz2, bz2))
-    q = torch.tanh(F.linear(F.relu(F.linear(torch.cat((r * hid, cat[:, 88:]), dim=-1), Wn1, bn1)), Wn2, bn2))
-    return (1 - z) * hid + z * q
 
 
 class _PtfFold(torch.autograd.Function):

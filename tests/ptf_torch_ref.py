@@ -3,7 +3,8 @@ device ops on the HIP index lists (fs_ptf_match), differentiable through autogra
 (freesplat_amd.ptf.fuse_gaussians) runs the fold and its backward on the HIP kernels; this formulation only checks them."""
 import torch
 
-from freesplat_amd.ptf import match_view, positional_encoding, world_to_camera
+from freesplat_amd.ptf import match_view, world_to_camera
+from oracle.ptf_oracle import gru as oracle_gru, positional_encoding     # the reference-pinned restatements
 
 
 def fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
@@ -31,7 +32,9 @@ def fuse_gaussians_torch(self, gaussians, coords, densities, weight_emb, depths,
         if fuse.numel() > 0:
             xe = positional_encoding(torch.cat([R[:, fuse], weight_emb[:, i, fpix]], dim=-1), 6)
             he = positional_encoding(torch.cat([densities[:, i, fpix], O[:, fuse]], dim=-1), 6)
-            fused = self.gru(gaussians[0][:, i, fpix].unsqueeze(2), G[:, fuse].unsqueeze(2), xe, he).squeeze(2)
+            n_f = fuse.numel()      # the oracle's GRU (oracle/ptf_oracle.py:gru) on the module's parameters: autograd reaches them
+            fused = oracle_gru(dict(self.gru.named_parameters()), gaussians[0][0, i, fpix], G[0, fuse], xe.reshape(n_f, 24),
+                               he.reshape(n_f, 24))[None]
             w0 = R[:, fuse].repeat(1, 1, 1, 2)
             w1 = densities[:, i, fpix].repeat(1, 1, 1, 2)
             G = torch.cat([G[:, keep], fused], dim=1)

@@ -14,6 +14,21 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 pytestmark = pytest.mark.gpu
 
 
+_GRU_KEYS = [f"{m}.{l}.{t}" for m in ("mlp_r", "mlp_z", "mlp_n") for l in ("0", "2") for t in ("weight", "bias")]   # ptf._gru_params order
+
+
+def _oracle_pe(positions, freqs):
+    from oracle.ptf_oracle import positional_encoding      # the reference-pinned restatement (encoder_freesplat.py:62-77)
+    return positional_encoding(positions, freqs)
+
+
+def _oracle_gru_rows(params, cat):
+    """oracle/ptf_oracle.py:gru (networks.py:201-214, pinned by the reference's golden folds) on rows
+    cat = [hid(64) | he(24) | x(64) | xe(24)] with the parameters in ptf._gru_params order."""
+    from oracle.ptf_oracle import gru
+    return gru(dict(zip(_GRU_KEYS, params)), cat[:, 88:152], cat[:, :64], cat[:, 152:], cat[:, 64:88])
+
+
 def _load(name):
     z = np.load(os.path.join(HERE, "golden", name))
     g = {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
@@ -200,7 +215,7 @@ def test_gru_backward_kernel_vs_autograd(hip_device, n):
     dcat, grads = P.gru_backward(params, P.gru_tables(gru), P.gru_operand_stream(gru), cat, g)
     cat_ = cat.clone().requires_grad_(True)
     ps = [q.detach().clone().requires_grad_(True) for q in params]
-    ref = torch.autograd.grad(P._gru_from_cat(ps, cat_), [cat_] + ps, g)
+    ref = torch.autograd.grad(_oracle_gru_rows(ps, cat_), [cat_] + ps, g)
     rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-20))
     worst = {"dcat": rel(dcat, ref[0])}
     for k, (a, b) in enumerate(zip(grads, ref[1:])):
@@ -235,8 +250,8 @@ def test_gru_inputs_rows_and_their_backward(hip_device, n):
                                    _lib.current_stream()), "fs_ptf_gru_inputs")
 
     def rows(G, R, O, lat, rho, om):
-        he = P.positional_encoding(torch.stack([rho[fpix], O[fuse]], -1).double(), 6)
-        xe = P.positional_encoding(torch.stack([R[fuse], om[fpix]], -1).double(), 6)
+        he = _oracle_pe(torch.stack([rho[fpix], O[fuse]], -1).double(), 6)
+        xe = _oracle_pe(torch.stack([R[fuse], om[fpix]], -1).double(), 6)
         return torch.cat([G[fuse].double(), he, lat[fpix].double(), xe], -1)
     ins = [t.detach().clone().requires_grad_(True) for t in (G, R, O, lat, rho, om)]
     ref = rows(*ins)
@@ -293,7 +308,7 @@ def test_gru_forward_kernel_on_materialised_rows(hip_device, n):
     _lib.check(_lib.lib().fs_ptf_gru_forward(n, _lib.ptr(cat), _lib.ptr(tab), _lib.ptr(fused), _lib.current_stream()),
                "fs_ptf_gru_forward")
     with torch.no_grad():
-        ref = P._gru_from_cat(P._gru_params(gru), cat)
+        ref = _oracle_gru_rows(P._gru_params(gru), cat)
     assert (fused - ref).abs().max().item() < 1e-5
 
 
@@ -344,3 +359,28 @@ def test_fold_backward_matches_reference_gradients(hip_device):
     for k, p_ in m.gru.named_parameters():
         want = gg["d_gru__" + k.replace(".", "__")]
         assert rel(p_.grad, want) < 2e-3, (k, rel(p_.grad, want))
+
+
+def test_gru_module_forward_and_backward_run_on_the_kernels(hip_device):
+    """GRU.forward (networks.py:201-214's call signature, leading dims kept) runs fs_ptf_gru_forward and, under autograd,
+    fs_ptf_gru_backward + fs_ptf_gru_weight_grads: output and every gradient against the oracle's GRU; a CPU call raises."""
+    from freesplat_amd import ptf as P
+    torch.manual_seed(5)
+    gru = P.GRU().to(hip_device)
+    n = 777
+    x, hid = (torch.randn(1, n, 1, 64, device=hip_device, requires_grad=True) for _ in range(2))
+    xe, he = (torch.sin(3 * torch.randn(1, n, 1, 24, device=hip_device)).requires_grad_(True) for _ in range(2))
+    out = gru(x, hid, xe, he)
+    assert out.shape == (1, n, 1, 64)
+    g = torch.randn_like(out)
+    got = torch.autograd.grad(out, [x, hid, xe, he] + list(gru.parameters()), g)
+    ins = [t.detach().clone().reshape(n, -1).requires_grad_(True) for t in (x, hid, xe, he)]
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in gru.named_parameters()}
+    from oracle.ptf_oracle import gru as ogru
+    ref_out = ogru(ps, *ins)
+    assert (out.reshape(n, 64) - ref_out).abs().max().item() < 1e-5
+    ref = torch.autograd.grad(ref_out, ins + [ps[k] for k, _ in gru.named_parameters()], g.reshape(n, 64))
+    for a, b in zip(got, ref):
+        assert (a.reshape(b.shape) - b).abs().max().item() <= 1e-4 * (b.abs().max().item() + 1e-20)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        P.GRU()(x.cpu(), hid.cpu(), xe.cpu(), he.cpu())
