@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
                     help="top-level measurement. fwd: forward rendering (the metric); train: fwd + bwd (+ grad exchange)")
     ap.add_argument("--sections", default="all",
-                    help="N=1 only: comma list of extra sub-objects (train,c2,c5,cost_volume,ptf,encoder_tail), 'all', or 'raster' for none")
+                    help="N=1 only: comma list of extra sub-objects (train,c2,closeup,c5,cost_volume,ptf,encoder_tail,c3_step), 'all', or 'raster' for none")
     ap.add_argument("--grad-exchange", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
                     help="N>1 train mode: how the per-Gaussian gradients of the view shards are summed")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image all-gather")
@@ -127,7 +127,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
     from freesplat_amd.rasterizer import _state as _rstate
     _rstate(dev).last_instances = 0      # (capacity history of a previous workload in this process)
     _rstate(dev).retry_cap = 0
-    scene = synthetic.make_scene(N)
+    scene = synthetic.workload_scene(workload)
     n_total_views = views * world
     cams_all = synthetic.target_cameras(n_total_views)
     mine = shard_range(n_total_views, rank, world)
@@ -181,6 +181,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                 gather.launch(payload)
         return color, depth
 
+    capacity_retries = 0
     for attempt in range(2):
         for _ in range(max(warmup, 1) if attempt else warmup):
             color, depth = step()
@@ -194,6 +195,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
             # updated by the check, warm up again with it (the timed region below still fails loudly on overflow)
             if attempt:
                 raise
+            capacity_retries += 1
     cx.barrier()
     profile = not args.no_profile
     dominant = "render_bwd" if train else "render"
@@ -356,6 +358,16 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                                                               (" + all_gather(color,depth)" if args.gather_depth else " + all_gather(color)")
                                                               + ("" if args.gather_dtype == "fp32" else f"[{args.gather_dtype}]") if gather else "")},
     }
+    # what the fixed per-tile key areas cost in memory at this workload's instance capacity (fs_raster_buffer_sizes), and how
+    # often the warm-up had to be repeated with a capacity taken from the overflow counters
+    from freesplat_amd import rasterizer as _Rz
+    cap_now = _Rz.default_capacity(N, _state(dev), H, W)
+    bsz = _Rz._buffer_sizes(N, H, W, cap_now)
+    out["raster_buffers"] = {"instance_capacity": int(cap_now), "geom_bytes_per_view": bsz[0], "binning_bytes_per_view": bsz[1],
+                             "image_bytes_per_view": bsz[2], "scratch_bytes_per_stream": bsz[3],
+                             "capacity_retries": capacity_retries,
+                             "note": "capacity_retries = warm-up passes repeated after an instance-capacity overflow (first contact "
+                                     "with a workload denser than 8 entries per Gaussian); the timed region never retries"}
     if multi is not None:
         out["multi_gpu"] = multi
     if graph_views_per_s is not None:
@@ -370,7 +382,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         if train:
             traffic, traffic_src = (committed_traffic("fs::render_bwd_kernel<" + ("true" if _R_FAST() else "false"))
                                     if workload.startswith("c3") else (None, None))
-        elif sh_fp16:
+        elif sh_fp16 or "closeup" in workload:
             traffic, traffic_src = None, None
         else:   # per launch of the fused sort + blend kernel (profiles/tools/fwd_traffic.py)
             traffic, traffic_src = traffic_lookup("raster_" + workload[:2], "fs::sort_blend_kernel")
@@ -395,7 +407,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         if iso[1] and iso[0] > 0:
             out["roofline"]["frac_isolated"] = alg / (iso[0] / iso[1] * 1e-3) / 8e12
         out["roofline"]["pipeline_frac_wall"] = alg * n_views_done / dt / 8e12
-        if not train and not sh_fp16:
+        if not train and not sh_fp16 and "closeup" not in workload:
             out["roofline"]["pipeline_traffic_per_view"] = traffic_lookup("raster_" + workload[:2])[0]
         ksum = sum(out["kernel_ms_per_view"].values())
         if ksum > 0:   # the whole pipeline of one view against the same algorithmic bytes
@@ -657,7 +669,7 @@ def main():
     out = bench_raster(cx, args.workload, args.mode, args.views, args.steps, args.warmup, cpu)
     sections = []
     if cx.world == 1 and args.sections != "raster":
-        sections = ["train", "c2", "c5", "cost_volume", "ptf", "encoder_tail"] if args.sections == "all" else args.sections.split(",")
+        sections = ["train", "c2", "closeup", "c5", "cost_volume", "ptf", "encoder_tail", "c3_step"] if args.sections == "all" else args.sections.split(",")
 
     def section(fn):
         """A secondary measurement must never take the headline line down with it."""
@@ -684,6 +696,16 @@ def main():
         out["train"] = section(lambda: bench_raster(cx, args.workload, "train", min(args.views, 8), max(3, args.steps // 2), 2, cpu))
     if "c2" in sections and not args.workload.startswith("c2"):
         out["c2"] = section(lambda: bench_raster(cx, "c2_640x480_300k", "fwd", args.views, args.steps, args.warmup, cpu))
+    if "closeup" in sections and args.mode == "fwd":
+        # the unfriendly config-3 workload (synthetic.WORKLOADS): every splat 2.5x its size, every tile list beyond the 2 048
+        # entries that sort in LDS -> the global-memory sort path of sort_blend_kernel
+        cu = section(lambda: bench_raster(cx, "c3_closeup_968x1296_1M", "fwd", min(args.views, 4), max(3, args.steps // 4), 1, cpu))
+        if "error" not in cu:
+            per_inst = lambda o: o["value"] * o["config"]["instances_per_view"]
+            cu["views_per_s_per_instance_vs_headline"] = per_inst(cu) / per_inst(out)
+            cu["scratch_bytes"] = cu["raster_buffers"]["scratch_bytes_per_stream"]
+            cu["capacity_retries"] = cu["raster_buffers"]["capacity_retries"]
+        out["c3_closeup"] = cu
     if "c5" in sections and args.mode == "fwd":
         # BASELINE config 5's storage option on the headline workload: SH coefficients held in fp16
         out["c3_fp16_sh"] = section(lambda: bench_raster(cx, args.workload, "fwd", args.views, args.steps, args.warmup, cpu, sh_fp16=True))
@@ -715,6 +737,10 @@ def main():
                 # compared at 96x128 in tests/test_configs_4_5.py)
                 "fold_30_views": section(lambda: be.bench_ptf(cx.dev, 2, 1, V=30, cpu=cpu, cpu_steps=9, train=False)),
             }
+    if "c3_step" in sections:
+        # BASELINE config 3 as written: ONE composed training step at 3 x 968x1296 (bench_c3_step.py)
+        import bench_c3_step as bc
+        out["c3_train_step_hotpath"] = section(lambda: bc.bench_c3_step(cx.dev, steps=3, warmup=2))
     if cx.rank == 0:
         emit(out)
     if cx.dist_on:

@@ -316,6 +316,7 @@ FS_API int fs_unproject_forward(int32_t V, int32_t h, int32_t w, const float* de
     if (V == 0) return FS_OK;
     if (!depths || !xyz) return FS_ERR_INVALID_ARG;
     const size_t n = (size_t)V * h * w;
+    ScopedStage prof_(kStEncoderTail, (hipStream_t)stream_);
     hipLaunchKernelGGL(unproject_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, V, h,
                        w, depths, extrinsics, k0_pix, xyz);
     FS_CHECK_LAUNCH("unproject_forward");
@@ -329,6 +330,7 @@ FS_API int fs_unproject_backward(int32_t V, int32_t h, int32_t w, const float* e
     if (V == 0) return FS_OK;
     if (!g_xyz || !g_depths) return FS_ERR_INVALID_ARG;
     const size_t n = (size_t)V * h * w;
+    ScopedStage prof_(kStEncoderTail, (hipStream_t)stream_);
     hipLaunchKernelGGL(unproject_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, V, h,
                        w, extrinsics, k0_pix, g_xyz, g_depths);
     FS_CHECK_LAUNCH("unproject_backward");
@@ -343,6 +345,7 @@ FS_API int fs_gaussian_head_forward(int64_t M, const float* raw, const float* de
     if (M < 0 || !multiplier || !sh_mask) return FS_ERR_INVALID_ARG;
     if (M == 0) return FS_OK;
     if (!raw || !depths || !extrinsics || !cov || !harmonics || !scales || !rotations) return FS_ERR_INVALID_ARG;
+    ScopedStage prof_(kStEncoderTail, (hipStream_t)stream_);
     hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
                        (long long)M, raw, depths, extrinsics, multiplier, (long long)mult_stride, sh_mask, scale_min,
                        scale_max, cov, harmonics, scales, rotations);
@@ -359,6 +362,7 @@ FS_API int fs_gaussian_head_backward(int64_t M, const float* raw, const float* d
     if (M < 0 || !multiplier || !sh_mask) return FS_ERR_INVALID_ARG;
     if (M == 0) return FS_OK;
     if (!raw || !depths || !extrinsics || !g_raw || !g_depths || !g_extrinsics) return FS_ERR_INVALID_ARG;
+    ScopedStage prof_(kStEncoderTail, (hipStream_t)stream_);
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
                        (long long)M, raw, depths, extrinsics, multiplier, (long long)mult_stride, sh_mask, scale_min,
                        scale_max, g_cov, g_harmonics, g_scales, g_rotations, g_raw, g_depths, g_extrinsics);

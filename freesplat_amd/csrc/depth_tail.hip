@@ -303,6 +303,7 @@ FS_API int fs_depth_tail_forward(int32_t B, int32_t D, int32_t h2, int32_t w2, c
         return FS_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream_;
     const long long n = (long long)B * h2 * w2;
+    ScopedStage prof_(kStEncoderTail, st);
     hipLaunchKernelGGL(depth_expect_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, B, D, h2 * w2, logits,
                        candidates, log_planes, stats, coarse, depth);
     if (depth_map)
@@ -329,6 +330,7 @@ FS_API int fs_depth_tail_backward(int32_t B, int32_t D, int32_t h2, int32_t w2, 
     (void)scratch_gE; (void)scratch_gprob;      // (ABI 1 - 3 scratch of the scatter form: unused since the gather form, may be NULL)
     hipStream_t st = (hipStream_t)stream_;
     const long long n = (long long)B * h2 * w2;
+    ScopedStage prof_(kStEncoderTail, st);
     hipLaunchKernelGGL(depth_tail_bwd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, B, D, h2, w2, logits,
                        candidates, log_planes, stats, coarse, depth, depth_map, argmax, g_coarse, g_depth, g_map, g_weights,
                        g_logits);

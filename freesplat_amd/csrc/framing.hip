@@ -147,6 +147,7 @@ FS_API int fs_frame_views(int32_t v, const float* extrinsics, const float* intri
     if (v == 0) return FS_OK;
     if (!extrinsics || !intrinsics || !near || !far || !view || !full || !campos || !tanfov || !scale)
         return FS_ERR_INVALID_ARG;
+    ScopedStage prof_(kStPreprocess, (hipStream_t)stream_, 0);   // (framing of a decoder call: counted with the projection stage, no launch units)
     hipLaunchKernelGGL(frame_views_kernel, dim3((v + 63) / 64), dim3(64), 0, (hipStream_t)stream_, v, extrinsics,
                        intrinsics, near, far, scale_invariant, view, full, campos, tanfov, scale);
     FS_CHECK_LAUNCH("frame_views");

@@ -32,7 +32,7 @@ void set_last_error(const char* what, hipError_t e);
 // ---- optional per-kernel event timing (fs_profile_*; off by default, zero cost when off) ------
 enum Stage {
     kStPreprocess = 0, kStTileScan, kStRender, kStRenderBwd, kStPreprocessBwd,
-    kStCostVolume, kStPtf, kNumStages
+    kStCostVolume, kStPtf, kStEncoderTail, kNumStages
 };
 struct ScopedStage {
     ScopedStage(Stage s, hipStream_t st, int units = 1);  // units: views covered by the launch (reported as launches)

@@ -45,7 +45,7 @@ ScopedStage::~ScopedStage()
     (void)hipEventRecord(g_recs[slot_].b, st_);
 }
 static const char* kStageNames[kNumStages] = {"preprocess", "tile_scan", "render",
-                                              "render_bwd", "preprocess_bwd", "cost_volume", "ptf"};
+                                              "render_bwd", "preprocess_bwd", "cost_volume", "ptf", "encoder_tail"};
 }  // namespace fs
 
 FS_API int fs_profile_enable(int stage_mask)

@@ -446,6 +446,7 @@ class DecoderSplattingCUDA(nn.Module):
         self.group = group
         self.single_rank_collectives = single_rank_collectives
         self._replicas_checked = None      # Gaussian count of the last scene whose replicas were compared
+        self._sharded_calls = 0            # sharded forward calls so far (the check is also repeated every N-th call)
 
     def _dist_group(self):
         if self.group is None or self.group is False:
@@ -457,14 +458,16 @@ class DecoderSplattingCUDA(nn.Module):
         return (g, dist) if (dist.get_world_size(g) > 1 or self.single_rank_collectives) else None
 
     def _check_replicas(self, group, dist, gaussians, extrinsics):
-        """All ranks of the group must hold the same scene: compare a cheap signature (Gaussian count; sum and sum of
-        squares of the means and of the extrinsics) through one MIN and one MAX all-reduce of 5 doubles.  The count must
+        """All ranks of the group must hold the same scene: compare a cheap signature (Gaussian count; sum of magnitudes and
+        sum of squares of the means and of the extrinsics) through one MIN and one MAX all-reduce of 5 doubles.  The count must
         be equal; the sums within 1e-6 relative -- replicated encoders agree to rounding, not to the bit (MIOpen algorithm
-        choice, float atomics in the encoder's backward kernels), while different scenes differ in the first digits."""
+        choice, float atomics in the encoder's backward kernels), while different scenes differ in the first digits.  Every
+        entry is a sum of NON-NEGATIVE terms: a signed sum that cancels towards zero (a centred scene) would turn legitimate
+        rounding differences into a relative error above any tolerance."""
         from .view_sharding import _stage
         m, e = gaussians.means.detach().double(), extrinsics.detach().double()
-        sig = torch.stack([torch.tensor(float(m.shape[-2]), dtype=torch.float64, device=m.device), m.sum(), (m * m).sum(), e.sum(),
-                           (e * e).sum()])
+        sig = torch.stack([torch.tensor(float(m.shape[-2]), dtype=torch.float64, device=m.device), m.abs().sum(), (m * m).sum(),
+                           e.abs().sum(), (e * e).sum()])
         lo, hi = _stage(sig.clone(), group), _stage(sig.clone(), group)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
@@ -484,12 +487,16 @@ class DecoderSplattingCUDA(nn.Module):
         bg = self.background_color
         sharded = self._dist_group()
         if sharded is not None:
-            # on the first sharded call, whenever the Gaussian count changes (a new scene), and always with
-            # FREESPLAT_CHECK_REPLICAS=1
+            # on the first sharded call, whenever the Gaussian count changes (a new scene), every
+            # FREESPLAT_CHECK_REPLICAS_EVERY-th call (default 64: scenes of EQUAL count -- fixed-size outputs without PTF --
+            # are re-validated too), and always with FREESPLAT_CHECK_REPLICAS=1
             n_now = int(gaussians.means.shape[-2])
-            if self._replicas_checked != n_now or os.environ.get("FREESPLAT_CHECK_REPLICAS") == "1":
+            every = max(1, int(os.environ.get("FREESPLAT_CHECK_REPLICAS_EVERY", "64")))
+            if (self._replicas_checked != n_now or self._sharded_calls % every == 0
+                    or os.environ.get("FREESPLAT_CHECK_REPLICAS") == "1"):
                 self._check_replicas(sharded[0], sharded[1], gaussians, extrinsics)
                 self._replicas_checked = n_now
+            self._sharded_calls += 1
             color, depth = self._forward_sharded(sharded[0], sharded[1], gaussians, extrinsics, intrinsics, near, far,
                                                  image_shape, with_depth=depth_mode is not None)
             if depth is None:

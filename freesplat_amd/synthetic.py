@@ -57,9 +57,10 @@ def wall_depth(u, v, rng, noise=0.02):
 
 
 def make_scene(n_gaussians: int, n_context: int = 3, seed: int = SEED, sh_degree: int = 2,
-               ctx_hw: tuple[int, int] = (384, 512)) -> dict:
+               ctx_hw: tuple[int, int] = (384, 512), splat_scale: float = 1.0) -> dict:
     """Returns CPU float32 tensors: means [N,3], covariances [N,3,3], harmonics [N,3,d_sh],
-    opacities [N], plus the context cameras."""
+    opacities [N], plus the context cameras.  `splat_scale`: every Gaussian's three axes multiplied by this factor (the same
+    random draws: splat_scale = 1 is bit-identical to the scene every earlier number was measured on) -- see WORKLOADS."""
     rng = np.random.default_rng(seed)
     K = intrinsics_normalized()
     c2ws = arc_cameras(n_context)
@@ -84,7 +85,7 @@ def make_scene(n_gaussians: int, n_context: int = 3, seed: int = SEED, sh_degree
     N = means.shape[0]
     fx_px, fy_px = FX_N * ctx_hw[1], FY_N * ctx_hw[0]
     mult = 0.1 * (1.0 / fx_px + 1.0 / fy_px)
-    scales = rng.uniform(0.5, 15.0, (N, 3)) * depths[:, None] * mult
+    scales = rng.uniform(0.5, 15.0, (N, 3)) * depths[:, None] * mult * float(splat_scale)
     q = rng.normal(size=(N, 4))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     x, y, z, w = q.T  # xyzw, as the reference's quaternion_to_matrix (gaussians.py:8-44)
@@ -120,4 +121,17 @@ WORKLOADS = {
     "c1_256x256_plumbing": (256, 256, 20_000),
     "c2_640x480_300k": (480, 640, 300_000),
     "c3_968x1296_1M": (968, 1296, 1_000_000),
+    # the UNFRIENDLY config-3 workload: the same 1.0 M Gaussians and cameras with every splat at 2.5x its
+    # size on screen -- what a camera at 0.4x the distance sees of surfaces whose Gaussians all stay in frame.  (Moving the
+    # target camera alone does not do it: a FreeSplat scene holds one Gaussian per context pixel, so at 1/3 of the distance
+    # each splat is 3x larger but only 1/4 of them stay in view -- the oracle counts 9.2 -> 7.1 list entries per Gaussian.)
+    # Oracle (3-sigma rectangles, no tile culling) at 2.0x: 25.5 entries per Gaussian, median tile list 5 316, EVERY tile list
+    # > 2 048 entries, i.e. the global-memory sort path of sort_blend_kernel (include/freesplat_amd.h) on every tile.
+    "c3_closeup_968x1296_1M": (968, 1296, 1_000_000),
 }
+SCENE_OPTIONS = {"c3_closeup_968x1296_1M": {"splat_scale": 2.5}}
+
+
+def workload_scene(name: str) -> dict:
+    """The scene of a named workload (make_scene with its options)."""
+    return make_scene(WORKLOADS[name][2], **SCENE_OPTIONS.get(name, {}))
