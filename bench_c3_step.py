@@ -14,9 +14,9 @@ tests/test_composed_dropin.py, so that every hot-path stage sees config 3's tens
 (the same modules run alone, forward + backward, on the captured inputs) and is not the subject.
 
 Reported (one stream, HIP events): ms per whole step; ms of library kernels per stage (fs_profile_* hooks: cost_volume,
-encoder_tail, ptf, preprocess, tile_scan, render, render_bwd, preprocess_bwd); ms of the stand-in modules alone; and the
-REST = step - library - stand-ins: the torch / rocclr glue between the stages (reshapes that copy, index kernels, fills,
-reductions, the loss, host-induced gaps), i.e. what the inter-stage plumbing costs on the GPU's clock.
+encoder_tail, ptf, preprocess, tile_scan, render, render_bwd, preprocess_bwd); the rest (stand-in modules + glue + idle).  The
+GLUE between the stages (reshapes that copy, index kernels, fills, reductions, the loss) is separated from the stand-ins' own
+kernels in a rocprofv3 kernel trace of the same step, by kernel name: profiles/tools/c3_step_glue.py.
 `python bench_c3_step.py [--steps 3]` prints the section as one JSON line; bench.py embeds it as `c3_train_step_hotpath`.
 """
 from __future__ import annotations
@@ -119,38 +119,20 @@ class _Encoder(nn.Module):
         return fuse_gaussians(self, *a, **k)
 
 
-def _standins(enc):
-    return {"backbone": enc.backbone, "cv_encoder": enc.cv_encoder, "depth_trunk": enc.depth_decoder.trunk,
-            "high_resolution_skip": enc.high_resolution_skip[0], "to_gaussians": enc.to_gaussians}
+def committed_glue():
+    """{glue_ms_per_step, glue_frac_of_hotpath_gpu_time, source} from the newest profiles/*_c3_step_glue.json, or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c3_step_glue.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            return {"glue_ms_per_step": d["per_step_ms"]["glue"], "glue_frac_of_hotpath_gpu_time": d["glue_frac_of_hotpath_gpu_time"],
+                    "source": os.path.relpath(f, ROOT)}
+        except Exception:
+            continue
+    return None
 
 
-def _flat_tensors(o):
-    if torch.is_tensor(o):
-        return [o]
-    if isinstance(o, (list, tuple)):
-        return [t for x in o for t in _flat_tensors(x)]
-    if isinstance(o, dict):
-        return [t for x in o.values() for t in _flat_tensors(x)]
-    return []
-
-
-def _snapshot(o):
-    if torch.is_tensor(o):
-        return ("t", o.detach(), bool(o.requires_grad))
-    if isinstance(o, (list, tuple)):
-        return ("l", [_snapshot(x) for x in o])
-    return ("o", o)
-
-
-def _restore(s):
-    if s[0] == "t":
-        return s[1].clone().requires_grad_(s[2])
-    if s[0] == "l":
-        return [_restore(x) for x in s[1]]
-    return s[1]
-
-
-def bench_c3_step(dev, steps=3, warmup=2, H=968, W=1296, V=3, D=128, C=48, n_targets=4) -> dict:
+def bench_c3_step(dev, steps=3, warmup=2, H=968, W=1296, V=3, D=128, C=48, n_targets=4, trace_steps=0) -> dict:
     import inputs
     from freesplat_amd import _lib
     from freesplat_amd.decoder import DecoderSplattingCUDA
@@ -180,6 +162,16 @@ def bench_c3_step(dev, steps=3, warmup=2, H=968, W=1296, V=3, D=128, C=48, n_tar
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    if trace_steps:
+        # a profiler is attached: nothing but plain steps between two markers the trace can be cut at
+        torch.cuda.synchronize()
+        mark = torch.full((64,), 0.25, device=dev)
+        torch.erfinv(mark)                      # marker launch (a kernel name nothing else in the step uses: c3_step_glue.py)
+        for _ in range(trace_steps):
+            step()
+        torch.erfinv(mark)
+        torch.cuda.synchronize()
+        return {"trace_steps": trace_steps, "gaussians": info["gaussians"]}
     # ---- whole step, events off ----
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     import time
@@ -203,32 +195,11 @@ def bench_c3_step(dev, steps=3, warmup=2, H=968, W=1296, V=3, D=128, C=48, n_tar
     _R.NUM_STREAMS = streams
     stages = {k: v[0] / steps for k, v in _lib.profile_collect().items() if v[0] > 0}
     lib_ms = sum(stages.values())
-    # ---- the stand-in modules alone (forward + backward on the inputs they saw in a step) ----
-    captured = {}
-    hooks = [m.register_forward_hook(lambda mod, args, out, n=n: captured.__setitem__(n, _snapshot(args)),
-                                     with_kwargs=False) for n, m in _standins(enc).items()]
-    step()
-    for h_ in hooks:
-        h_.remove()
-    standin = {}
-    for n, m in _standins(enc).items():
-        args = _restore(captured[n])        # (leaves that require grad exactly where the step's inputs did)
-
-        def run():
-            outs = _flat_tensors(m(*args))
-            sum(o.sum() for o in outs).backward()
-        run()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(steps):
-            run()
-        b.record()
-        torch.cuda.synchronize()
-        standin[n] = a.elapsed_time(b) / steps
-    standin_ms = sum(standin.values())
-    glue_ms = max(step_ms - lib_ms - standin_ms, 0.0)
-    hot_ms = lib_ms + glue_ms                           # the hot path's own GPU time: its kernels + its plumbing
+    other_ms = max(step_ms - lib_ms, 0.0)
+    # The split of `other` into the stand-in modules' own kernels (out of scope) and the GLUE between the hot-path stages cannot be
+    # taken from events (the stand-ins run interleaved with the glue, forward and backward): it comes from a rocprofv3 kernel
+    # trace of this same step, every kernel classified by name (profiles/tools/c3_step_glue.py -> profiles/*_c3_step_glue.json).
+    glue = committed_glue()
     n_g = info["gaussians"]
     return {"metric": f"composed config-3 training steps/sec ({V} context views @ {H}x{W}, cost volume {H // 4}x{W // 4} K={V - 1} "
                       f"D={D}, PTF fold, {n_targets} target views, fwd+bwd)",
@@ -239,11 +210,14 @@ def bench_c3_step(dev, steps=3, warmup=2, H=968, W=1296, V=3, D=128, C=48, n_tar
                        "raw_gaussians": V * H * W, "gaussians_after_fold": n_g},
             "gaussians": n_g, "target_views": n_targets,
             "library_kernel_ms": lib_ms, "library_kernel_ms_by_stage": stages,
-            "standin_modules_ms": standin_ms, "standin_modules_ms_by_module": standin,
-            "glue_ms": glue_ms, "glue_frac_of_gpu_time": glue_ms / max(hot_ms, 1e-9),
-            "glue_frac_note": "glue / (library kernels + glue): the stand-ins' own convolutions are out of scope and left out of "
-                              "the denominator; glue = step - library - stand-ins by HIP events on one stream, so it also holds "
-                              "any GPU idle time the host causes",
+            "non_library_ms": other_ms,
+            "non_library_note": "step - library kernels by HIP events on one stream: the stand-in modules' own kernels (convolutions, "
+                                "the Linear layer: out of scope) + the torch / rocclr glue between the hot-path stages + GPU idle time",
+            "glue_ms": None if glue is None else glue["glue_ms_per_step"],
+            "glue_frac_of_gpu_time": None if glue is None else glue["glue_frac_of_hotpath_gpu_time"],
+            "glue_source": None if glue is None else glue["source"],
+            "glue_note": "from the committed rocprofv3 kernel trace of this step, kernels classified by name: glue / (library kernels + "
+                         "glue); the stand-ins' kernels are left out of the denominator",
             "loss": float(loss.detach())}
 
 
@@ -251,8 +225,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--trace-steps", type=int, default=0,
+                    help="run ONLY this many plain steps after the warm-up and print their count (for rocprofv3 --kernel-trace: "
+                         "profiles/tools/c3_step_glue.py divides the trace by it)")
     ap.add_argument("--small", action="store_true", help="config 1's size (256x256, 2 views, D = 16): a quick functional run")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     kw = dict(H=256, W=256, V=2, D=16, n_targets=2) if a.small else {}
+    if a.trace_steps:
+        kw["trace_steps"] = a.trace_steps
     print(json.dumps(bench_c3_step(dev, a.steps, a.warmup, **kw)))

@@ -25,7 +25,7 @@ class RasterDims(C.Structure):
                 ("flags", C.c_int32)]
 
 
-ABI_VERSION = 4          # include/freesplat_amd.h FS_ABI_VERSION
+ABI_VERSION = 5          # include/freesplat_amd.h FS_ABI_VERSION
 
 RASTER_TILE_CULL = 1
 RASTER_SH_FP16 = 2
@@ -61,6 +61,7 @@ SIGNATURES = {
     "fs_cost_volume_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
     "fs_cost_volume_forward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 9),
     "fs_cost_volume_backward_workspace_bytes": (C.c_size_t, [C.c_int32] * 6),
+    "fs_cost_volume_backward_workspace_bytes_for": (C.c_size_t, [C.c_int32] * 6 + [C.c_int64]),
     "fs_cost_volume_backward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 16),
     "fs_cost_volume_depth_planes": (C.c_int, [C.c_int32] + [_VP] * 5),
     "fs_cost_volume_saved_bytes": (C.c_size_t, [C.c_int32] * 5),
@@ -70,6 +71,8 @@ SIGNATURES = {
     "fs_unproject_backward": (C.c_int, [C.c_int32] * 3 + [_VP] * 5),
     "fs_gaussian_head_forward": (C.c_int, [C.c_int64] + [_VP] * 4 + [C.c_int64, _VP, C.c_float, C.c_float] + [_VP] * 5),
     "fs_gaussian_head_backward": (C.c_int, [C.c_int64] + [_VP] * 4 + [C.c_int64, _VP, C.c_float, C.c_float] + [_VP] * 8),
+    "fs_latents_pack_forward": (C.c_int, [C.c_int32, C.c_int64, C.c_int32] + [_VP] * 5),
+    "fs_latents_pack_backward": (C.c_int, [C.c_int32, C.c_int64, C.c_int32] + [_VP] * 5),
     "fs_ptf_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
     "fs_ptf_match": (C.c_int, [C.c_int32] * 3 + [_VP] * 4 + [C.c_float] + [_VP] * 7),
     "fs_ptf_gru_inputs": (C.c_int, [C.c_int32] + [_VP] * 10),

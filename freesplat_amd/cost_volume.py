@@ -102,7 +102,7 @@ class _CostVolumeFn(torch.autograd.Function):
         D, strides = ctx.D, ctx.strides
         dev = g.device
         L = _lib.lib()
-        ws = torch.empty(L.fs_cost_volume_backward_workspace_bytes(B, K, C, h, w, D), dtype=torch.uint8, device=dev)
+        ws = torch.empty(L.fs_cost_volume_backward_workspace_bytes_for(B, K, C, h, w, D, strides[2]), dtype=torch.uint8, device=dev)
         d_cur, d_src = torch.empty_like(cur_feats), torch.empty_like(src_feats)
         e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         d_w1, d_b1, d_w2, d_b2, d_w3, d_b3 = e(32, C + 1), e(32), e(32, 32), e(32), e(1, 32), e(1)

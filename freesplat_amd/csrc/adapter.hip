@@ -111,6 +111,20 @@ __device__ __forceinline__ void mat3_mul_at(const float* X, const float* Y, floa
 // instruction of a wavefront span 64 x 136 bytes (2.5 - 3.5 TB/s of the algorithmic bytes in rounds 2 - 3).  A workgroup's 256
 // consecutive rows are ONE contiguous slab, so they cross HBM as 16-byte coalesced accesses and meet their threads in LDS
 // (row strides 34 / 27 / 9 words: at most 2-way bank conflicts).
+// One 4-float row of a per-Gaussian 4x4: a 16-byte access when the array is 16-byte aligned (the rows are 16-byte multiples
+// apart, so the base decides), four scalar ones otherwise -- in the inference fold the extrinsics are a view at float offset
+// rows * 69 inside one buffer, 4-byte aligned when h * w is not a multiple of 4.
+__device__ __forceinline__ float4 load_row4(const float* __restrict__ p)
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) return *(const float4*)p;
+    return make_float4(p[0], p[1], p[2], p[3]);
+}
+__device__ __forceinline__ void store_row4(float* __restrict__ p, float4 v)
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) { *(float4*)p = v; return; }
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+}
+
 template <int PER>
 __device__ __forceinline__ void rows_in(float* __restrict__ lds, const float* __restrict__ src, long long m0, int cnt)
 {
@@ -161,7 +175,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(long long M, const float*
         float Rc[9], B[9], S[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float4 er = ((const float4*)(E + m * 16))[a];
+            const float4 er = load_row4(E + m * 16 + 4 * a);
             Rc[3 * a] = er.x; Rc[3 * a + 1] = er.y; Rc[3 * a + 2] = er.z;
         }
         mat3_mul(Rc, f.A, B);        // c2w @ cov
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(long long M, const float*
     float Rc[9], G[9], B[9];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float4 er = ((const float4*)(E + m * 16))[a];
+        const float4 er = load_row4(E + m * 16 + 4 * a);
         Rc[3 * a] = er.x; Rc[3 * a + 1] = er.y; Rc[3 * a + 2] = er.z;
 #pragma unroll
         for (int b = 0; b < 3; ++b) G[3 * a + b] = g_cov ? g_cov[m * 9 + 3 * a + b] : 0.0f;
@@ -298,11 +312,75 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(long long M, const float*
         g_depths[m] = gdepth;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-            ((float4*)(g_E + m * 16))[a] = a < 3 ? make_float4(dRc[3 * a], dRc[3 * a + 1], dRc[3 * a + 2], 0.0f)
-                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            store_row4(g_E + m * 16 + 4 * a, a < 3 ? make_float4(dRc[3 * a], dRc[3 * a + 1], dRc[3 * a + 2], 0.0f)
+                                                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
     __syncthreads();
     rows_out<34>(g_raw, s_rows, m0, cnt);
+}
+
+
+// ------------------------------------------------------------------ per-pixel latents: head + skip, channel-major -> pixel-major
+// encoder_freesplat.py:311-316: latents = (head[:, 1:] + skip) rearranged "(b v) c h w -> b v (h w) c", densities from head[:, :1].
+// In torch that is an add, then -- because the fold wants [V, P, 64] rows -- a transposing copy of 963 MB at config 3 (1.4 ms), and
+// in the backward two more (4.5 ms each: the gradient back to channel-major for the head slice and for the skip convolution):
+// 10.3 ms of a 70 ms training step (profiles/r5_c3_step_glue.json).  Here: one pass each way through a 64 x 64 LDS tile -- rows of
+// 64 pixels (256 B) in, rows of 64 channels (256 B) out, the same single fp32 add.
+constexpr int kLpC = 64, kLpT = 64;   // channels, pixels per tile
+__global__ __launch_bounds__(256) void latents_pack_fwd_kernel(long long P, const float* __restrict__ head,
+                                                               const float* __restrict__ skip, float* __restrict__ lat,
+                                                               float* __restrict__ dens)
+{
+    __shared__ float tile[kLpC][kLpT + 1];
+    const int v = blockIdx.y, t = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * kLpT;
+    const int np = (int)min((long long)kLpT, P - p0);
+    const float* hv = head + (size_t)v * (kLpC + 1) * P;
+    const float* sv = skip + (size_t)v * kLpC * P;
+    const int px = t & 63, c0 = t >> 6;
+    if (px < np) {
+#pragma unroll 4
+        for (int c = c0; c < kLpC; c += 4) tile[c][px] = hv[(size_t)(1 + c) * P + p0 + px] + sv[(size_t)c * P + p0 + px];
+        if (c0 == 0 && dens) dens[(size_t)v * P + p0 + px] = hv[p0 + px];
+    }
+    __syncthreads();
+    float* o = lat + ((size_t)v * P + p0) * kLpC;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = k * 256 + t, q = e >> 4, c4 = (e & 15) * 4;      // pixel q of the tile, channels c4 .. c4 + 3
+        if (q < np) *(float4*)(o + (size_t)q * kLpC + c4) = make_float4(tile[c4][q], tile[c4 + 1][q], tile[c4 + 2][q], tile[c4 + 3][q]);
+    }
+}
+
+// g_head [V, C + 1, P] (channel 0 <- g_dens or 0, channel 1 + c <- g_lat[.., c]) and g_skip [V, C, P] (<- g_lat[.., c]); either
+// output may be NULL (its input does not require a gradient), g_lat == NULL means a zero gradient.
+__global__ __launch_bounds__(256) void latents_pack_bwd_kernel(long long P, const float* __restrict__ g_lat,
+                                                               const float* __restrict__ g_dens, float* __restrict__ g_head,
+                                                               float* __restrict__ g_skip)
+{
+    __shared__ float tile[kLpC][kLpT + 1];
+    const int v = blockIdx.y, t = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * kLpT;
+    const int np = (int)min((long long)kLpT, P - p0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = k * 256 + t, q = e >> 4, c4 = (e & 15) * 4;
+        float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (g_lat && q < np) g = *(const float4*)(g_lat + ((size_t)v * P + p0 + q) * kLpC + c4);
+        tile[c4][q] = g.x; tile[c4 + 1][q] = g.y; tile[c4 + 2][q] = g.z; tile[c4 + 3][q] = g.w;
+    }
+    __syncthreads();
+    const int px = t & 63, c0 = t >> 6;
+    if (px >= np) return;
+    float* hv = g_head ? g_head + (size_t)v * (kLpC + 1) * P + p0 + px : nullptr;
+    float* sv = g_skip ? g_skip + (size_t)v * kLpC * P + p0 + px : nullptr;
+#pragma unroll 4
+    for (int c = c0; c < kLpC; c += 4) {
+        const float g = tile[c][px];
+        if (hv) hv[(size_t)(1 + c) * P] = g;
+        if (sv) sv[(size_t)c * P] = g;
+    }
+    if (c0 == 0 && hv) hv[0] = g_dens ? g_dens[(size_t)v * P + p0 + px] : 0.0f;
 }
 
 }  // namespace fs
@@ -367,5 +445,31 @@ FS_API int fs_gaussian_head_backward(int64_t M, const float* raw, const float* d
                        (long long)M, raw, depths, extrinsics, multiplier, (long long)mult_stride, sh_mask, scale_min,
                        scale_max, g_cov, g_harmonics, g_scales, g_rotations, g_raw, g_depths, g_extrinsics);
     FS_CHECK_LAUNCH("gaussian_head_backward");
+    return FS_OK;
+}
+
+FS_API int fs_latents_pack_forward(int32_t V, int64_t P, int32_t C, const float* head, const float* skip, float* latents,
+                                   float* dens, void* stream_)
+{
+    if (V < 0 || P < 0 || C != kLpC) return FS_ERR_INVALID_ARG;
+    if (V == 0 || P == 0) return FS_OK;
+    if (!head || !skip || !latents || V > 65535) return FS_ERR_INVALID_ARG;
+    ScopedStage prof_(kStEncoderTail, (hipStream_t)stream_);
+    hipLaunchKernelGGL(latents_pack_fwd_kernel, dim3((unsigned)((P + kLpT - 1) / kLpT), (unsigned)V), dim3(256), 0, (hipStream_t)stream_,
+                       (long long)P, head, skip, latents, dens);
+    FS_CHECK_LAUNCH("latents_pack_forward");
+    return FS_OK;
+}
+
+FS_API int fs_latents_pack_backward(int32_t V, int64_t P, int32_t C, const float* g_latents, const float* g_dens, float* g_head,
+                                    float* g_skip, void* stream_)
+{
+    if (V < 0 || P < 0 || C != kLpC) return FS_ERR_INVALID_ARG;
+    if (V == 0 || P == 0 || (!g_head && !g_skip)) return FS_OK;
+    if (V > 65535) return FS_ERR_INVALID_ARG;
+    ScopedStage prof_(kStEncoderTail, (hipStream_t)stream_);
+    hipLaunchKernelGGL(latents_pack_bwd_kernel, dim3((unsigned)((P + kLpT - 1) / kLpT), (unsigned)V), dim3(256), 0, (hipStream_t)stream_,
+                       (long long)P, g_latents, g_dens, g_head, g_skip);
+    FS_CHECK_LAUNCH("latents_pack_backward");
     return FS_OK;
 }

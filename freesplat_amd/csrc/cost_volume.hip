@@ -437,17 +437,17 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
             if (c == 0) xm[pl * hw + pix] = make_float2(dot_sum * inv, __uint_as_float(flags));
         }
         // ---- to the operand order: lane (n, g) takes quarter g of pixel n ----
-        float xm[NT];
+        float xop[NT];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) xm[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(favg[r] * inv)));
-        xm[NR] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(c == 0 ? dot_sum * inv : (c == 1 ? 1.0f : 0.0f))));
+        for (int r = 0; r < NR; ++r) xop[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(favg[r] * inv)));
+        xop[NR] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(c == 0 ? dot_sum * inv : (c == 1 ? 1.0f : 0.0f))));
         // ---- layer 1 ----
         f32x4 h1[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             h1[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int t = 0; t < NT; ++t) h1[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[blk][t], xm[t], h1[blk], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) h1[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[blk][t], xop[t], h1[blk], 0, 0, 0);
         }
         // ---- layer 2 ----
         f32x4 h2[2];
@@ -1205,8 +1205,8 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
 //   d src_k[t] = sum over (pixel p, plane d) whose bilinear taps cover texel t of
 //                w_tap * (valid_k * dfavg'(p, d) + [z_k > 0] * ddot'(p, d) * cur(p))
 // with dfavg' = d favg / cnt, ddot' = d dot / cnt and the two bits per source from the first pass's records.  A workgroup
-// owns a TILE of 16 x 16 source texels of one (view, source) -- its gradient lives in LDS, channel-planar, for the whole
-// sweep -- and walks the planes: for plane d the current pixels that can touch the tile are the preimage of the tile
+// (ONE wavefront) owns a TILE of 8 x 8 source texels of one (view, source) -- its gradient lives in LDS, texel-major rows of
+// C + 4 floats, for the whole sweep -- and walks the planes: for plane d the current pixels that can touch the tile are the preimage of the tile
 // rectangle (grown by the bilinear footprint) under the plane-induced homography, a convex quadrilateral whose bounding
 // box comes from the four corners through the INVERSE homography (cv_bwd_prep_kernel; profiles/tools/cv_tile_box_count.py
 // checks on the CPU that no pixel with a tap in a tile falls outside its box, and counts 1.0 - 1.1 visited pixels per
@@ -1462,25 +1462,27 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
                 if (pend) claim[ge.cid] = (uint32_t)lane;
                 wave_lds_sync();
                 const bool win = pend && claim[ge.cid] == (uint32_t)lane;
-                if (win) {
+                // Two winners never share a tap BASE, but tap 1 of base (0, 0) is tap 0 of base (1, 0): the four tap groups
+                // must reach the LDS in program order (all lanes' tap t before any lane's tap t + 1).  wave_lds_sync() -- a
+                // compiler-only fence, no instruction -- keeps the scheduler from hoisting a later group's ds_reads above an
+                // earlier group's ds_writes, which are provably distinct addresses within ONE lane.
 #pragma unroll
-                    for (int tap = 0; tap < 4; ++tap) {
-                        const int ox = tap & 1, oy = tap >> 1;
-                        if (ge.okm & (1u << tap)) {
-                            const float wt = (ox ? ge.tx : 1.0f - ge.tx) * (oy ? ge.ty : 1.0f - ge.ty);
-                            float4* a = (float4*)(acc + (ge.t00 + oy * TW + ox) * ST);
+                for (int tap = 0; tap < 4; ++tap) {
+                    const int ox = tap & 1, oy = tap >> 1;
+                    if (win && (ge.okm & (1u << tap))) {
+                        const float wt = (ox ? ge.tx : 1.0f - ge.tx) * (oy ? ge.ty : 1.0f - ge.ty);
+                        float4* a = (float4*)(acc + (ge.t00 + oy * TW + ox) * ST);
 #pragma unroll
-                            for (int s = 0; s < NV; ++s) {
-                                float4 v = a[s];
-                                v.x = fmaf(wt, S[s].x, v.x); v.y = fmaf(wt, S[s].y, v.y);
-                                v.z = fmaf(wt, S[s].z, v.z); v.w = fmaf(wt, S[s].w, v.w);
-                                a[s] = v;
-                            }
+                        for (int s = 0; s < NV; ++s) {
+                            float4 v = a[s];
+                            v.x = fmaf(wt, S[s].x, v.x); v.y = fmaf(wt, S[s].y, v.y);
+                            v.z = fmaf(wt, S[s].z, v.z); v.w = fmaf(wt, S[s].w, v.w);
+                            a[s] = v;
                         }
                     }
+                    wave_lds_sync();
                 }
                 pend = pend && !win;
-                wave_lds_sync();
             }
         };
         Geo gA, gB;
@@ -1683,18 +1685,6 @@ FS_API int fs_cost_volume_forward_train(int32_t B, int32_t K, int32_t C, int32_t
                            plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, b3, workspace, out, saved, stream_);
 }
 
-FS_API size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w,
-                                                      int32_t D)
-{
-    if (B <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return 0;
-    const size_t hw = (size_t)h * w;
-    // pixel-major copies curT, srcT and their gradients d_curT, d_srcT; the projection rows; and for the two-pass form
-    // (constant planes, K <= 16) one record of C + 2 floats per (view, plane, pixel) and the inverse plane homographies
-    return align_up((size_t)B * (1 + (size_t)K) * C * hw * 2 * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256) +
-           align_up((size_t)B * D * hw * C * sizeof(float), 256) + align_up((size_t)B * D * hw * 2 * sizeof(float), 256) +
-           align_up((size_t)B * K * D * 9 * sizeof(float), 256);
-}
-
 // The two-pass backward (records + source-tile sweep) needs plane depths that do not vary per pixel (a plane-induced
 // homography) and the sources' flag bits in one word; FS_CV_BWD_ATOMIC=1 forces the one-kernel scatter form (A/B runs)
 static bool cv_bwd_two_pass(int K, int64_t plane_stride_pix)
@@ -1702,6 +1692,33 @@ static bool cv_bwd_two_pass(int K, int64_t plane_stride_pix)
     const char* e = getenv("FS_CV_BWD_ATOMIC");
     if (e && *e && atoi(e) != 0) return false;
     return plane_stride_pix == 0 && K <= 16;
+}
+
+static size_t cv_bwd_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D, bool two_pass)
+{
+    if (B <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return 0;
+    const size_t hw = (size_t)h * w;
+    // pixel-major copies curT, srcT and their gradients d_curT, d_srcT; the projection rows; and for the two-pass form
+    // (constant planes, K <= 16) one record of C + 2 floats per (view, plane, pixel) and the inverse plane homographies
+    size_t n = align_up((size_t)B * (1 + (size_t)K) * C * hw * 2 * sizeof(float), 256) + align_up((size_t)B * K * 12 * 4, 256);
+    if (two_pass)
+        n += align_up((size_t)B * D * hw * C * sizeof(float), 256) + align_up((size_t)B * D * hw * 2 * sizeof(float), 256) +
+             align_up((size_t)B * K * D * 9 * sizeof(float), 256);
+    return n;
+}
+// Upper bound for any call of these dimensions (the two-pass form's records included: B * D * h * w * (C + 2) floats, ~3 GB for
+// 10 views at 96 x 128 with D = 128) ...
+FS_API size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w,
+                                                      int32_t D)
+{
+    return cv_bwd_workspace_bytes(B, K, C, h, w, D, true);
+}
+// ... and what THIS call needs: without the record and inverse-homography regions when the one-kernel scatter form will run
+// (per-pixel planes, K > 16, FS_CV_BWD_ATOMIC=1), which never touches them.
+FS_API size_t fs_cost_volume_backward_workspace_bytes_for(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w,
+                                                          int32_t D, int64_t plane_stride_pix)
+{
+    return cv_bwd_workspace_bytes(B, K, C, h, w, D, cv_bwd_two_pass(K, plane_stride_pix));
 }
 
 static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,

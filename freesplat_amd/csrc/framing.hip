@@ -113,8 +113,8 @@ __global__ void invert4x4_kernel(int n, const float* __restrict__ src, float* __
 
 // generate_depth_planes (cost_volume.py:116-125) in one launch, op by op -- 1 / min, 1 / max, min^-1 + (max^-1 - min^-1) * ramp,
 // 1 / that, every operation rounded as torch rounds it -- instead of the module's eight elementwise launches.  (It lives in THIS
-// translation unit because cost_volume.hip is built with -ffp-contract=fast, under which the backend fuses the multiply-add
-// whatever the source says: one rounding less than torch's.)
+// translation unit, built with -ffp-contract=off: cost_volume.hip is built with -ffp-contract=on, under which a * b + c written as
+// one expression is fused -- one rounding less than torch's.)
 __global__ void cv_depth_planes_kernel(int D, const float* __restrict__ min_depth, const float* __restrict__ max_depth,
                                        const float* __restrict__ ramp, float* __restrict__ out)
 {

@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256) void ptf_flags_count_kernel(int M, const int32
     const int blk = second ? blockIdx.x - nbM : blockIdx.x;
     const int base = blk * kScanBlock + threadIdx.x * 4;
     uint32_t v = 0;
-    if (base + 3 < n) {
+    // the 16-byte loads below need 16-byte aligned arrays: depth_i = depths + i * P is only 4-byte aligned when h * w is not a
+    // multiple of 4 -- such a call takes the scalar path (workgroup-uniform)
+    const bool al16 = second ? ((((uintptr_t)zbuf | (uintptr_t)depth_i) & 15) == 0)
+                             : ((((uintptr_t)pix_of | (uintptr_t)zbits_of) & 15) == 0);
+    if (base + 3 < n && al16) {
         // a full quad: the four elements' loads are issued together (a loop that may leave early serialises the dependent
         // gathers pix_of -> zbuf / depth_i: 192 workgroups of latency instead of 768)
         if (second) {
@@ -694,7 +698,8 @@ FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int3
 // Camera constants of the fold in one launch: thread i scales the normalised intrinsics of view i to pixels
 // (encoder_freesplat.py:445-448, one multiply each: same bits as torch); all threads replicate view 0's extrinsics per
 // pixel (the initial per-Gaussian extrinsics, :441).  The world-to-camera matrices are NOT formed here: a pixel's
-// round-half-even decision can hinge on their last bit, so they come from the same torch inverse the reference uses.
+// round-half-even decision can hinge on their last bit; they come from fs_invert_4x4 (framing.hip: double precision inside,
+// rounded once -- tests/test_ptf_hip.py::test_invert_4x4_vs_float64_inverse), in the fold and in the tests' oracle alike.
 __global__ __launch_bounds__(256) void ptf_cameras_kernel(int V, int P, int h, int w, const float* __restrict__ Es,
                                                           const float* __restrict__ Kn, float* __restrict__ kpix,
                                                           float* __restrict__ E0, uint32_t* __restrict__ zbuf)

@@ -105,7 +105,11 @@ constexpr int kBwdQuads = 7;  // float4 per slot of two survivors
 // the (blue, depth) pair runs as scalar operations (packed fp32 has no throughput advantage on this chip, fs_common.h), and
 // the wavefront reduction carries 9 instead of 10 values per survivor.
 template <bool FAST_EXP, bool DEPTH>
+#ifdef FS_BWD_WAVES         // (A/B builds: make VARIANT=b8 EXTRA=-DFS_BWD_WAVES=8 forces <= 64 registers)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FS_BWD_WAVES, FS_BWD_WAVES))) void render_bwd_kernel(
+#else
 __global__ __launch_bounds__(64) void render_bwd_kernel(
+#endif
     int H, int W, int T, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
     const float* __restrict__ bg, const uint32_t* __restrict__ counters, const float* __restrict__ final_T,

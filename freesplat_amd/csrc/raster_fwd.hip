@@ -751,12 +751,15 @@ constexpr uint32_t kMaxBucket = 24;
 // barrier) for the blend that follows in the same workgroup; `gout` != nullptr also writes them to the saved list
 // (training: the backward walks it).
 template <int EPT>
-__device__ __forceinline__ void sort_tile_buckets(const unsigned long long* __restrict__ keys, uint32_t* __restrict__ gout,
-                                                  uint32_t n, unsigned long long* sk, uint32_t* cnt, uint32_t* s_red)
+__device__ __forceinline__ void sort_tile_buckets(const unsigned long long* keys, uint32_t* __restrict__ gout,
+                                                  uint32_t n, unsigned long long* sk, uint32_t* cnt, uint32_t* s_red,
+                                                  int tid = -1)
 {
     constexpr int CAP = 256 * EPT;  // capacity == number of buckets
     uint32_t* const list = cnt;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // (`tid`: the caller's opaque copy of threadIdx.x -- sort_tile_partitioned calls this in a loop and must not have the
+    //  lane-derived shuffle addresses of this body hoisted out of it and kept live in registers across the whole loop)
+    const int t = tid >= 0 ? tid : (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     unsigned long long k[EPT];
     uint32_t zmin = 0xFFFFFFFFu, zmax = 0u;
 #pragma unroll
@@ -857,6 +860,125 @@ __device__ __forceinline__ void sort_tile_buckets(const unsigned long long* __re
             if (gout) gout[pos[e]] = (uint32_t)k[e];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tile lists LONGER than the LDS sort's capacity (close-up / dense views: round 5's c3_closeup workload has every tile there):
+// a two-level distribution sort, O(n) like the bucket sort it builds on, instead of the O(n log^2 n) networks (register bitonic
+// up to 4096 keys, ~550 VALU per key; beyond that the in-place global-memory network: ~100 barrier-separated passes over the keys).
+//   1. zmin / zmax and a 2048-bin depth histogram of the tile's keys (bins monotone in the depth bits) in LDS;
+//   2. exclusive scan; consecutive bins are grouped greedily into GROUPS of <= kSortLds keys (thread 0, binary searches on the
+//      prefix sums: <= 64 groups);
+//   3. per group: the keys of its depth range are compacted from the tile's key area into the LDS staging (ballot + one LDS
+//      atomic per wavefront; arrival order is irrelevant), sorted by sort_tile_buckets -- the full (depth bits, id) order -- and
+//      written to the group's range of the tile's saved list.  Groups are depth-ordered and equal depths share a bin, so the
+//      concatenation is the same total order as before, bit for bit.
+// Cost: 2 + G passes over the keys (L2-resident, coalesced) + G LDS sorts, G ~ n / 1500.  A single bin of more than kSortLds keys
+// (thousands of identical depths) or more than 64 groups returns false: the caller falls back to the global network.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxGroups = 64;
+// (forceinline: as a separate function -- tried to keep its register pressure out of the kernel -- the second group's key count
+//  came out wrong on the GPU (gfx950, ROCm 7.2: its output range held 2048 entries instead of m; profiles/r5_long_sort_debug.txt);
+//  inlined, the group loop spills ~15 registers to scratch, in this cold path only.)
+__device__ __forceinline__ bool sort_tile_partitioned(
+    const unsigned long long* __restrict__ kt, uint32_t* __restrict__ gl, uint32_t n,
+                                                      unsigned long long* sk, uint32_t* cnt, uint32_t* s_red, uint32_t* s_grp)
+{
+    constexpr int NB = kSortLds;   // fine bins (== cnt's size - 1)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t zmin = 0xFFFFFFFFu, zmax = 0u;
+    for (uint32_t i = t; i < n; i += 256) {
+        const uint32_t z = (uint32_t)(kt[i] >> 32);
+        zmin = min(zmin, z);
+        zmax = max(zmax, z);
+    }
+    for (int i = t; i <= NB; i += 256) cnt[i] = 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        zmin = min(zmin, (uint32_t)__shfl_xor((int)zmin, m, 64));
+        zmax = max(zmax, (uint32_t)__shfl_xor((int)zmax, m, 64));
+    }
+    if (lane == 0) { s_red[wave] = zmin; s_red[4 + wave] = zmax; }
+    __syncthreads();
+    zmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    zmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    const float scale = (float)NB / (float)(zmax - zmin + 1u);
+    auto bin_of = [&](unsigned long long key) { return min((uint32_t)(NB - 1), (uint32_t)((float)((uint32_t)(key >> 32) - zmin) * scale)); };
+    for (uint32_t i = t; i < n; i += 256) atomicAdd(&cnt[bin_of(kt[i])], 1u);
+    __syncthreads();
+    // exclusive scan of the NB bin counts: thread t owns bins [t * 8, t * 8 + 8)
+    constexpr int BPT = NB / 256;
+    uint32_t c[BPT], sum = 0u;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) { c[j] = cnt[t * BPT + j]; sum += c[j]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_red[8 + wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) run += w < wave ? s_red[8 + w] : 0u;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) { cnt[t * BPT + j] = run; run += c[j]; }
+    if (t == 255) cnt[NB] = run;   // == n
+    __syncthreads();
+    // groups of consecutive bins holding <= kSortLds keys: s_grp[g] = first bin, s_grp[kMaxGroups + 1 + g] = keys before it
+    if (t == 0) {
+        uint32_t g = 0, b = 0;
+        bool ok = true;
+        while (b < (uint32_t)NB && ok) {
+            const uint32_t base = cnt[b];
+            uint32_t lo = b, hi = NB;              // largest e in (b, NB] with cnt[e] - base <= kSortLds
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (cnt[mid] - base <= (uint32_t)kSortLds) lo = mid; else hi = mid - 1;
+            }
+            if (lo == b || g >= (uint32_t)kMaxGroups) { ok = false; break; }   // one bin alone is too long / too many groups
+            s_grp[g] = b;
+            s_grp[kMaxGroups + 1 + g] = base;
+            ++g;
+            b = lo;
+        }
+        s_grp[g] = NB;
+        s_grp[kMaxGroups + 1 + g] = n;
+        s_grp[2 * kMaxGroups + 2] = ok ? g : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint32_t G = s_grp[2 * kMaxGroups + 2];
+    if (G == 0xFFFFFFFFu) return false;
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t b0 = s_grp[g], b1 = s_grp[g + 1], off = s_grp[kMaxGroups + 1 + g], m = s_grp[kMaxGroups + 2 + g] - off;
+        if (m == 0u) continue;   // (workgroup-uniform)
+        if (t == 0) s_red[12] = 0u;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+            const uint32_t i = i0 + t;
+            unsigned long long key = 0ull;
+            bool in = false;
+            if (i < n) {
+                key = kt[i];
+                const uint32_t b = bin_of(key);
+                in = b >= b0 && b < b1;
+            }
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+            if (mask != 0ull) {
+                uint32_t base = 0u;
+                if (lane == 0) base = atomicAdd(&s_red[12], (uint32_t)__popcll(mask));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (in) sk[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = key;
+            }
+        }
+        __syncthreads();
+        int tt = t;
+        asm volatile("" : "+v"(tt));   // opaque per iteration (see sort_tile_buckets)
+        sort_tile_buckets<kSortLds / 256>(sk, gl + off, m, sk, cnt, s_red, tt);
+        __syncthreads();   // the sort's last LDS writes (its list copy) precede the next group's zeroing of the counters
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1044,7 +1166,10 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
 // ------------------------------------------------------------------------------------------
 static_assert(4 * kPairArea * sizeof(float4) <= kSortLds * sizeof(unsigned long long), "compaction areas must fit the key staging");
 template <bool FAST_EXP, bool TRACK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void sort_blend_kernel(
+#ifndef FS_BLEND_WAVES
+#define FS_BLEND_WAVES 6      // (A/B builds: make VARIANT=w4 EXTRA=-DFS_BLEND_WAVES=4)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_BLEND_WAVES, FS_BLEND_WAVES))) void sort_blend_kernel(
     int H, int W, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t tile_cap,
     unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
     const float* __restrict__ bg, const uint32_t* __restrict__ counters,
@@ -1054,6 +1179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __shared__ __attribute__((aligned(16))) unsigned long long sk[kSortLds];
     __shared__ uint32_t s_cnt[kSortLds + 1];
     __shared__ uint32_t s_red[16];
+    __shared__ uint32_t s_grp[2 * kMaxGroups + 3];   // sort_tile_partitioned: group bins | keys before each group | group count
     if (counters[1]) return;  // overflowed capacity: key areas / saved lists are not backed by memory
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     const int tile = tile_for_block(blockIdx.x, gx, gy);  // XCD-aware, balanced (fs_common.h)
@@ -1072,14 +1198,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         sort_tile_buckets<4>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
     } else if (n <= 2048u) {
         sort_tile_buckets<8>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
-    } else if (n <= 2560u) {
+    }
+#ifdef FS_LONG_SORT_NETWORKS   // (rounds 1 - 4: register bitonic networks up to 4096 keys, the global-memory network beyond; A/B builds)
+    else if (n <= 2560u) {
         sort_tile_two_runs<8, 2>(kt, gl, n, sk);
     } else if (n <= 3072u) {
         sort_tile_two_runs<8, 4>(kt, gl, n, sk);
     } else if (n <= 4096u) {
         sort_tile_in_registers<16>(kt, gl, n, sk);
-    } else {
-        // rare: very long tile lists sort in place in global memory (same network)
+    }
+#endif
+    else if (!sort_tile_partitioned(kt, gl, n, sk, s_cnt, s_red, s_grp)) {
+        // degenerate (thousands of identical depths in one tile): in place in global memory, the plain network
         __syncthreads();
         bitonic_sort_any(kt, n);
         for (uint32_t k = threadIdx.x; k < n; k += 256) gl[k] = (uint32_t)kt[k];

@@ -65,8 +65,17 @@ def encoder_forward(self, context, global_step: int, deterministic: bool = False
     # per-pixel latents (+ full-resolution skip), densities, depths, depth weights
     flat_images = images.reshape(b * V, *images.shape[2:])
     head = dec["output_pred_s-1_b1hw"]
-    latents = (head[:, 1:] + self.high_resolution_skip[0](flat_images)).reshape(b, V, -1, h * w).transpose(-1, -2)
-    densities = torch.sigmoid(_bv(head[:, :1], b))
+    skip = self.high_resolution_skip[0](flat_images)
+    if head.is_cuda and head.shape[1] == 65 and skip.shape[1] == 64:
+        # the fold reads pixel-major rows: head[:, 1:] + skip and the channel-major -> pixel-major move in one HIP pass each way
+        # (gaussian_adapter.latents_pack) instead of an add and three transposing 1 GB copies per training step at config 3
+        from .gaussian_adapter import latents_pack
+        lat, dens_raw = latents_pack(head, skip)
+        latents = lat.reshape(b, V, h * w, -1)
+        densities = torch.sigmoid(dens_raw).reshape(b, V, h * w, 1, 1)
+    else:       # host tensors (tests/test_compat_reference.py runs this glue on the reference's own CPU modules)
+        latents = (head[:, 1:] + skip).reshape(b, V, -1, h * w).transpose(-1, -2)
+        densities = torch.sigmoid(_bv(head[:, :1], b))
     depths = _bv(dec["depth_pred_s-1_b1hw"], b)
     weights = _bv(dec["depth_weights"], b)
     xy_ray = _pixel_grid(h, w, device) + torch.zeros(b, V, h * w, self.cfg.num_surfaces, 2, device=latents.device)

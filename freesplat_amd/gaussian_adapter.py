@@ -103,6 +103,51 @@ class _Head(torch.autograd.Function):
         return g_raw, g_dep, g_E, None, None, None, None
 
 
+class _LatentsPack(torch.autograd.Function):
+    """(head [N,65,h,w], skip [N,64,h,w]) -> (latents [N, h*w, 64] = head[:, 1:] + skip in the fold's pixel-major layout,
+    dens [N, h*w] = head[:, 0]): fs_latents_pack_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, head, skip):
+        N, P = head.shape[0], head.shape[2] * head.shape[3]
+        lat = torch.empty(N, P, 64, dtype=torch.float32, device=head.device)
+        dens = torch.empty(N, P, dtype=torch.float32, device=head.device)
+        p = _lib.ptr
+        _lib.check(_lib.lib().fs_latents_pack_forward(N, P, 64, p(head), p(skip), p(lat), p(dens), _lib.current_stream()),
+                   "fs_latents_pack_forward")
+        ctx.shapes = (head.shape, skip.shape)
+        return lat, dens
+
+    @staticmethod
+    def backward(ctx, g_lat, g_dens):
+        hs, ss = ctx.shapes
+        need_h, need_s = ctx.needs_input_grad
+        if (g_lat is None and g_dens is None) or not (need_h or need_s):
+            return None, None
+        dev = g_lat.device if g_lat is not None else g_dens.device
+        g_head = torch.empty(hs, dtype=torch.float32, device=dev) if need_h else None
+        g_skip = torch.empty(ss, dtype=torch.float32, device=dev) if need_s else None
+        gl = None if g_lat is None else g_lat.float().contiguous()
+        gd = None if g_dens is None else g_dens.float().contiguous()
+        p = _lib.ptr
+        _lib.check(_lib.lib().fs_latents_pack_backward(hs[0], hs[2] * hs[3], 64, p(gl), p(gd), p(g_head), p(g_skip),
+                                                       _lib.current_stream()), "fs_latents_pack_backward")
+        return g_head, g_skip
+
+
+def latents_pack(head: Tensor, skip: Tensor):
+    """The per-pixel latents and density logits of encoder_freesplat.py:311-316 from the depth decoder's head map
+    [(b v), 1 + 64, h, w] and the skip convolution's output [(b v), 64, h, w]:
+        latents [(b v), h*w, 64] = rearrange(head[:, 1:] + skip, "n c h w -> n (h w) c"),   dens [(b v), h*w] = head[:, 0]
+    -- one HIP pass each way (csrc/adapter.hip) instead of torch's add plus a transposing copy forward and two backward."""
+    if head.device.type != "cuda":
+        raise RuntimeError(f"freesplat_amd latents_pack: tensors must live on a HIP device (got {head.device}); no CPU path")
+    if head.dim() != 4 or skip.dim() != 4 or head.shape[1] != 65 or skip.shape[1] != 64 or head.shape[0] != skip.shape[0] \
+            or head.shape[2:] != skip.shape[2:]:
+        raise RuntimeError(f"latents_pack: head {tuple(head.shape)} / skip {tuple(skip.shape)}: expected [N,65,h,w] and [N,64,h,w]")
+    return _LatentsPack.apply(_chk(head, "head"), _chk(skip, "skip"))
+
+
 class GaussianAdapter(nn.Module):
     def __init__(self, cfg: GaussianAdapterCfg):
         super().__init__()
@@ -120,7 +165,14 @@ class GaussianAdapter(nn.Module):
         return 7 + 3 * self.d_sh
 
     def get_scale_multiplier(self, intrinsics: Tensor, pixel_size: Tensor, multiplier: float = 0.1) -> Tensor:
-        xy = multiplier * torch.einsum("...ij,j->...i", torch.linalg.inv_ex(intrinsics[..., :2, :2]).inverse, pixel_size)
+        """gaussian_adapter.py:203-214.  Broadcast batch dimensions (the encoder hands in ONE camera `expand()`-ed over the M
+        fused Gaussians, encoder_freesplat.py:378) are collapsed to size 1 first: inverting the same 2x2 matrix M = 1.6 M times
+        was 3.5 ms of rocsolver kernels per config-3 training step (profiles/r5_c3_step_glue.json).  The result broadcasts
+        against the leading shape exactly as before."""
+        K = intrinsics[..., :2, :2]
+        lead = K.shape[:-2]
+        K = K[tuple(slice(0, 1) if (st == 0 and n > 1) else slice(None) for n, st in zip(lead, K.stride()[:-2]))]
+        xy = multiplier * torch.einsum("...ij,j->...i", torch.linalg.inv_ex(K).inverse, pixel_size)
         return xy.sum(dim=-1)
 
     def forward(self, extrinsics, intrinsics, coordinates, depths, opacities, raw_gaussians, image_shape,

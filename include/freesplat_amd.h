@@ -44,7 +44,7 @@ const char* fs_version(void);
  * it right after loading the library (freesplat_amd/_lib.py does): a stale build would otherwise accept calls with
  * shifted pointers.  3 = round 3 (single-pass binning: scratch = per-tile key areas, counters[1] = largest tile list on
  * overflow, geom without the mask / depth arrays; fused sort + blend). */
-#define FS_ABI_VERSION 4
+#define FS_ABI_VERSION 5
 int fs_abi_version(void);
 /* Last HIP error string observed by a failing call on this thread (never NULL). */
 const char* fs_last_error(void);
@@ -226,6 +226,10 @@ int fs_cost_volume_forward_train(int32_t B, int32_t K, int32_t C, int32_t h, int
 
 size_t fs_cost_volume_backward_workspace_bytes(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w,
                                                int32_t D);
+/* The same for ONE call: plane_stride_pix != 0 (per-pixel planes), K > 16 or FS_CV_BWD_ATOMIC=1 select the one-kernel scatter
+ * form, whose workspace holds no records (ABI 5).  The first function stays the upper bound for these dimensions. */
+size_t fs_cost_volume_backward_workspace_bytes_for(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w,
+                                                   int32_t D, int64_t plane_stride_pix);
 
 /*
  * Backward of fs_cost_volume_forward w.r.t. the features and the MLP.  grad_out[B,D,h,w] ->
@@ -386,6 +390,20 @@ int fs_gaussian_head_backward(int64_t M, const float* raw, const float* depths, 
                               float scale_min, float scale_max, const float* g_cov, const float* g_harmonics,
                               const float* g_scales, const float* g_rotations, float* g_raw, float* g_depths,
                               float* g_extrinsics, void* stream);
+
+/*
+ * Per-pixel latents of the fold (encoder_freesplat.py:311-316: `gaussians = head[:, 1:] + skip`, rearranged
+ * "(b v) c h w -> b v (h w) c"; densities from head[:, :1]), ABI 5.  head [V, C + 1, P] and skip [V, C, P] are the channel-major
+ * maps of the depth decoder's last convolution and of the full-resolution skip convolution (C = 64, P = h * w);
+ * latents [V, P, C] = head[:, 1 + c] + skip[:, c] in the pixel-major layout fs_ptf_fold reads, dens [V, P] (optional) = head[:, 0]
+ * (the raw density logit).  One pass through an LDS tile each way instead of torch's add + three transposing copies per
+ * training step.  Backward: g_latents [V, P, C] (NULL = zero), g_dens [V, P] (NULL = zero) -> g_head [V, C + 1, P] (every
+ * channel written), g_skip [V, C, P]; either output may be NULL.
+ */
+int fs_latents_pack_forward(int32_t V, int64_t P, int32_t C, const float* head, const float* skip, float* latents,
+                            float* dens, void* stream);
+int fs_latents_pack_backward(int32_t V, int64_t P, int32_t C, const float* g_latents, const float* g_dens, float* g_head,
+                             float* g_skip, void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * Camera framing of the decoder (cuda_splatting.py:17-44, :64-87; projection.py:233-247) *

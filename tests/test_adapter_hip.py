@@ -84,3 +84,35 @@ def test_gaussian_head_backward_vs_oracle_autograd(hip_device):
     for got, want, name in ((rg.grad, r64.grad, "raw"), (dg.grad, d64.grad, "depths"), (eg.grad, e64.grad, "extrinsics")):
         s = want.abs().max().item()
         assert (got.cpu().double() - want).abs().max().item() <= 2e-4 * s, name
+
+
+@pytest.mark.parametrize("N,h,w", [(1, 8, 8), (3, 37, 41), (2, 64, 96)])
+def test_latents_pack_is_the_reference_expression(hip_device, N, h, w):
+    """fs_latents_pack_forward / _backward against the glue they replace, op for op (encoder_freesplat.py:311-316 on the CPU:
+    `head[:, 1:] + skip` rearranged "(b v) c h w -> b v (h w) c", densities from head[:, :1]): ONE fp32 add per element and
+    pure data movement, so values AND gradients are bit-identical; tiles that end inside the image (h*w not a multiple of 64),
+    a single partial tile, and gradients on one output only."""
+    from freesplat_amd.gaussian_adapter import latents_pack
+    g = torch.Generator().manual_seed(N * 1000 + h)
+    head, skip = torch.randn(N, 65, h, w, generator=g), torch.randn(N, 64, h, w, generator=g)
+    g_lat, g_dens = torch.randn(N, h * w, 64, generator=g), torch.randn(N, h * w, generator=g)
+
+    def ref(head, skip):
+        lat = (head[:, 1:] + skip).reshape(N, 64, h * w).transpose(-1, -2)
+        return lat, head[:, 0].reshape(N, h * w)
+    hc, sc = head.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    rl, rd = ref(hc, sc)
+    ((rl * g_lat).sum() + (rd * g_dens).sum()).backward()
+    hd, sd = head.to(hip_device).requires_grad_(True), skip.to(hip_device).requires_grad_(True)
+    lat, dens = latents_pack(hd, sd)
+    assert lat.shape == (N, h * w, 64) and lat.is_contiguous() and dens.shape == (N, h * w)
+    assert torch.equal(lat.detach().cpu(), rl.detach()) and torch.equal(dens.detach().cpu(), rd.detach())
+    ((lat * g_lat.to(hip_device)).sum() + (dens * g_dens.to(hip_device)).sum()).backward()
+    assert torch.equal(hd.grad.cpu(), hc.grad) and torch.equal(sd.grad.cpu(), sc.grad)
+    # only the latents carry a gradient: the density channel of g_head must be written as zero (not left uninitialised)
+    hd2 = head.to(hip_device).requires_grad_(True)
+    lat2, _ = latents_pack(hd2, skip.to(hip_device))
+    (lat2 * g_lat.to(hip_device)).sum().backward()
+    assert bool((hd2.grad[:, 0] == 0).all()) and torch.equal(hd2.grad[:, 1:].cpu(), hc.grad[:, 1:])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        latents_pack(head, skip)
