@@ -740,7 +740,7 @@ def main():
     if "c3_step" in sections:
         # BASELINE config 3 as written: ONE composed training step at 3 x 968x1296 (bench_c3_step.py)
         import bench_c3_step as bc
-        out["c3_train_step_hotpath"] = section(lambda: bc.bench_c3_step(cx.dev, steps=3, warmup=2))
+        out["c3_train_step_hotpath"] = section(lambda: bc.bench_c3_step(cx.dev, steps=5, warmup=3))
     if cx.rank == 0:
         emit(out)
     if cx.dist_on:

@@ -108,6 +108,7 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
 
 # operand tables per GRU module, valid while the parameters keep their storage and version; weak keys: a table must not
 # outlive its module (a new module may get the same id(), the same parameter addresses and the same version counters)
+_KEEP_BYTES = int(__import__("os").environ.get("FREESPLAT_PTF_KEEP_BYTES", str(8 << 30)))   # see _PtfFold.forward
 _table_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 LAST_FOLD_COUNTS = None   # device tensor [V,4] (kept, fused, appended, state rows) of the last fused fold: bench accounting
 
@@ -426,10 +427,15 @@ class _PtfFold(torch.autograd.Function):
         # rows that exist (one copy of sum_i n_i rows, ~0.3 ms at 10 views): what the backward holds on to is O(V n).
         # The LAST state is only returned (the backward reads states 0 .. V-2): its G, X, E, D stay views of the worst-case
         # buffer unless that would pin more than 256 MB of rows that do not exist.
+        # ... unless the worst-case buffers are small next to the device's memory (FREESPLAT_PTF_KEEP_BYTES, default 8 GiB: config 3's
+        # three views at 968x1296 queue 2.2 GB): then nothing is copied -- the trims were 0.8 ms of rocclr copies per config-3
+        # training step (profiles/r5_c3_step_glue.json) for memory a 288 GB device does not miss.
+        worst = sum((i + 1) * P for i in range(1, V)) * 86 * 4
+        trim = worst > _KEEP_BYTES
         for i in range(1, V - 1):
-            states[i] = tuple(t[: cnt[i][3]].clone() for t in states[i])
+            states[i] = tuple((t[: cnt[i][3]].clone() if trim else t[: cnt[i][3]]) for t in states[i])
         G, X, R, O, E, D = states[V - 1]
-        if (V * P - n) * 84 * 4 > (256 << 20):
+        if trim and (V * P - n) * 84 * 4 > (256 << 20):
             G, X, E, D = (t[:n].clone() for t in (G, X, E, D))
         states[V - 1] = None
         ctx.cnt, ctx.hw, ctx.states, ctx.scratches = cnt, (h, w), states, scratches
