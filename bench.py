@@ -409,6 +409,24 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         out["roofline"]["pipeline_frac_wall"] = alg * n_views_done / dt / 8e12
         if not train and not sh_fp16 and "closeup" not in workload:
             out["roofline"]["pipeline_traffic_per_view"] = traffic_lookup("raster_" + workload[:2])[0]
+        # VALU-issue roofline of the blend kernel: the HBM figure above cannot move for a kernel whose limit is
+        # instruction issue.  Issue cycles per launch = hardware instruction-class counters x microbenchmarked cycles per class
+        # (profiles/tools/valu_roofline.py -> the newest committed profiles/*_valu_roofline.json; PMC counters cannot be
+        # collected inside this run) against 1024 SIMDs x 2.4 GHz x THIS run's isolated launch time.
+        rv = committed_valu_roofline("fs::render_bwd_kernel<" if train else "fs::sort_blend_kernel<")
+        if rv is not None and not sh_fp16 and workload.startswith("c3") and "closeup" not in workload and iso[1] and iso[0] > 0:
+            t_iso = iso[0] / iso[1] * 1e-3
+            peak_cyc = 1024 * 2.4e9 * t_iso
+            out["roofline_valu"] = {"bound": "valu_issue", "kernel": rv["kernel"], "achieved": rv["issue_cycles"] / t_iso / 1e12,
+                                    "peak": 1024 * 2.4e9 / 1e12, "unit": "T SIMD-cycles/s", "frac": rv["issue_cycles"] / peak_cyc,
+                                    "issue_cycles_per_launch": rv["issue_cycles"], "valu_instructions_per_launch": rv["SQ_INSTS_VALU"],
+                                    "mean_cycles_per_instruction": rv["mean_cycles_per_valu_instruction"],
+                                    "hw_valu_busy_frac": rv.get("hw_valu_busy_frac"),
+                                    "hw_dual_issue_frac": rv.get("hw_dual_issue_frac_of_valu_quads"),
+                                    "isolated_launch_ms": t_iso * 1e3, "source": rv["source"],
+                                    "note": "frac = microbenchmark-priced issue cycles / available SIMD cycles; hw_valu_busy_frac = "
+                                            "SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE per XCD): the wave-cycles spent IN "
+                                            "VALU instructions, which at 6 wavefronts per SIMD includes their latency"}
         ksum = sum(out["kernel_ms_per_view"].values())
         if ksum > 0:   # the whole pipeline of one view against the same algorithmic bytes
             out["roofline"]["pipeline_frac_isolated"] = (alg_fwd + (alg_bwd if train else 0)) / (ksum * 1e-3) / 8e12
@@ -429,6 +447,21 @@ def traffic_lookup(workload: str, kernel_prefix=None):
         return fwd_traffic.lookup(workload, kernel_prefix)
     except Exception:
         return None, None
+
+
+def committed_valu_roofline(kernel_prefix: str):
+    """The kernel's entry of the newest committed profiles/*_valu_roofline.json (profiles/tools/valu_roofline.py), or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_roofline.json")), reverse=True):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        # the inference instantiation for the forward metric (<false, false>), the training one otherwise
+        for name in sorted(ks):
+            if name.startswith(kernel_prefix) and (not kernel_prefix.startswith("fs::sort_blend") or name.endswith("<false, false>")):
+                return dict(ks[name], kernel=name, source=os.path.relpath(f, ROOT))
+    return None
 
 
 def committed_traffic(kernel: str):

@@ -180,15 +180,30 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
     # (the differentiable inputs are made ONCE; a step = forward, loss, backward, then dropping the gradients)
     ins = [t.detach().clone().requires_grad_(True) for t in (a[0][0], a[1][0], a[2], a[3], a[4])]
 
-    def train_step(fn):
+    def train_step_sum_loss(fn):
+        """Rounds 3 - 4's harness: a sum() loss over the four outputs, leaves accumulating .grad -- per step 4 reductions, 3 adds,
+        4 copies of the expanded cotangents and 5 clones in AccumulateGrad (the op returns views of ONE zero-filled buffer, which a
+        leaf cannot adopt): ~0.2 ms of harness at 2 views that no caller of the op pays (upstream autograd nodes take the views)."""
         out = fn([ins[0]], [ins[1]], ins[2], ins[3], ins[4], *a[5:])
         sum(o.sum() for o in out).backward()
         for t in ins:
             t.grad = None
         for q in m.gru.parameters():
             q.grad = None
+    cot = None
+
+    def train_step(fn):
+        """forward + backward of the fold with FIXED contiguous cotangents on its four outputs (torch.autograd.grad w.r.t. the five
+        differentiable inputs and the 12 GRU tensors): the op's own training cost."""
+        nonlocal cot
+        out = fn([ins[0]], [ins[1]], ins[2], ins[3], ins[4], *a[5:])
+        if cot is None or cot[0].shape != out[0].shape:
+            gg = torch.Generator(device=dev).manual_seed(3)
+            cot = [torch.randn(o.shape, device=dev, generator=gg) for o in out]
+        torch.autograd.grad(out, ins + list(m.gru.parameters()), cot, allow_unused=True)
     n_tr = max(2, steps // 4)
     dt_train = timed(lambda: train_step(m.fuse_gaussians), n_tr, 2) if train else float("nan")
+    dt_train_sum = timed(lambda: train_step_sum_loss(m.fuse_gaussians), n_tr, 1) if train else float("nan")
     ms_tr_stage = float("nan")
     if train:
         # the library kernels of a training step, event-timed through the stage hooks (a second loop: events off above)
@@ -244,6 +259,10 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
                  "config": {"workload": f"ptf_{V}_views_{h}x{w}", "views": V, "gaussians_in": M_in, "gaussians_out": M_out,
                             "fused_pairs_per_step": [c[1] for c in steps_counts[1:]]},
                  "train_fwd_bwd": {"hip_ms": dt_train * 1e3 if train else None,
+                                   "hip_ms_sum_loss_harness": dt_train_sum * 1e3 if train else None,
+                                   "harness": "hip_ms: torch.autograd.grad with fixed cotangents on the four outputs; "
+                                              "hip_ms_sum_loss_harness: rounds 3 - 4's sum() loss on leaf inputs (adds ~13 torch "
+                                              "kernels of harness per step)",
                                    "roofline": None if not train else {
                                        "bound": "mfma", "kernel": "PTF training step: every library kernel of the fold and its "
                                        "backward (match, GRU, state movement; ptf_gru_bwd_kernel, ptf_gru_dw_kernel, "

@@ -1264,7 +1264,10 @@ __global__ __launch_bounds__(256) void cv_bwd_prep_kernel(
     }
 }
 
-constexpr int kSgTW = 8, kSgTH = 8, kSgG = 4;
+#ifndef FS_SG_TH
+#define FS_SG_TH 8            // (A/B builds: -DFS_SG_TH=4 halves the tile and its LDS: twice the wavefronts per CU, more halo)
+#endif
+constexpr int kSgTW = 8, kSgTH = FS_SG_TH, kSgG = 4;
 #ifdef FS_CV_SG_STATS   // debug build: [0] wave iterations, [1] pixels with a tap in the tile, [2] (tile, plane) cells walked,
 __device__ unsigned long long g_sg_stats[8];   // [3] whole-image fallbacks, [4] cells skipped (behind), [5] box pixels, [6] claim rounds
 #define FS_SG_COUNT(i, n) do { atomicAdd(&g_sg_stats[i], (unsigned long long)(n)); } while (0)
@@ -1501,12 +1504,12 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
     // ---- the tile leaves once, in the caller's [C, h, w] layout (slot q = parity * C/2 + s  ->  channel 2 s + parity) ----
     {
         float* const dmap = d_src + (((size_t)b * K + k) * C) * hw;
-        const int ty = lane >> 3, tx = lane & 7;
-        const bool inside = tx < tw_ && ty < th_;
+        const int ty = lane / TW, tx = lane % TW;
+        const bool inside = lane < NT && tx < tw_ && ty < th_;
         float* const dpx = dmap + (size_t)(ty0 + ty) * w + (tx0 + tx);
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
-            const float4 v = ((const float4*)(acc + lane * ST))[s];
+            const float4 v = ((const float4*)(acc + (lane < NT ? lane : 0) * ST))[s];
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -96,10 +96,14 @@ def encoder_forward(self, context, global_step: int, deterministic: bool = False
     n_raw = V * h * w
     depth_maps = dec["depth_pred_s-1_b1hw"].reshape(b, V, *dec["depth_pred_s-1_b1hw"].shape[1:])
     fused = []
+    # (b = 1, the only batch size the reference's configurations use: the whole tensors, not `x[0:1]` -- a slice's backward
+    #  zero-fills a full-size gradient and copies into it: two 1 GB fills + copies per config-3 training step for the latents)
+    whole = (lambda t: t) if b == 1 else None
     for i in range(b):
         one = slice(i, i + 1)
-        lat, xyz, extr, dep = self.fuse_gaussians([latents[one]], [coords[one]], densities[one], weights[one], depth_maps[i],
-                                                  context["extrinsics"][one], context["intrinsics"][one], (h, w))
+        pick = whole if whole is not None else (lambda t: t[one])
+        lat, xyz, extr, dep = self.fuse_gaussians([pick(latents)], [pick(coords)], pick(densities), pick(weights), depth_maps[i],
+                                                  pick(context["extrinsics"]), pick(context["intrinsics"]), (h, w))
         raw = self.to_gaussians(lat)
         raw = raw.reshape(*raw.shape[:-1], self.cfg.num_surfaces, -1)                    # [1, M, srf, 2 + d_in]
         M = raw.shape[1]

@@ -307,7 +307,9 @@ def _fold_inputs(gaussians, coords, densities, weight_emb, depths, extrinsics, V
         xs, rho, om = c.view(V, P, 3), rh.view(V, P), om.view(V, P)
     else:
         xs, rho, om = c[0, :, :, 0, 0], rh[0, :, :, 0, 0], om[0, :, :, 0, 0]
-    return (_f32c(d(gaussians[0][0])), _f32c(d(xs)), _f32c(d(rho)), _f32c(d(om)), _f32c(d(depths.reshape(V, -1))),
+    g0 = gaussians[0]
+    lat = g0.reshape(V, P, g0.shape[-1]) if g0.shape[0] == 1 else g0[0]      # (a reshape's backward is a view; a select's fills + copies)
+    return (_f32c(d(lat)), _f32c(d(xs)), _f32c(d(rho)), _f32c(d(om)), _f32c(d(depths.reshape(V, -1))),
             _f32c(extrinsics[0].detach()).reshape(V, 16))
 
 

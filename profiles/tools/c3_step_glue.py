@@ -18,7 +18,7 @@ import re
 import sys
 
 STANDIN = re.compile(r"miopen|MIOpen|igemm|Igemm|naive_conv|gridwise|Cijk_|gemm|Gemm|conv|Conv|tanh|upsample_bilinear|threshold|"
-                     r"CatArrayBatchedCopy|col2im|im2col|SubTensorOpWithScalar|transpose_|batched_transpose|wrw|fwd_|bwd_", re.I)
+                     r"CatArrayBatchedCopy|col2im|im2col|SubTensorOpWithScalar|transpose_|batched_transpose|wrw|fwd_|bwd_|clamp_min|relu", re.I)
 
 
 def main(src, steps):

@@ -54,7 +54,10 @@ def main(src):
     rates = json.loads(next(l for l in rate_txt.splitlines() if l.startswith("JSON "))[5:])
     cyc = rates["cycles_at_2.4GHz"]
     mix = json.load(open(os.path.join(ROOT, "profiles", "r5_isa_static_mix.json")))["kernels"]
-    other_cost = sum(cyc[k] for k in ("v_mov_b32", "v_cndmask_b32", "v_cmp_gt_f32", "v_mov_b32_dpp")) / 4
+    # "other" = moves, selects, compares, DPP moves.  Selects are priced in the VOP3 form with an SGPR-pair mask (2.7 cycles: what the
+    # blend loops use, profiles/r5_isa_static_mix.json); the VOP2 form reading VCC measured 11.3 cycles and is listed, not used.
+    cnd = cyc.get("v_cndmask_b32_e64 (SGPR mask)", cyc["v_cndmask_b32"])
+    other_cost = (cyc["v_mov_b32"] + cnd + cyc["v_cmp_gt_f32"] + cyc["v_mov_b32_dpp"]) / 4
     int_cost = sum(cyc[k] for k in ("v_add_u32", "v_and_b32", "v_lshlrev_b32", "v_mad_u32_u24", "v_bfe_u32")) / 5
     trans_cost = sum(cyc[k] for k in ("v_exp_f32", "v_rcp_f32")) / 2
     out = {"what": __doc__.split("\n\n")[0], "issue_cycles_per_instruction_at_2.4GHz": cyc, "counter_ghz": rates["counter_ghz"],

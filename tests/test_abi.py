@@ -215,17 +215,24 @@ def test_traffic_lookup_refuses_kernels_the_library_no_longer_contains():
 
 
 def test_committed_bench_line_honours_the_contract():
-    """The tracked copy of the driver-format bench line (profiles/r4_bench.json, written by `python bench.py` on the GPU box from
-    the final code): every key the bench contract names, the roofline / cpu_baseline objects, BASELINE.json's workload, and the
-    sub-objects the documentation cites -- so that the training headline stays reproducible from a tracked file (the driver's own
-    record truncates the line)."""
+    """The tracked copy of the bench output of the final code (profiles/r5_bench.json = the FULL sectioned line,
+    profiles/r5_bench_headline.json = the compact LAST line the driver parses; both written by `python bench.py` on the GPU box):
+    every key the bench contract names, the roofline / cpu_baseline objects, BASELINE.json's workload, the sub-objects the
+    documentation cites, and the compact line's size."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r4_bench.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r5_bench.json")))
+    raw = open(os.path.join(root, "profiles", "r5_bench_headline.json")).read().strip()
+    hl = json.loads(raw)
+    assert len(raw) <= 4096 and "\n" not in raw                              # VERDICT r4 item 1: the driver parsed nothing of 28 KB
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert k in d, k
+        assert k in hl, k
+    assert abs(hl["value"] - d["value"]) <= 1e-3 * d["value"] and hl["config"]["workload"] == d["config"]["workload"]
+    assert hl["roofline"]["bound"] == "hbm" and hl["cpu_baseline"]["kind"] == "port" and hl["parity"]["bit_exact"] is True
+    assert {"train", "c2", "c3_closeup", "c3_train_step_hotpath", "cost_volume.fvt10_96x128_K8", "ptf.fold_30_views"} <= set(hl["sections"])
     assert d["config"]["workload"] == "c3_968x1296_1M" and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert d["unit"] == "views/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
     assert abs(d["value"] - 16 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
@@ -234,13 +241,20 @@ def test_committed_bench_line_honours_the_contract():
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["frac_isolated"] > r["frac_overlapped"] > 0 and r["traffic"] is not None
+    # the VALU-issue roofline beside it: microbenchmark-priced issue cycles against the SIMD cycles of the launch
+    for blk in (d["roofline_valu"], d["train"]["roofline_valu"]):
+        assert blk["bound"] == "valu_issue" and 0.2 < blk["frac"] < 1.0 and 0.5 < blk["hw_valu_busy_frac"] <= 1.0
+        assert abs(blk["frac"] - blk["issue_cycles_per_launch"] / (1024 * 2.4e9 * blk["isolated_launch_ms"] * 1e-3)) < 1e-6
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "oracle/raster_oracle.c" in c["sample"]
     assert d["parity"]["bit_exact"] is True and d["parity"]["pixels_above_1e-4"] == 0
-    # the sub-objects: training step, config 2, fp16 SH, the three cost-volume shapes (each with the backward's roofline), four folds
+    # the sub-objects: training step, config 2, fp16 SH, the close-up workload, the three cost-volume shapes, four folds
     assert d["train"]["value"] > 1000 and d["train"]["roofline"]["kernel"] == "render_bwd_kernel"
     assert d["c2"]["config"]["workload"].startswith("c2") and d["c3_fp16_sh"]["config"]["sh_storage"] == "fp16"
     assert d["c3_fp16_sh"]["parity"]["bit_exact"] is True
+    cu = d["c3_closeup"]        # every tile list beyond the LDS sort; bit-exact; per list entry no slower than the headline
+    assert cu["parity"]["bit_exact"] is True and cu["config"]["instances_per_gaussian"] >= 19 and cu["views_per_s_per_instance_vs_headline"] >= 0.6
+    assert cu["raster_buffers"]["capacity_retries"] == 1 and cu["raster_buffers"]["scratch_bytes_per_stream"] > 1 << 30
     cv = d["cost_volume"]
     assert set(cv) == {"native_96x128_K1", "c3scale_242x324_K2", "fvt10_96x128_K8"}
     for name, v in cv.items():
@@ -249,16 +263,24 @@ def test_committed_bench_line_honours_the_contract():
         assert abs(b["algorithmic_flops_per_launch"] - 2 * v["roofline"]["algorithmic_flops_per_launch"]) < 1, name
         assert "cpu_baseline" in v and "parity" in v and v["roofline"]["traffic"] is not None and b["traffic"] is not None, name
     assert cv["fvt10_96x128_K8"]["train_fwd_bwd"]["ms"] <= 25 and cv["c3scale_242x324_K2"]["train_fwd_bwd"]["ms"] <= 14
-    assert cv["native_96x128_K1"]["train_fwd_bwd"]["ms"] <= 1.3                       # VERDICT r3 item 1's three targets
+    assert cv["native_96x128_K1"]["train_fwd_bwd"]["ms"] <= 1.3
     assert set(d["ptf"]) == {"fold_2_views", "fold_10_views", "fold_3_views_968x1296", "fold_30_views"}
     for name, v in d["ptf"].items():
         assert v["parity"]["same_count_and_order"] is True and v["roofline"]["bound"] == "hbm" and v["cpu_baseline"]["cores"] <= 16, name
+        assert v["roofline"]["kernel_ms_per_fold"] <= v["ms_per_call"] + 1e-9, name          # 
         tr = v["train_fwd_bwd"]
-        if tr["hip_ms"] is not None:       # the training step's own roofline block ("missing" item 6)
+        if tr["hip_ms"] is not None:
             assert tr["roofline"]["bound"] == "mfma" and 0 < tr["roofline"]["frac"] < 1, name
             assert tr["roofline"]["kernel_ms_per_step"] <= tr["hip_ms"], name
-    assert d["ptf"]["fold_2_views"]["ms_per_call"] <= 0.23 and d["ptf"]["fold_2_views"]["train_fwd_bwd"]["hip_ms"] <= 1.6   # item 7
+    assert d["ptf"]["fold_30_views"]["parity"]["views_compared"] == 10                        # (item 8: was a 4-view prefix)
+    assert d["ptf"]["fold_2_views"]["ms_per_call"] <= 0.23 and d["ptf"]["fold_2_views"]["train_fwd_bwd"]["hip_ms"] <= 1.6
     assert set(d["encoder_tail"]) == {"depth_tail", "gaussian_head"}
+    # BASELINE config 3 as it is written, one composed step: stages sum to the library time, glue <= 10 %
+    st = d["c3_train_step_hotpath"]
+    assert st["config"]["image_hw"] == [968, 1296] and st["config"]["context_views"] == 3 and st["config"]["match_hw"] == [242, 324]
+    assert abs(sum(st["library_kernel_ms_by_stage"].values()) - st["library_kernel_ms"]) < 1e-6
+    assert set(st["library_kernel_ms_by_stage"]) >= {"cost_volume", "ptf", "encoder_tail", "render", "render_bwd", "preprocess", "preprocess_bwd"}
+    assert st["library_kernel_ms"] < st["ms_per_step"] and st["glue_frac_of_gpu_time"] <= 0.10 and st["glue_source"].endswith("_c3_step_glue.json")
 
 
 def test_compact_headline_fits_the_driver_window():
@@ -272,7 +294,7 @@ def test_compact_headline_fits_the_driver_window():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    full = json.load(open(os.path.join(root, "profiles", "r4_bench.json")))
+    full = json.load(open(os.path.join(root, "profiles", "r5_bench.json")))
     h = bench.headline(full)
     line = json.dumps(h)
     assert len(line) <= bench.HEADLINE_MAX_BYTES <= 8192
