@@ -193,6 +193,42 @@ def test_tile_sort_heavy_depth_ties(hip_device, monkeypatch, copies, N):
     assert (np.diff(dbg["offsets"]) > 24).any()
 
 
+@pytest.mark.parametrize("copies,N", [(3, 2500), (2600, 2), (40, 150)])
+def test_long_list_partitioned_sort_with_depth_ties(hip_device, monkeypatch, copies, N):
+    """Tile lists beyond the LDS sort (the two-level distribution sort, round 5) with bit-identical depths: triples spread over
+    7 500 entries (ties inside the groups' buckets), ONE depth value 2 600 times per Gaussian (a single fine bin longer than a
+    group: the global-memory network fallback), and 40-fold ties at 6 000 entries (groups whose LDS sort falls back to its
+    register network).  List order = (depth, index), images bit-exact."""
+    _set_cull(monkeypatch, False)
+    H = W = 32
+    scene, cams = small_scene(N=N, H=H, W=W, seed=21)
+    scene["covariances"] = scene["covariances"] * 400.0
+    scene["opacities"] = scene["opacities"] * 0.01
+    for k in ("means", "covariances", "harmonics", "opacities"):
+        scene[k] = torch.cat([scene[k]] * copies)
+    vi = view_inputs(scene, cams, 0, H, W)
+    st, _, _ = _check_forward(vi, hip_device)
+    assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 2048
+    dbg, _, _ = _internal_state(vi, hip_device)
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    np.testing.assert_array_equal(dbg["n_contrib"], st["n_contrib"])
+
+
+def test_long_list_more_groups_than_the_partitioned_sort_holds(hip_device, monkeypatch):
+    """140 000 entries in ONE tile: more than 64 groups of <= 2048 keys, so sort_tile_partitioned declines and the tile is sorted
+    by the global-memory network; same list as the oracle's stable sort."""
+    _set_cull(monkeypatch, False)
+    H = W = 16
+    scene, cams = small_scene(N=140_000, H=H, W=W, seed=22)
+    scene["covariances"] = scene["covariances"] * 900.0
+    scene["opacities"] = scene["opacities"] * 0.01
+    vi = view_inputs(scene, cams, 0, H, W)
+    st, _, _ = _check_forward(vi, hip_device)
+    assert int(st["ranges"][0, 1] - st["ranges"][0, 0]) > 64 * 2048
+    dbg, _, _ = _internal_state(vi, hip_device)
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+
+
 def test_capacity_overflow_retry(hip_device, monkeypatch):
     from freesplat_amd import rasterizer as R
     scene, cams = small_scene(N=3000, H=64, W=64, seed=8)
