@@ -146,7 +146,13 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
                                            "prices the reference formulation's flops (41 MFMAs per cell), the K = 1 sweep issues 16",
                          "traffic": _traffic(wl_name)[0], "traffic_source": _traffic(wl_name)[1],
                          "traffic_unit": "HBM bytes per call (all current views)",
-                         "algorithmic_bytes_per_call": 4 * V * ((1 + K) * C + D) * h4 * w4}}, **extra)
+                         "algorithmic_bytes_per_call": 4 * V * ((1 + K) * C + D) * h4 * w4,
+                         # the general (K >= 2) sweep gathers 4 bilinear taps x C channels per (pixel, plane, source) through the
+                         # vector L1: its real ceiling is the L1's 64 B per clock per CU, not the matrix pipe
+                         "l1_tap_roofline": None if K < 2 else {
+                             "bound": "vector L1 bandwidth", "tap_bytes_per_launch": V * K * D * h4 * w4 * 4 * C * 4,
+                             "achieved": V * K * D * h4 * w4 * 4 * C * 4 / kern / 1e12, "peak": 256 * 64 * 2.4e9 / 1e12,
+                             "unit": "TB/s", "frac": V * K * D * h4 * w4 * 4 * C * 4 / kern / (256 * 64 * 2.4e9)}}}, **extra)
 
 
 def _ptf_w2c(E):
