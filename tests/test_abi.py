@@ -272,7 +272,7 @@ def test_committed_bench_line_honours_the_contract():
         if tr["hip_ms"] is not None:
             assert tr["roofline"]["bound"] == "mfma" and 0 < tr["roofline"]["frac"] < 1, name
             assert tr["roofline"]["kernel_ms_per_step"] <= tr["hip_ms"], name
-    assert d["ptf"]["fold_30_views"]["parity"]["views_compared"] == 10                        # (item 8: was a 4-view prefix)
+    assert d["ptf"]["fold_30_views"]["parity"]["views_compared"] >= 10                        # (item 8: was a 4-view prefix)
     assert d["ptf"]["fold_2_views"]["ms_per_call"] <= 0.23 and d["ptf"]["fold_2_views"]["train_fwd_bwd"]["hip_ms"] <= 1.6
     assert set(d["encoder_tail"]) == {"depth_tail", "gaussian_head"}
     # BASELINE config 3 as it is written, one composed step: stages sum to the library time, glue <= 10 %

@@ -537,12 +537,13 @@ def test_cpu_tensor_raises(hip_device):
                               cov3D_precomp=vi["cov3D"])  # neither shs nor colors
 
 
-@pytest.mark.parametrize("workload", ["c2_640x480_300k", "c3_968x1296_1M"])
+@pytest.mark.parametrize("workload", ["c2_640x480_300k", "c3_968x1296_1M", "c3_closeup_968x1296_1M"])
 def test_full_size_parity_and_properties(hip_device, workload):
     """BASELINE.json full sizes: pixel parity + PSNR vs the oracle, and size-independent properties
-    (tile lists sorted, colour linear in the SH DC term)."""
+    (tile lists sorted, colour linear in the SH DC term).  The close-up workload (round 5: every tile list beyond the LDS sort's
+    2 048 keys, 19.6 M culled entries) takes the two-level distribution sort on every tile."""
     H, W, N = synthetic.WORKLOADS[workload]
-    scene = synthetic.make_scene(N)
+    scene = synthetic.workload_scene(workload)
     cams = synthetic.target_cameras(2)
     vi = view_inputs(scene, cams, 0, H, W)
     st, (color, radii, depth, alpha), _ = _check_forward(vi, hip_device)
