@@ -61,3 +61,24 @@ def test_cost_volume_inputs_consistent_with_golden_generator():
                                      (h4 * 4, w4 * 4), num_context_views=V)
     for k in ("src_feats", "src_extrinsics", "src_poses", "src_Ks", "cur_invK", "min_depth", "max_depth"):
         np.testing.assert_allclose(out[k].numpy(), kw[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_scale_multiplier_collapses_broadcast_cameras():
+    """GaussianAdapter.get_scale_multiplier (gaussian_adapter.py:203-214) on ONE camera expand()-ed over M Gaussians (what
+    encoder_freesplat.py:378 hands it) inverts the 2x2 once instead of M times (round 5: 3.5 ms of rocsolver per config-3 training
+    step) and broadcasts to the same values; per-camera batches keep one inverse per camera."""
+    import torch
+    from freesplat_amd.gaussian_adapter import GaussianAdapter, GaussianAdapterCfg
+    a = GaussianAdapter(GaussianAdapterCfg(0.5, 15.0, 2))
+    K = torch.tensor([[0.9, 0.02, 0.49], [0.01, 1.2, 0.51], [0, 0, 1.0]])
+    px = 1 / torch.tensor((128.0, 96.0))
+    ref = lambda Ke: (0.1 * torch.einsum("...ij,j->...i", torch.linalg.inv_ex(Ke[..., :2, :2]).inverse, px)).sum(-1)   # :203-214
+    Ke = K[None, None, None, None, None].expand(1, 1, 5000, 1, 1, 3, 3)
+    m = a.get_scale_multiplier(Ke, px)
+    assert m.numel() == 1 and m.shape == (1, 1, 1, 1, 1)
+    assert torch.equal(m.expand(1, 1, 5000, 1, 1), ref(Ke))
+    Kb = torch.stack([K, 1.1 * K, 0.7 * K])[:, None, None, None, None].expand(3, 1, 40, 1, 1, 3, 3)
+    m = a.get_scale_multiplier(Kb, px)
+    assert m.shape == (3, 1, 1, 1, 1) and torch.equal(m.expand(3, 1, 40, 1, 1), ref(Kb))
+    Kf = torch.stack([K * (1 + 0.01 * i) for i in range(6)]).reshape(2, 3, 1, 1, 1, 3, 3)          # nothing broadcast: unchanged
+    assert torch.equal(a.get_scale_multiplier(Kf, px), ref(Kf))

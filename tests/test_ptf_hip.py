@@ -384,3 +384,33 @@ def test_gru_module_forward_and_backward_run_on_the_kernels(hip_device):
         assert (a.reshape(b.shape) - b).abs().max().item() <= 1e-4 * (b.abs().max().item() + 1e-20)
     with pytest.raises(RuntimeError, match="no CPU path"):
         P.GRU()(x.cpu(), hid.cpu(), xe.cpu(), he.cpu())
+
+
+def test_training_fold_with_and_without_state_trims(hip_device, monkeypatch):
+    """_PtfFold.forward keeps the steps' worst-case state buffers when they are small (FREESPLAT_PTF_KEEP_BYTES, round 5) and trims
+    them to the rows that exist above that: both ways the outputs and every gradient are the same bits (the backward reads the
+    same rows either way)."""
+    from freesplat_amd import ptf as P
+    V, h, w = 4, 48, 64
+    E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=77)
+    torch.manual_seed(3)
+    m = P.PixelwiseTripletFusion().to(hip_device)
+    d = lambda t: t.to(hip_device)
+    gen = torch.Generator().manual_seed(5)
+
+    def run():
+        ins = [d(t).requires_grad_(True) for t in (lat, coords, dens, wts, depths)]
+        out = m.fuse_gaussians([ins[0]], [ins[1]], ins[2], ins[3], ins[4], d(E)[None], d(Kn)[None], (h, w))
+        cot = [torch.randn(o.shape, generator=torch.Generator().manual_seed(11 + k)).to(hip_device) for k, o in enumerate(out)]
+        grads = torch.autograd.grad(out, ins + list(m.gru.parameters()), cot, allow_unused=True)
+        return [o.detach() for o in out], grads
+    monkeypatch.setattr(P, "_KEEP_BYTES", 1 << 40)
+    out_keep, g_keep = run()
+    monkeypatch.setattr(P, "_KEEP_BYTES", 0)
+    out_trim, g_trim = run()
+    for a, b in zip(out_keep, out_trim):
+        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(g_keep[:5], g_trim[:5])):       # (input gradients: plain stores / fixed-order sums per row)
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), k
+    for a, b in zip(g_keep[5:], g_trim[5:]):                          # (GRU weights: fixed-order partial sums -> same bits)
+        assert torch.equal(a, b)
