@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import weakref
 
 import torch
@@ -108,7 +109,7 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
 
 # operand tables per GRU module, valid while the parameters keep their storage and version; weak keys: a table must not
 # outlive its module (a new module may get the same id(), the same parameter addresses and the same version counters)
-_KEEP_BYTES = int(__import__("os").environ.get("FREESPLAT_PTF_KEEP_BYTES", str(8 << 30)))   # see _PtfFold.forward
+_KEEP_BYTES = int(os.environ.get("FREESPLAT_PTF_KEEP_BYTES", str(8 << 30)))   # see _PtfFold.forward
 _table_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 LAST_FOLD_COUNTS = None   # device tensor [V,4] (kept, fused, appended, state rows) of the last fused fold: bench accounting
 
