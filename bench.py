@@ -382,8 +382,10 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         if train:
             traffic, traffic_src = (committed_traffic("fs::render_bwd_kernel<" + ("true" if _R_FAST() else "false"))
                                     if workload.startswith("c3") else (None, None))
-        elif sh_fp16 or "closeup" in workload:
+        elif sh_fp16:
             traffic, traffic_src = None, None
+        elif "closeup" in workload:
+            traffic, traffic_src = traffic_lookup("raster_closeup", "fs::sort_blend_kernel")
         else:   # per launch of the fused sort + blend kernel (profiles/tools/fwd_traffic.py)
             traffic, traffic_src = traffic_lookup("raster_" + workload[:2], "fs::sort_blend_kernel")
         out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": 8000.0,
@@ -407,8 +409,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         if iso[1] and iso[0] > 0:
             out["roofline"]["frac_isolated"] = alg / (iso[0] / iso[1] * 1e-3) / 8e12
         out["roofline"]["pipeline_frac_wall"] = alg * n_views_done / dt / 8e12
-        if not train and not sh_fp16 and "closeup" not in workload:
-            out["roofline"]["pipeline_traffic_per_view"] = traffic_lookup("raster_" + workload[:2])[0]
+        if not train and not sh_fp16:
+            out["roofline"]["pipeline_traffic_per_view"] = traffic_lookup("raster_closeup" if "closeup" in workload else "raster_" + workload[:2])[0]
         # VALU-issue roofline of the blend kernel: the HBM figure above cannot move for a kernel whose limit is
         # instruction issue.  Issue cycles per launch = hardware instruction-class counters x microbenchmarked cycles per class
         # (profiles/tools/valu_roofline.py -> the newest committed profiles/*_valu_roofline.json; PMC counters cannot be

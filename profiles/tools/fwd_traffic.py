@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
 
 WORKLOADS = {   # name -> (units per call, default calls)
-    "raster_c3": (16, 4), "raster_c2": (16, 4), "cv_native_K1": (1, 6), "cv_c3scale_K2": (1, 3), "cv_fvt10_K8": (1, 3),
-    "ptf_2_views": (1, 6), "ptf_10_views": (1, 3),
+    "raster_c3": (16, 4), "raster_c2": (16, 4), "raster_closeup": (4, 3), "cv_native_K1": (1, 6), "cv_c3scale_K2": (1, 3), "cv_fvt10_K8": (1, 3),
+    "ptf_2_views": (1, 6), "ptf_10_views": (1, 3), "ptf_3_views": (1, 3),      # (ptf_3_views: 3 views at 968x1296)
     # training steps of the cost volume (forward + backward w.r.t. features and MLP): unit = one step
     "cvt_native_K1": (1, 4), "cvt_c3scale_K2": (1, 2), "cvt_fvt10_K8": (1, 2),
 }
@@ -33,11 +33,16 @@ def run(name, calls):
     if name.startswith("raster"):
         from freesplat_amd import synthetic
         from freesplat_amd.decoder import render_views
-        H, W, N = synthetic.WORKLOADS["c3_968x1296_1M" if name == "raster_c3" else "c2_640x480_300k"]
-        scene = synthetic.make_scene(N)
-        cams = {k: v.to(dev) for k, v in synthetic.target_cameras(16).items()}
+        wl = {"raster_c3": "c3_968x1296_1M", "raster_c2": "c2_640x480_300k", "raster_closeup": "c3_closeup_968x1296_1M"}[name]
+        H, W, N = synthetic.WORKLOADS[wl]
+        scene = synthetic.workload_scene(wl)
+        nv = WORKLOADS[name][0]
+        cams = {k: v.to(dev) for k, v in synthetic.target_cameras(nv).items()}
         g = {k: scene[k].to(dev) for k in ("means", "covariances", "harmonics", "opacities")}
-        bg = torch.zeros(16, 3, device=dev)
+        bg = torch.zeros(nv, 3, device=dev)
+        if name == "raster_closeup":     # (no overflow + re-render inside the traced calls: start from the capacity the bench ends up with)
+            from freesplat_amd import rasterizer as R
+            R._state(dev).note_overflow(24_000_000, 16_000, H, W)
         fn = lambda: render_views(cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"], (H, W), bg, g["means"],
                                   g["covariances"], g["harmonics"], g["opacities"])
     elif name.startswith("cv"):
@@ -60,8 +65,8 @@ def run(name, calls):
     else:
         from test_ptf_hip import _scene
         from freesplat_amd.ptf import PixelwiseTripletFusion
-        V = 2 if name == "ptf_2_views" else 10
-        h, w = 384, 512
+        V = {"ptf_2_views": 2, "ptf_10_views": 10, "ptf_3_views": 3}[name]
+        h, w = (968, 1296) if name == "ptf_3_views" else (384, 512)
         E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=5)
         torch.manual_seed(1)
         m = PixelwiseTripletFusion().to(dev)
