@@ -82,3 +82,47 @@ def test_scale_multiplier_collapses_broadcast_cameras():
     assert m.shape == (3, 1, 1, 1, 1) and torch.equal(m.expand(3, 1, 40, 1, 1), ref(Kb))
     Kf = torch.stack([K * (1 + 0.01 * i) for i in range(6)]).reshape(2, 3, 1, 1, 1, 3, 3)          # nothing broadcast: unchanged
     assert torch.equal(a.get_scale_multiplier(Kf, px), ref(Kf))
+
+
+def test_two_level_distribution_sort_model():
+    """The order sort_tile_partitioned (csrc/raster_fwd.hip, round 5) produces, restated on the CPU: keys = (depth bits << 32 | id
+    word); a 2 048-bin histogram over [zmin, zmax] with the kernel's float bin function, bins grouped greedily into groups of
+    <= 2 048 keys, every group sorted by the full key and the groups concatenated == one stable sort of all keys -- for
+    random depths, heavy ties (equal depths share a bin, hence a group) and a narrow depth band; a single bin longer than a
+    group is the declared fallback."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    NB, CAP = 2048, 2048
+
+    def two_level(keys):
+        z = (keys >> np.uint64(32)).astype(np.uint32)
+        zmin, zmax = z.min(), z.max()
+        scale = np.float32(NB) / np.float32(np.uint32(zmax - zmin) + np.uint32(1))
+        bins = np.minimum(NB - 1, ((z - zmin).astype(np.float32) * scale).astype(np.uint32)).astype(np.int64)
+        assert (np.diff(bins[np.argsort(z, kind="stable")]) >= 0).all()            # the bin function is monotone in the depth bits
+        cnt = np.bincount(bins, minlength=NB)
+        pre = np.concatenate([[0], np.cumsum(cnt)])
+        out, b, groups = [], 0, 0
+        while b < NB:
+            e = int(np.searchsorted(pre, pre[b] + CAP, side="right")) - 1          # largest e with pre[e] - pre[b] <= CAP
+            if e == b:
+                return None                                                        # one bin alone exceeds a group: fallback
+            sel = keys[(bins >= b) & (bins < e)]
+            out.append(np.sort(sel))
+            b, groups = e, groups + 1
+        return np.concatenate(out), groups
+
+    for n, mode in ((2049, "random"), (6000, "random"), (40000, "random"), (9000, "ties"), (5000, "narrow")):
+        if mode == "random":
+            depth = rng.uniform(0.3, 9.0, n).astype(np.float32)
+        elif mode == "ties":
+            depth = np.repeat(rng.uniform(0.3, 9.0, n // 3).astype(np.float32), 3)
+        else:
+            depth = (np.float32(2.0) + rng.integers(0, 300, n).astype(np.float32) * np.float32(2.4e-7)).astype(np.float32)
+        ids = rng.permutation(len(depth)).astype(np.uint64)
+        keys = (depth.view(np.uint32).astype(np.uint64) << np.uint64(32)) | (ids << np.uint64(4)) | np.uint64(5)
+        got = two_level(keys)
+        assert got is not None, (n, mode)
+        assert (got[0] == np.sort(keys)).all() and got[1] >= -(-len(keys) // CAP), (n, mode)
+    same = (np.float32(3.0).view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.arange(2500, dtype=np.uint64) << np.uint64(4))
+    assert two_level(same) is None

@@ -706,7 +706,7 @@ def test_fast_exp_mode_quantified(hip_device, monkeypatch, H, W, N, seed, worklo
     assert float((dbg["n_contrib"] != st["n_contrib"]).mean()) < 1e-4      # termination flips only
 
 
-@pytest.mark.parametrize("N", [2300, 3000, 4000, 5200])
+@pytest.mark.parametrize("N", [2300, 3000, 4000, 5200, 9500, 15000])
 def test_dense_tiles_long_lists(hip_device, monkeypatch, N):
     """Every Gaussian of the scene lands on the same 2x2 tiles: per-tile lists of ~N entries drive the sort paths
     beyond the LDS bucket sort (2048 < n <= 4096: register bitonic networks, two-run and full; n > 4096: the in-place
