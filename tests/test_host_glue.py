@@ -126,3 +126,45 @@ def test_two_level_distribution_sort_model():
         assert (got[0] == np.sort(keys)).all() and got[1] >= -(-len(keys) // CAP), (n, mode)
     same = (np.float32(3.0).view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.arange(2500, dtype=np.uint64) << np.uint64(4))
     assert two_level(same) is None
+
+
+def test_c3_step_glue_classifier_on_a_synthetic_trace(tmp_path):
+    """profiles/tools/c3_step_glue.py (what `c3_train_step_hotpath.glue_*` in the bench line comes from): kernels between the two
+    erfinv marker launches, classified library / stand-in / glue by name and summed per step."""
+    import csv
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows, t = [], 1000
+
+    def k(name, us):
+        nonlocal t
+        rows.append({"Kernel_Name": name, "Start_Timestamp": t, "End_Timestamp": t + us * 1000})
+        t += us * 1000 + 500
+    k("void fs::cost_volume16_kernel<48, false>(int)", 999)                                   # before the window: ignored
+    k("void at::native::vectorized_elementwise_kernel<4, at::native::erfinv_kernel_cuda>(int)", 5)
+    for _ in range(2):                                                                        # two "steps"
+        k("void fs::cost_volume16_kernel<48, false>(int, int)", 2700)
+        k("miopenSp3AsmConv_v30_3_1_gfx9_fp32_f2x3_stride1", 800)
+        k("Cijk_Ailk_Bljk_S_B_Bias_HA_S_SAV_UserArgs_MT64x256x16", 200)
+        k("void at::native::(anonymous namespace)::upsample_bilinear2d_out_frame<float>(int)", 100)
+        k("void at::native::elementwise_kernel_manual_unroll<128, 4, at::native::direct_copy_kernel_cuda>(int)", 400)
+        k("__amd_rocclr_copyBuffer", 50)
+        k("void fs::render_bwd_kernel<false, false>(int)", 1300)
+    k("void at::native::vectorized_elementwise_kernel<4, at::native::erfinv_kernel_cuda>(int)", 5)
+    k("void fs::ptf_gru_kernel<true>(int)", 777)                                              # after the window: ignored
+    d = tmp_path / "trace"
+    d.mkdir()
+    with open(d / "x_kernel_trace.csv", "w", newline="") as f:
+        wr = csv.DictWriter(f, fieldnames=["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        wr.writeheader()
+        wr.writerows(rows)
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "tools", "c3_step_glue.py"), str(d), "2"],
+                         capture_output=True, text=True, check=True).stdout
+    g = json.loads(out)
+    assert g["kernels_in_window"] == 14 and g["steps"] == 2
+    assert g["per_step_ms"] == {"library": 4.0, "standin": 1.1, "glue": 0.45}
+    assert abs(g["glue_frac_of_hotpath_gpu_time"] - 0.45 / 4.45) < 1e-4
+    assert g["top_glue_kernels"][0]["kernel"].endswith("direct_copy_kernel_cuda>") and g["launches_per_step"]["glue"] == 2.0
