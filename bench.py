@@ -649,11 +649,12 @@ def headline(full: dict) -> dict:
                 e["order_ok"] = p["same_count_and_order"]
                 e["views_cmp"] = p.get("views_compared")
             digest[f"{group}.{name}"] = e
-    if isinstance(full.get("c3_train_step_hotpath"), dict):
-        o = full["c3_train_step_hotpath"]
-        digest["c3_train_step_hotpath"] = ({"error": str(o["error"])[:80]} if "error" in o else
-                                           _pick(o, ("ms_per_step", "library_kernel_ms", "glue_ms", "glue_frac_of_gpu_time",
-                                                     "gaussians", "target_views")))
+    for name in ("c3_train_step_hotpath", "c4_eval_step_hotpath"):
+        if isinstance(full.get(name), dict):
+            o = full[name]
+            digest[name] = ({"error": str(o["error"])[:80]} if "error" in o else
+                            {k: v for k, v in _pick(o, ("ms_per_step", "library_kernel_ms", "glue_ms", "glue_frac_of_gpu_time",
+                                                        "gaussians", "target_views")).items() if v is not None})
     h["sections"] = digest
     h["full_line"] = "previous stdout line; gpurun_out/bench_full.json"
     # never exceed the driver's window: drop digest entries (last first) until the line fits
@@ -777,6 +778,10 @@ def main():
         # BASELINE config 3 as written: ONE composed training step at 3 x 968x1296 (bench_c3_step.py)
         import bench_c3_step as bc
         out["c3_train_step_hotpath"] = section(lambda: bc.bench_c3_step(cx.dev, steps=5, warmup=3))
+        # BASELINE config 4's work on ONE of its GPUs as one composed EVALUATION step: 10 context views at the native 384x512, each
+        # matched against its 8 pose-nearest views (num_views = 9), the 10-view fold, 8 rendered target views; no autograd
+        out["c4_eval_step_hotpath"] = section(lambda: bc.bench_c3_step(cx.dev, steps=5, warmup=2, H=384, W=512, V=10, n_targets=8,
+                                                                       train=False, num_views=9, workload="c4_eval_step_hotpath"))
     if cx.rank == 0:
         emit(out)
     if cx.dist_on:

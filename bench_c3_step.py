@@ -97,12 +97,13 @@ class _DepthDecoder(nn.Module):
 class _Encoder(nn.Module):
     """The attributes encoder_forward reads from an EncoderFreeSplat (encoder_freesplat.py:100-188), hot-path members = HIP."""
 
-    def __init__(self, H, W, V, D, C):
+    def __init__(self, H, W, V, D, C, num_views=None):
         super().__init__()
         from freesplat_amd.cost_volume import AVGFeatureVolumeManager
         from freesplat_amd.gaussian_adapter import GaussianAdapter, GaussianAdapterCfg
         from freesplat_amd.ptf import GRU
-        self.cfg = types.SimpleNamespace(num_views=V, num_surfaces=1)
+        # cfg.num_views: how many views enter one cost volume (the view itself + its pose-nearest sources, encoder_freesplat.py:236-254)
+        self.cfg = types.SimpleNamespace(num_views=num_views or V, num_surfaces=1)
         self.max_depth = 1
         torch.manual_seed(11)
         self.backbone = _Backbone(C)
@@ -133,12 +134,13 @@ def committed_glue():
     return None
 
 
-def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_targets=4, trace_steps=0) -> dict:
+def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_targets=4, trace_steps=0, train=True,
+                  num_views=None, workload="c3_train_step_hotpath") -> dict:
     import inputs
     from freesplat_amd import _lib
     from freesplat_amd.decoder import DecoderSplattingCUDA
     from freesplat_amd.encoder_forward import encoder_forward
-    enc = _Encoder(H, W, V, D, C).to(dev)
+    enc = _Encoder(H, W, V, D, C, num_views=num_views).to(dev)
     dec = DecoderSplattingCUDA((0.0, 0.0, 0.0)).to(dev)
     g = torch.Generator().manual_seed(99)
     E, Kn = inputs.cameras(V, H, W, baseline=0.3, seed=5)
@@ -151,6 +153,12 @@ def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_tar
     info = {}
 
     def step():
+        if not train:       # evaluation: test_step's encoder + decoder calls (model_wrapper.py:314-324), no autograd
+            with torch.no_grad():
+                res = encoder_forward(enc, dict(ctx), 0, is_testing=True)
+                out = dec(res["gaussians"][0], tgt_E, tgt_K, near_t, far_t, (H, W), depth_mode=None)
+            info["gaussians"] = int(res["num_gaussians"])
+            return out.color[0, 0, 0, 0, 0]
         for p_ in enc.parameters():
             p_.grad = None
         res = encoder_forward(enc, dict(ctx), 0)
@@ -201,14 +209,15 @@ def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_tar
     # The split of `other` into the stand-in modules' own kernels (out of scope) and the GLUE between the hot-path stages cannot be
     # taken from events (the stand-ins run interleaved with the glue, forward and backward): it comes from a rocprofv3 kernel
     # trace of this same step, every kernel classified by name (profiles/tools/c3_step_glue.py -> profiles/*_c3_step_glue.json).
-    glue = committed_glue()
+    glue = committed_glue() if workload == "c3_train_step_hotpath" else None
     n_g = info["gaussians"]
-    return {"metric": f"composed config-3 training steps/sec ({V} context views @ {H}x{W}, cost volume {H // 4}x{W // 4} K={V - 1} "
-                      f"D={D}, PTF fold, {n_targets} target views, fwd+bwd)",
+    K_src = (num_views or V) - 1
+    return {"metric": f"composed {'training' if train else 'evaluation'} steps/sec ({V} context views @ {H}x{W}, cost volume "
+                      f"{H // 4}x{W // 4} K={K_src} D={D}, PTF fold, {n_targets} target views, {'fwd+bwd' if train else 'forward only'})",
             "value": 1e3 / step_ms, "unit": "steps/s", "ms_per_step": step_ms, "ms_each_step": [round(x, 3) for x in each], "wall_ms_per_step": wall_ms, "steps": steps,
             "dtype": "f32", "data": "synthetic (random images, seeded cameras; stand-in modules for the reference's out-of-scope networks)",
-            "config": {"workload": "c3_train_step_hotpath", "image_hw": [H, W], "context_views": V, "target_views": n_targets,
-                       "depth_planes": D, "match_hw": [H // 4, W // 4], "sources_per_view": V - 1,
+            "config": {"workload": workload, "image_hw": [H, W], "context_views": V, "target_views": n_targets,
+                       "depth_planes": D, "match_hw": [H // 4, W // 4], "sources_per_view": K_src,
                        "raw_gaussians": V * H * W, "gaussians_after_fold": n_g},
             "gaussians": n_g, "target_views": n_targets,
             "library_kernel_ms": lib_ms, "library_kernel_ms_by_stage": stages,
@@ -220,7 +229,7 @@ def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_tar
             "glue_source": None if glue is None else glue["source"],
             "glue_note": "from the committed rocprofv3 kernel trace of this step, kernels classified by name: glue / (library kernels + "
                          "glue); the stand-ins' kernels are left out of the denominator",
-            "loss": float(loss.detach())}
+            "loss": float(loss.detach()) if train else None}
 
 
 if __name__ == "__main__":
@@ -230,10 +239,13 @@ if __name__ == "__main__":
     ap.add_argument("--trace-steps", type=int, default=0,
                     help="run ONLY this many plain steps after the warm-up and print their count (for rocprofv3 --kernel-trace: "
                          "profiles/tools/c3_step_glue.py divides the trace by it)")
+    ap.add_argument("--c4", action="store_true", help="config 4's evaluation step instead: 10 views at 384x512, K = 8, 8 targets, no autograd")
     ap.add_argument("--small", action="store_true", help="config 1's size (256x256, 2 views, D = 16): a quick functional run")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     kw = dict(H=256, W=256, V=2, D=16, n_targets=2) if a.small else {}
+    if a.c4:
+        kw = dict(H=384, W=512, V=10, n_targets=8, train=False, num_views=9, workload="c4_eval_step_hotpath")
     if a.trace_steps:
         kw["trace_steps"] = a.trace_steps
     print(json.dumps(bench_c3_step(dev, a.steps, a.warmup, **kw)))

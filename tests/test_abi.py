@@ -281,6 +281,9 @@ def test_committed_bench_line_honours_the_contract():
     assert abs(sum(st["library_kernel_ms_by_stage"].values()) - st["library_kernel_ms"]) < 1e-6
     assert set(st["library_kernel_ms_by_stage"]) >= {"cost_volume", "ptf", "encoder_tail", "render", "render_bwd", "preprocess", "preprocess_bwd"}
     assert st["library_kernel_ms"] < st["ms_per_step"] and st["glue_frac_of_gpu_time"] <= 0.10 and st["glue_source"].endswith("_c3_step_glue.json")
+    c4 = d["c4_eval_step_hotpath"]          # config 4's per-GPU evaluation step: 10 views at the native size, K = 8, no backward stages
+    assert c4["config"]["context_views"] == 10 and c4["config"]["sources_per_view"] == 8 and c4["config"]["image_hw"] == [384, 512]
+    assert not {"render_bwd", "preprocess_bwd"} & set(c4["library_kernel_ms_by_stage"]) and c4["library_kernel_ms"] < c4["ms_per_step"]
 
 
 def test_compact_headline_fits_the_driver_window():
