@@ -25,7 +25,7 @@ class RasterDims(C.Structure):
                 ("flags", C.c_int32)]
 
 
-ABI_VERSION = 5          # include/freesplat_amd.h FS_ABI_VERSION
+ABI_VERSION = 6          # include/freesplat_amd.h FS_ABI_VERSION
 
 RASTER_TILE_CULL = 1
 RASTER_SH_FP16 = 2
@@ -102,6 +102,7 @@ SIGNATURES = {
     "fs_invert_4x4": (C.c_int, [C.c_int32, _VP, _VP, _VP]),
     "fs_depth_tail_forward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 7),
     "fs_depth_tail_backward": (C.c_int, [C.c_int32] * 4 + [_VP] * 2 + [C.c_int32] + [_VP] * 13),
+    "fs_raster_scratch_slots": (C.c_int, [C.c_int32, C.c_int32]),
     "fs_raster_tile_ranges": (_VP, [_VP, C.c_int32, C.c_int32]),
     "fs_raster_point_list": (_VP, [_VP, C.c_int32, C.c_int32]),
     "fs_raster_geom_records": (_VP, [_VP]),

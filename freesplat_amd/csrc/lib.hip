@@ -79,6 +79,6 @@ FS_API int fs_profile_collect(int n, float* ms_total, int32_t* launches)
     return rc;
 }
 
-FS_API const char* fs_version(void) { return "freesplat_amd 0.5.0 gfx950"; }
+FS_API const char* fs_version(void) { return "freesplat_amd 0.6.0 gfx950"; }
 FS_API int fs_abi_version(void) { return FS_ABI_VERSION; }
 FS_API const char* fs_last_error(void) { return fs::g_last_error; }

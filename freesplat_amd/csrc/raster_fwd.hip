@@ -29,11 +29,31 @@
 //   * tile -> workgroup mapping is XCD-aware and balanced: workgroup b runs on XCD b % 8; tiles are grouped in 4x4
 //     super-tiles (neighbours share most of their Gaussians -> one L2) and super-tile s goes to XCD s % 8
 //     (fs_common.h:tile_for_block).
+#include <stdlib.h>
+#include <string.h>
+
 #include <type_traits>
 
 #include "fs_common.h"
 
 namespace fs {
+
+// value of lane (l ^ M): DPP / ds_swizzle below 32 (no address register), ds_bpermute for 32
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
+{
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+    else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);
+    else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);
+    else return (uint32_t)__shfl_xor((int)v, M, 64);
+}
+template <int M>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long v)
+{
+    const uint32_t lo = lane_xor<M>((uint32_t)v), hi = lane_xor<M>((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 // ------------------------------------------------------------------------------------------
 // preprocess
@@ -261,58 +281,27 @@ __device__ __forceinline__ void stage_rows_half(float* lds, const _Float16* __re
     for (int k = done + threadIdx.x; k < total; k += blockDim.x) lds[k] = (float)s[k];
 }
 
-__global__ __launch_bounds__(256) void preprocess_kernel(
-    fs_raster_dims d, const float* __restrict__ means3D, const float* __restrict__ cov3D,
-    const float* __restrict__ shs, const float* __restrict__ colors,
-    const float* __restrict__ opacities, const float* __restrict__ view,
-    const float* __restrict__ proj, const float* __restrict__ campos,
-    const float* __restrict__ tanfov_dev, const float* __restrict__ scale_dev, GeomView g,
-    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_counts, unsigned long long* __restrict__ keys,
-    uint32_t tile_cap)
+// One Gaussian into one camera: cull (z <= 0.2), EWA conic + 0.3 px^2, 3-sigma radius, tile rect, SH -> RGB, skip threshold.
+// Shared by both projection kernels, so that a Gaussian's record has the same bits whichever launch shape produced it.
+struct Projected {
+    float4 r0, r1, r2;   // the 48-byte screen-space record (fs_common.h)
+    ushort4 rect;
+    uint8_t cb;          // SH clamp bits (backward)
+    int rad;             // 0 = culled
+};
+__device__ __forceinline__ Projected project_gaussian(
+    const fs_raster_dims& d, bool live, float3 p_in, const float (&c_in)[6], float op, size_t i,
+    const float* __restrict__ colors, const float* sh /* this Gaussian's staged SH row (LDS) */, int sh_cs, int sh_ks,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+    float tanfovx, float tanfovy, bool rescale, float wscale)
 {
-    const float tanfovx = tanfov_dev ? tanfov_dev[0] : d.tanfovx;
-    const float tanfovy = tanfov_dev ? tanfov_dev[1] : d.tanfovy;
-    const float wscale = scale_dev ? scale_dev[0] : 1.0f;  // scale-invariant rescale (1/near)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    FS_PT(0, 0);
-    const int base = blockIdx.x * 256;
-    const int cnt = min(256, d.N - base);
-    const int per_sh = d.M * 3;
-    const bool sh_cm = (d.flags & FS_RASTER_SH_CHANNEL_MAJOR) != 0;
-    const int sh_cs = sh_cm ? d.M : 1, sh_ks = sh_cm ? 1 : 3;
-    const int per_cov = (d.flags & FS_RASTER_COV_FULL) ? 9 : 6;
-    float* l_sh = lds;                                   // [256 * per_sh]: the only rows wide enough to need staging
-    if (shs) {
-        if (d.flags & FS_RASTER_SH_FP16) stage_rows_half(l_sh, (const _Float16*)shs, base, cnt, per_sh);
-        else stage_rows(l_sh, shs, base, cnt, per_sh);
-    }
-    const int t = threadIdx.x;
-    const bool live = t < cnt;
-    const int i = base + t;
-    // mean (12 B) and covariance (24 / 36 B) rows straight into registers: a wavefront's rows are one contiguous
-    // 0.8 - 2.3 KB range, every fetched line is fully used
-    float3 p_in = make_float3(0.0f, 0.0f, 0.0f);
-    float c_in[6] = {0, 0, 0, 0, 0, 0};
-    if (live) {
-        p_in = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
-        if (per_cov == 9) {  // row-major 3x3, upper triangle
-            const float* cr = cov3D + 9 * (size_t)i;
-            c_in[0] = cr[0]; c_in[1] = cr[1]; c_in[2] = cr[2]; c_in[3] = cr[4]; c_in[4] = cr[5]; c_in[5] = cr[8];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) c_in[k] = cov3D[6 * (size_t)i + k];
-        }
-    }
-    __syncthreads();
-    FS_PT(0, 1);  // inputs staged
-
-    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
-    ushort4 rect = make_ushort4(0, 0, 0, 0);
-    uint8_t cb = 0;
-    int rad = 0;
-
+    Projected o;
+    o.r0 = make_float4(0, 0, 0, 0); o.r1 = o.r0; o.r2 = o.r0;
+    o.rect = make_ushort4(0, 0, 0, 0);
+    o.cb = 0;
+    o.rad = 0;
     float3 p = p_in;
-    if (scale_dev) { p.x = p.x * wscale; p.y = p.y * wscale; p.z = p.z * wscale; }
+    if (rescale) { p.x = p.x * wscale; p.y = p.y * wscale; p.z = p.z * wscale; }
     const float3 pv = xform43(view, p);
     if (live && pv.z > 0.2f) {
         const float4 ph = xform44(proj, p);
@@ -322,7 +311,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         float c3[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) c3[k] = c_in[k];
-        if (scale_dev) {
+        if (rescale) {
             const float s2 = wscale * wscale;
 #pragma unroll
             for (int k = 0; k < 6; ++k) c3[k] = c3[k] * s2;
@@ -347,22 +336,20 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             if ((x1 - x0) * (y1 - y0) > 0) {
                 float rgb[3];
                 if (colors) {
-                    rgb[0] = colors[3 * (size_t)i];
-                    rgb[1] = colors[3 * (size_t)i + 1];
-                    rgb[2] = colors[3 * (size_t)i + 2];
+                    rgb[0] = colors[3 * i];
+                    rgb[1] = colors[3 * i + 1];
+                    rgb[2] = colors[3 * i + 2];
                 } else {
                     float3 dir = make_float3(p.x - campos[0], p.y - campos[1], p.z - campos[2]);
                     const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                     dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
-                    const float* sh = l_sh + (size_t)t * per_sh;
                     switch (d.sh_degree) {
-                        case 0: eval_sh<0>(sh, dir, rgb, cb, sh_cs, sh_ks); break;
-                        case 1: eval_sh<1>(sh, dir, rgb, cb, sh_cs, sh_ks); break;
-                        case 2: eval_sh<2>(sh, dir, rgb, cb, sh_cs, sh_ks); break;
-                        default: eval_sh<3>(sh, dir, rgb, cb, sh_cs, sh_ks); break;
+                        case 0: eval_sh<0>(sh, dir, rgb, o.cb, sh_cs, sh_ks); break;
+                        case 1: eval_sh<1>(sh, dir, rgb, o.cb, sh_cs, sh_ks); break;
+                        case 2: eval_sh<2>(sh, dir, rgb, o.cb, sh_cs, sh_ks); break;
+                        default: eval_sh<3>(sh, dir, rgb, o.cb, sh_cs, sh_ks); break;
                     }
                 }
-                const float op = opacities[i];
                 // Conservative skip threshold for the blend loop: alpha = op*exp(power) < 1/255
                 // whenever power < log(1/(255 op)) - margin.  Pure optimisation: pairs inside the
                 // margin are evaluated exactly, so the result never depends on this value.
@@ -373,15 +360,263 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 } else {
                     thr = 1.0f;  // power <= 0 < thr: never contributes
                 }
-                r0 = make_float4(px, py, -0.5f * cA, -0.5f * cC);
-                r1 = make_float4(-cB, op, thr, pv.z);
-                r2 = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
-                rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1,
-                                    (unsigned short)y1);
-                rad = r;
+                o.r0 = make_float4(px, py, -0.5f * cA, -0.5f * cC);
+                o.r1 = make_float4(-cB, op, thr, pv.z);
+                o.r2 = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+                o.rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1,
+                                      (unsigned short)y1);
+                o.rad = r;
             }
         }
     }
+    return o;
+}
+
+// Mean (12 B) and covariance (24 / 36 B) rows straight into registers: a wavefront's rows are one contiguous
+// 0.8 - 2.3 KB range, every fetched line is fully used.
+__device__ __forceinline__ void load_mean_cov(const fs_raster_dims& d, const float* __restrict__ means3D,
+                                              const float* __restrict__ cov3D, size_t i, float3& p_in, float (&c_in)[6])
+{
+    p_in = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    if (d.flags & FS_RASTER_COV_FULL) {  // row-major 3x3, upper triangle
+        const float* cr = cov3D + 9 * i;
+        c_in[0] = cr[0]; c_in[1] = cr[1]; c_in[2] = cr[2]; c_in[3] = cr[4]; c_in[4] = cr[5]; c_in[5] = cr[8];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c_in[k] = cov3D[6 * i + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// preprocess_views: projection + binning of ALL views of a call in one launch ("one launch set for
+// all v target views").  A workgroup owns CH chunks of 64 consecutive Gaussians; their SH rows are staged in LDS once and
+// mean / covariance / opacity sit in registers for the whole launch, so the 148-160 B per Gaussian are read ONCE for the
+// v views (the per-view kernel of rounds 1-5 re-read them v times: 279 MB of its traffic per view).  Wavefront w works
+// on chunk w % CH and the views w / CH, w / CH + 4 / CH, ...: the view index is wave-uniform (camera matrices arrive by
+// scalar loads) and the BINNING IS WAVEFRONT-PRIVATE -- the 64 Gaussians of a chunk are neighbours on screen, their tile
+// box (median 44 tiles at config 3) gets its counters in the wavefront's own 2 KB of LDS, and the count / reserve / write
+// phases are separated by wave-level fences only.  After the staging barrier the four wavefronts never meet again: the
+// returning global atomics and record stores of one view overlap the arithmetic of another.
+//   CH = 1: v >= 4 (4 views in flight per workgroup)   CH = 2: v == 2   CH = 4: v == 1 or 3 (every wavefront its own chunk)
+// ------------------------------------------------------------------------------------------
+constexpr int kWaveBins = 512;   // tiles of a wavefront's bounding box whose counters live in LDS (config 3: 99.9 % of the boxes)
+
+__device__ __forceinline__ void bin_wave(const fs_raster_dims& d, int lane, uint32_t* s_cnt, uint32_t i, const Projected& pr,
+                                         uint32_t* __restrict__ tile_counts, unsigned long long* __restrict__ keys,
+                                         uint32_t tile_cap)
+{
+    const float4 r0 = pr.r0, r1 = pr.r1;
+    const ushort4 rect = pr.rect;
+    const bool valid = pr.rad > 0;
+    const bool cull = (d.flags & FS_RASTER_TILE_CULL) != 0;
+    const int gx = (d.W + kTile - 1) / kTile;
+    const QuadForm qf = quad_form(r0, r1);
+    const int area = (rect.z - rect.x) * (rect.w - rect.y);
+    const bool small = area <= 16;
+    unsigned long long qm = 0;
+    if (valid && small) qm = pack_quad_masks(qf, r0, rect);
+    // key = depth bits : (gaussian id << 4 | quadrant mask); the mask is a function of (id, tile), so
+    // ordering by the key is ordering by (depth, id)
+    const unsigned long long key_hi = ((unsigned long long)__float_as_uint(r1.w) << 32) | (i << 4);
+    // the wavefront's tile box (shuffles; two 16-bit fields per exchange)
+    int x0 = valid ? (int)rect.x : 0x7fff, y0 = valid ? (int)rect.y : 0x7fff;
+    int x1 = valid ? (int)rect.z : 0, y1 = valid ? (int)rect.w : 0;
+#define FS_BOX_STEP(M)                                                                                           \
+    {                                                                                                            \
+        const int lo = (int)lane_xor<M>((uint32_t)((x0 << 16) | y0)), hi = (int)lane_xor<M>((uint32_t)((x1 << 16) | y1)); \
+        x0 = min(x0, lo >> 16); y0 = min(y0, lo & 0xffff);                                                       \
+        x1 = max(x1, hi >> 16); y1 = max(y1, hi & 0xffff);                                                       \
+    }
+    FS_BOX_STEP(32) FS_BOX_STEP(16) FS_BOX_STEP(8) FS_BOX_STEP(4) FS_BOX_STEP(2) FS_BOX_STEP(1)
+#undef FS_BOX_STEP
+    const int bx0 = __builtin_amdgcn_readfirstlane(x0), by0 = __builtin_amdgcn_readfirstlane(y0);
+    const int bw = max(0, __builtin_amdgcn_readfirstlane(x1) - bx0), bh = max(0, __builtin_amdgcn_readfirstlane(y1) - by0);
+    const int nb = bw * bh;
+    if (nb == 0) return;   // (wave-uniform) nothing of this chunk is on screen
+    if (nb <= kWaveBins) {
+        for (int k = lane; k < nb; k += 64) s_cnt[k] = 0u;
+        wave_lds_sync();
+        if (valid) {
+            int k = 0;
+            for (int y = rect.y; y < rect.w; ++y) {
+                RowBands rb = {};
+                if (!small) rb = row_bands(qf, r0, y);
+                for (int x = rect.x; x < rect.z; ++x, ++k) {
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
+                    if (!cull || m) atomicAdd(&s_cnt[(y - by0) * bw + (x - bx0)], 1u);
+                }
+            }
+        }
+        wave_lds_sync();
+        // first slot of this wavefront in each touched tile's key area (one returning global atomic per touched tile)
+        for (int k0 = 0; k0 < nb; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < nb) {
+                const uint32_t c = s_cnt[k];
+                const int ky = k / bw, kx = k - ky * bw;
+                s_cnt[k] = c ? atomicAdd(&tile_counts[(by0 + ky) * gx + bx0 + kx], c) : 0u;
+            }
+        }
+        wave_lds_sync();
+        if (valid) {
+            int k = 0;
+            for (int y = rect.y; y < rect.w; ++y) {
+                RowBands rb = {};
+                if (!small) rb = row_bands(qf, r0, y);
+                for (int x = rect.x; x < rect.z; ++x, ++k) {
+                    const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
+                    if (!cull || m) {
+                        const uint32_t slot = atomicAdd(&s_cnt[(y - by0) * bw + (x - bx0)], 1u);
+                        // (tile * tile_cap + slot < 2^32: tile_capacity() bounds the product)
+                        if (slot < tile_cap) keys[(uint32_t)(y * gx + x) * tile_cap + slot] = key_hi | m;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();   // (the wavefront's next view reuses the counters)
+    } else if (valid) {    // a chunk that wraps around an image row of the context view: straight to the global counters
+        int k = 0;
+        for (int y = rect.y; y < rect.w; ++y) {
+            RowBands rb = {};
+            if (!small) rb = row_bands(qf, r0, y);
+            for (int x = rect.x; x < rect.z; ++x, ++k) {
+                const uint32_t m = small ? (uint32_t)(qm >> (4 * k)) & 15u : quad_mask_row(rb, r0, x);
+                if (!cull || m) {
+                    const uint32_t slot = atomicAdd(&tile_counts[y * gx + x], 1u);
+                    if (slot < tile_cap) keys[(uint32_t)(y * gx + x) * tile_cap + slot] = key_hi | m;
+                }
+            }
+        }
+    }
+}
+
+// the tile counters of nv views (view k's at base + k * stride bytes) in one launch
+__global__ __launch_bounds__(256) void zero_counts_kernel(char* base, size_t stride, int T)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < T) ((uint32_t*)(base + stride * blockIdx.y))[k] = 0u;
+}
+
+// per-view arrays of a call: view i's buffer = base + i * stride (bytes)
+struct ViewBuffers {
+    char* geom; size_t geom_stride;
+    char* scratch; size_t scratch_stride;     // [T] tile counts | [T x tile_cap] keys
+    int32_t* radii;                           // [v, N] | nullptr
+};
+
+#ifdef FS_PRE_WAVES      // (A/B builds: make VARIANT=pw5 EXTRA=-DFS_PRE_WAVES=5)
+#define FS_PRE_OCC __attribute__((amdgpu_waves_per_eu(FS_PRE_WAVES, FS_PRE_WAVES)))
+#else
+#define FS_PRE_OCC
+#endif
+template <int CH>
+__global__ __launch_bounds__(256) FS_PRE_OCC void preprocess_views_kernel(
+    fs_raster_dims d, int v, const float* __restrict__ means3D, const float* __restrict__ cov3D,
+    const float* __restrict__ shs, const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+    const float* __restrict__ tanfov_dev, const float* __restrict__ scale_dev, ViewBuffers vb, uint32_t tile_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int kPerBlock = 64 * CH;
+    const int base = blockIdx.x * kPerBlock;
+    const int cnt = min(kPerBlock, d.N - base);
+    const int per_sh = shs ? d.M * 3 : 0;
+    const bool sh_cm = (d.flags & FS_RASTER_SH_CHANNEL_MAJOR) != 0;
+    const int sh_cs = sh_cm ? d.M : 1, sh_ks = sh_cm ? 1 : 3;
+    float* const l_sh = lds;   // [64 * CH * per_sh]: the only rows wide enough to need staging
+    if (shs) {
+        if (d.flags & FS_RASTER_SH_FP16) stage_rows_half(l_sh, (const _Float16*)shs, base, cnt, per_sh);
+        else stage_rows(l_sh, shs, base, cnt, per_sh);
+    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int chunk = wave % CH;
+    uint32_t* const s_cnt = (uint32_t*)(lds + (size_t)kPerBlock * per_sh) + wave * kWaveBins;
+    const int li = chunk * 64 + lane;            // this thread's Gaussian inside the workgroup's slab
+    const bool live = li < cnt;
+    const uint32_t i = (uint32_t)(base + li);
+    float3 p_in = make_float3(0.0f, 0.0f, 0.0f);
+    float c_in[6] = {0, 0, 0, 0, 0, 0};
+    float op = 0.0f;
+    if (live) {
+        load_mean_cov(d, means3D, cov3D, i, p_in, c_in);
+        op = opacities[i];
+    }
+    __syncthreads();   // SH rows staged; the wavefronts go their own ways from here
+    const int T = num_tiles(d.H, d.W);
+    const size_t keys_off = align_up((size_t)T * 4, 256);
+#pragma nounroll
+    for (int j0 = wave / CH; j0 < v; j0 += 4 / CH) {
+        const int j = __builtin_amdgcn_readfirstlane(j0);
+        // (opaque per iteration: otherwise the LDS address of every SH coefficient and the lane-derived shuffle addresses are
+        //  hoisted out of the view loop and stay live across it -- 158 registers instead of ~80)
+        int li_ = li, lane_ = lane;
+        asm volatile("" : "+v"(li_), "+v"(lane_));
+        const float tanfovx = tanfov_dev ? tanfov_dev[2 * j] : d.tanfovx;
+        const float tanfovy = tanfov_dev ? tanfov_dev[2 * j + 1] : d.tanfovy;
+        const float wscale = scale_dev ? scale_dev[j] : 1.0f;  // scale-invariant rescale (1/near)
+        const Projected pr = project_gaussian(d, live, p_in, c_in, op, i, colors, l_sh + (size_t)li_ * per_sh, sh_cs, sh_ks,
+                                              view + 16 * j, proj + 16 * j, campos + 3 * j, tanfovx, tanfovy,
+                                              scale_dev != nullptr, wscale);
+        if (live) {
+            const GeomView g = geom_view(vb.geom + vb.geom_stride * j, d.N);
+            g.rec[3 * (size_t)i + 0] = pr.r0;
+            g.rec[3 * (size_t)i + 1] = pr.r1;
+            g.rec[3 * (size_t)i + 2] = pr.r2;
+            if (!(d.flags & FS_RASTER_NO_BACKWARD_STATE)) {   // (only the backward reads these)
+                g.rect[i] = pr.rect;
+                g.clamp[i] = pr.cb;
+            }
+            if (vb.radii) vb.radii[(size_t)j * d.N + i] = pr.rad;
+        }
+        char* const sc = vb.scratch + vb.scratch_stride * j;
+        bin_wave(d, lane_, s_cnt, i, pr, (uint32_t*)sc, (unsigned long long*)(sc + keys_off), tile_cap);
+    }
+}
+
+// The per-view projection + binning kernel of rounds 3 - 5 (one workgroup = 256 Gaussians, workgroup-wide binning with
+// four barriers): kept for same-session A/Bs against preprocess_views_kernel (FREESPLAT_PREPROCESS=legacy).
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    fs_raster_dims d, const float* __restrict__ means3D, const float* __restrict__ cov3D,
+    const float* __restrict__ shs, const float* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ campos,
+    const float* __restrict__ tanfov_dev, const float* __restrict__ scale_dev, GeomView g,
+    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_counts, unsigned long long* __restrict__ keys,
+    uint32_t tile_cap)
+{
+    const float tanfovx = tanfov_dev ? tanfov_dev[0] : d.tanfovx;
+    const float tanfovy = tanfov_dev ? tanfov_dev[1] : d.tanfovy;
+    const float wscale = scale_dev ? scale_dev[0] : 1.0f;  // scale-invariant rescale (1/near)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    FS_PT(0, 0);
+    const int base = blockIdx.x * 256;
+    const int cnt = min(256, d.N - base);
+    const int per_sh = d.M * 3;
+    const bool sh_cm = (d.flags & FS_RASTER_SH_CHANNEL_MAJOR) != 0;
+    const int sh_cs = sh_cm ? d.M : 1, sh_ks = sh_cm ? 1 : 3;
+    float* l_sh = lds;                                   // [256 * per_sh]: the only rows wide enough to need staging
+    if (shs) {
+        if (d.flags & FS_RASTER_SH_FP16) stage_rows_half(l_sh, (const _Float16*)shs, base, cnt, per_sh);
+        else stage_rows(l_sh, shs, base, cnt, per_sh);
+    }
+    const int t = threadIdx.x;
+    const bool live = t < cnt;
+    const int i = base + t;
+    float3 p_in = make_float3(0.0f, 0.0f, 0.0f);
+    float c_in[6] = {0, 0, 0, 0, 0, 0};
+    float op = 0.0f;
+    if (live) {
+        load_mean_cov(d, means3D, cov3D, (size_t)i, p_in, c_in);
+        op = opacities[i];
+    }
+    __syncthreads();
+    FS_PT(0, 1);  // inputs staged
+    const Projected pr = project_gaussian(d, live, p_in, c_in, op, (size_t)i, colors, l_sh + (size_t)t * per_sh, sh_cs, sh_ks,
+                                          view, proj, campos, tanfovx, tanfovy, scale_dev != nullptr, wscale);
+    const float4 r0 = pr.r0, r1 = pr.r1, r2 = pr.r2;
+    const ushort4 rect = pr.rect;
+    const uint8_t cb = pr.cb;
+    const int rad = pr.rad;
     FS_PT(0, 2);  // projected
     if (live) {
         g.rec[3 * (size_t)i + 0] = r0;
@@ -468,13 +703,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// tile_scan: exclusive scan over T tile counts (T ~ 5e3; one workgroup of 1024)
+// tile_scan: exclusive scan over T tile counts (T ~ 5e3; one workgroup of 1024 per view: workgroup b scans view b's
+// counters at counts0 + b * counts_stride bytes into offsets0 + b * offsets_stride bytes and counters0 + 2 b)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ counts,
-                                                         uint32_t* __restrict__ offsets, int T,
-                                                         uint32_t* __restrict__ counters,
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const char* __restrict__ counts0, size_t counts_stride,
+                                                         char* __restrict__ offsets0, size_t offsets_stride, int T,
+                                                         uint32_t* __restrict__ counters0,
                                                          unsigned long long cap, uint32_t tile_cap)
 {
+    const uint32_t* __restrict__ counts = (const uint32_t*)(counts0 + counts_stride * blockIdx.x);
+    uint32_t* __restrict__ offsets = (uint32_t*)(offsets0 + offsets_stride * blockIdx.x);
+    uint32_t* __restrict__ counters = counters0 + 2 * blockIdx.x;
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max[16];
     __shared__ unsigned long long s_wide[16];
@@ -571,22 +810,6 @@ __device__ __forceinline__ void bitonic_sort_any(Ptr a, uint32_t n)
 // of the 66 barrier-separated LDS passes of the plain network.  Same "flip" network as
 // bitonic_sort_any (all compare-exchanges ascending), so padding keys of ~0 stay at the top.
 // ------------------------------------------------------------------------------------------
-template <int M>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
-{
-    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
-    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
-    else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);
-    else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);
-    else return (uint32_t)__shfl_xor((int)v, M, 64);
-}
-template <int M>
-__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long v)
-{
-    const uint32_t lo = lane_xor<M>((uint32_t)v), hi = lane_xor<M>((uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // Exchange with thread t ^ TM; REV: partner's keys are taken in reversed order (flip step).
 template <int EPT, int TM, bool REV>
 __device__ __forceinline__ void thread_exchange(unsigned long long (&k)[EPT], int t, unsigned long long* lds)
@@ -973,6 +1196,11 @@ __device__ __forceinline__ bool sort_tile_partitioned(
             }
         }
         __syncthreads();
+        // The group must have received exactly the keys the histogram counted for its bins.  It always has when this function
+        // is inlined; as a separate (noinline) function the second group's count came out wrong on gfx950 / ROCm 7.2
+        // (profiles/r5_long_sort_debug.txt, root cause not found: ADVICE r5).  Should a toolchain change bring that back, the
+        // tile declines here and takes the global network -- slower, never wrong.  (workgroup-uniform: read after the barrier)
+        if (s_red[12] != m) return false;
         int tt = t;
         asm volatile("" : "+v"(tt));   // opaque per iteration (see sort_tile_buckets)
         sort_tile_buckets<kSortLds / 256>(sk, gl + off, m, sk, cnt, s_red, tt);
@@ -1161,8 +1389,10 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
 // list words stay in LDS, then each wavefront blends its own quadrant from them without another workgroup barrier.
 // LDS: 16 KiB key staging (reused as the four wavefronts' compaction areas once the sort is done) + 8 KiB bucket
 // offsets (reused as the sorted list) = 24.2 KiB -> 6 workgroups per CU, 6 wavefronts per SIMD.
-// Lists longer than the LDS sort's 2048 keys (none in the BASELINE configs) are sorted into the saved list in global
-// memory by the register / global bitonic networks and blended from there.
+// Lists longer than the LDS sort's 2048 keys (none in the BASELINE configs; every tile of the c3_closeup workload) are
+// sorted into the saved list in global memory by the two-level distribution sort (sort_tile_partitioned: histogram ->
+// groups of <= 2048 keys -> one LDS bucket sort per group) and blended from there; a tile it declines (thousands of equal
+// depths, > 64 groups, a group whose compacted count disagrees with the histogram) falls back to the in-place global network.
 // ------------------------------------------------------------------------------------------
 static_assert(4 * kPairArea * sizeof(float4) <= kSortLds * sizeof(unsigned long long), "compaction areas must fit the key staging");
 template <bool FAST_EXP, bool TRACK>
@@ -1263,17 +1493,29 @@ FS_API const int32_t* fs_raster_n_contrib(const void* image, int32_t H, int32_t 
     return (const int32_t*)((const char*)image + align_up((size_t)H * W * 4, 256));
 }
 
-FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
-                             const float* shs, const float* colors_precomp, const float* opacities,
-                             const float* bg, const float* viewmatrix, const float* projmatrix,
-                             const float* campos, const float* tanfov_dev, const float* scale_dev,
-                             void* geom, void* binning, void* image, void* scratch, int64_t cap, float* out_color, float* out_depth,
-                             float* out_alpha, int32_t* radii, uint32_t* counters, void* stream_)
+namespace fs {
+// FREESPLAT_PREPROCESS=legacy: the per-view projection kernel of rounds 3 - 5 (same-session A/Bs)
+static bool legacy_preprocess()
 {
-    if (!dims || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
-        !scratch || !out_color || !out_depth || !out_alpha || !counters)
-        return FS_ERR_INVALID_ARG;
-    const fs_raster_dims d = *dims;
+    static const bool on = [] { const char* e = getenv("FREESPLAT_PREPROCESS"); return e && strcmp(e, "legacy") == 0; }();
+    return on;
+}
+constexpr int kMaxViewsInFlight = 16;   // key areas (scratch slots) a multi-view call may use at once
+// FREESPLAT_RASTER_BATCH: views per projection launch of a multi-view call (default 16 = all views of a call in flight).  The blends of one batch run on the
+// side streams while the projection of the next batch runs on the main stream.
+static int raster_batch()
+{
+    static const int n = [] {
+        const char* e = getenv("FREESPLAT_RASTER_BATCH");
+        const int x = e ? atoi(e) : 16;
+        return x < 1 ? 1 : (x > kMaxViewsInFlight ? kMaxViewsInFlight : x);
+    }();
+    return n;
+}
+
+static int check_forward_args(const fs_raster_dims& d, const float* means3D, const float* cov3D, const float* shs,
+                              const float* colors_precomp, const float* opacities, const int32_t* radii, int64_t cap)
+{
     if (d.N < 0 || d.H <= 0 || d.W <= 0 || cap < 1) return FS_ERR_INVALID_ARG;
     if (d.N > 0) {  // an empty Gaussian set renders the background; its arrays may be NULL
         if (!means3D || !cov3D || !opacities || !radii) return FS_ERR_INVALID_ARG;
@@ -1285,11 +1527,57 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     if (gx > 32767 || gy > 32767) return FS_ERR_UNSUPPORTED;  // tile coordinates travel as 15-bit fields (ushort4 rects, packed shuffles)
     if (d.N > (1 << 28)) return FS_ERR_UNSUPPORTED;  // list entries are (id << 4 | quadrant mask)
     if (cap > 0xFFFFFFFFll) return FS_ERR_UNSUPPORTED;  // tile ranges are 32-bit
-    hipStream_t st = (hipStream_t)stream_;
+    return FS_OK;
+}
+
+// Projection + binning + tile ranges of `nv` views in ONE launch set on `st`: a 2-D fill of the views' tile counters, the
+// projection of every Gaussian into the nv cameras (preprocess_views_kernel) and one scan workgroup per view.  All per-view
+// pointers address the FIRST of the nv views; view k's buffers lie k strides further.
+static int launch_binning(const fs_raster_dims& d, int nv, const float* means3D, const float* cov3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* viewmatrix,
+                          const float* projmatrix, const float* campos, const float* tanfov, const float* scale,
+                          void* geom, size_t geom_stride, void* binning, size_t binning_stride, void* scratch,
+                          size_t scratch_stride, int64_t cap, int32_t* radii, uint32_t* counters, hipStream_t st)
+{
+    const int T = num_tiles(d.H, d.W);
+    const uint32_t tile_cap = tile_capacity(cap, T);
+    hipLaunchKernelGGL(zero_counts_kernel, dim3((T + 255) / 256, nv), dim3(256), 0, st, (char*)scratch, scratch_stride, T);
+    FS_CHECK_LAUNCH("zero tile counts");
+    if (d.N > 0) {
+        const int M = shs ? d.M : 0;
+        ViewBuffers vb;
+        vb.geom = (char*)geom; vb.geom_stride = geom_stride;
+        vb.scratch = (char*)scratch; vb.scratch_stride = scratch_stride;
+        vb.radii = radii;
+        const int ch = nv >= 4 ? 1 : (nv == 2 ? 2 : 4);
+        const size_t lds = (size_t)(64 * ch * M * 3) * sizeof(float) + (size_t)4 * kWaveBins * sizeof(uint32_t);
+        const dim3 grid((d.N + 64 * ch - 1) / (64 * ch));
+        ScopedStage prof_(kStPreprocess, st, nv);
+#define FS_LAUNCH_PRE(CH)                                                                                            \
+        hipLaunchKernelGGL((preprocess_views_kernel<CH>), grid, dim3(256), lds, st, d, nv, means3D, cov3D, shs,      \
+                           colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, scale, vb, tile_cap)
+        if (ch == 1) FS_LAUNCH_PRE(1); else if (ch == 2) FS_LAUNCH_PRE(2); else FS_LAUNCH_PRE(4);
+#undef FS_LAUNCH_PRE
+    }
+    FS_CHECK_LAUNCH("preprocess_views");
+    {
+        ScopedStage prof_(kStTileScan, st, nv);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(nv), dim3(1024), 0, st, (const char*)scratch, scratch_stride,
+                           (char*)binning, binning_stride, T, counters, (unsigned long long)cap, tile_cap);
+    }
+    FS_CHECK_LAUNCH("tile_scan");
+    return FS_OK;
+}
+
+// Sort + blend of ONE view whose keys are binned (launch_binning, or the legacy projection kernel).
+static int launch_blend(const fs_raster_dims& d, const float* bg, void* geom, void* binning, void* image, void* scratch,
+                        int64_t cap, float* out_color, float* out_depth, float* out_alpha, const uint32_t* counters,
+                        hipStream_t st)
+{
+    const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
     const int T = gx * gy;
     const size_t P = (size_t)d.H * d.W;
-
-    GeomView g = geom_view(geom, d.N > 0 ? d.N : 1);
+    const GeomView g = geom_view(geom, d.N > 0 ? d.N : 1);
     uint32_t* offsets = (uint32_t*)binning;
     uint32_t* point_list = (uint32_t*)((char*)binning + binning_offsets_bytes(d.H, d.W));
     float* final_T = (float*)image;
@@ -1297,7 +1585,33 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     uint32_t* counts = (uint32_t*)scratch;
     unsigned long long* keys = (unsigned long long*)((char*)scratch + align_up((size_t)T * 4, 256));
     const uint32_t tile_cap = tile_capacity(cap, T);
+    const int nblk = tile_grid_blocks(gx, gy);
+    {
+        ScopedStage prof_(kStRender, st);
+#define FS_LAUNCH_RENDER(F, TR)                                                                                     \
+        hipLaunchKernelGGL((sort_blend_kernel<F, TR>), dim3(nblk), dim3(256), 0, st, d.H, d.W, counts, offsets, tile_cap, \
+                           keys, point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T, n_contrib)
+        const bool track = !(d.flags & FS_RASTER_NO_BACKWARD_STATE);
+        if (d.flags & FS_RASTER_FAST_EXP) { if (track) FS_LAUNCH_RENDER(true, true); else FS_LAUNCH_RENDER(true, false); }
+        else { if (track) FS_LAUNCH_RENDER(false, true); else FS_LAUNCH_RENDER(false, false); }
+#undef FS_LAUNCH_RENDER
+    }
+    FS_CHECK_LAUNCH("sort_blend");
+    return FS_OK;
+}
 
+// rounds 3 - 5: projection + binning of one view by the per-view kernel, its own memset and single-workgroup scan
+static int launch_binning_legacy(const fs_raster_dims& d, const float* means3D, const float* cov3D, const float* shs,
+                                 const float* colors_precomp, const float* opacities, const float* viewmatrix,
+                                 const float* projmatrix, const float* campos, const float* tanfov_dev, const float* scale_dev,
+                                 void* geom, void* binning, void* scratch, int64_t cap, int32_t* radii, uint32_t* counters,
+                                 hipStream_t st)
+{
+    const int T = num_tiles(d.H, d.W);
+    GeomView g = geom_view(geom, d.N > 0 ? d.N : 1);
+    uint32_t* counts = (uint32_t*)scratch;
+    unsigned long long* keys = (unsigned long long*)((char*)scratch + align_up((size_t)T * 4, 256));
+    const uint32_t tile_cap = tile_capacity(cap, T);
     if (hipMemsetAsync(counts, 0, (size_t)T * 4, st) != hipSuccess) {
         set_last_error("memset tile counts", hipGetLastError());
         return FS_ERR_LAUNCH;
@@ -1316,38 +1630,59 @@ FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, c
     }
     {
         ScopedStage prof_(kStTileScan, st);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, T,
-                           counters, (unsigned long long)cap, tile_cap);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (const char*)counts, (size_t)0, (char*)binning,
+                           (size_t)0, T, counters, (unsigned long long)cap, tile_cap);
     }
     FS_CHECK_LAUNCH("tile_scan");
-    const int nblk = tile_grid_blocks(gx, (d.H + kTile - 1) / kTile);
-    {
-        ScopedStage prof_(kStRender, st);
-#define FS_LAUNCH_RENDER(F, TR)                                                                                     \
-        hipLaunchKernelGGL((sort_blend_kernel<F, TR>), dim3(nblk), dim3(256), 0, st, d.H, d.W, counts, offsets, tile_cap, \
-                           keys, point_list, g.rec, bg, counters, out_color, out_depth, out_alpha, final_T, n_contrib)
-        const bool track = !(d.flags & FS_RASTER_NO_BACKWARD_STATE);
-        if (d.flags & FS_RASTER_FAST_EXP) { if (track) FS_LAUNCH_RENDER(true, true); else FS_LAUNCH_RENDER(true, false); }
-        else { if (track) FS_LAUNCH_RENDER(false, true); else FS_LAUNCH_RENDER(false, false); }
-#undef FS_LAUNCH_RENDER
-    }
-    FS_CHECK_LAUNCH("sort_blend");
     return FS_OK;
+}
+}  // namespace fs
+
+FS_API int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
+                             const float* shs, const float* colors_precomp, const float* opacities,
+                             const float* bg, const float* viewmatrix, const float* projmatrix,
+                             const float* campos, const float* tanfov_dev, const float* scale_dev,
+                             void* geom, void* binning, void* image, void* scratch, int64_t cap, float* out_color, float* out_depth,
+                             float* out_alpha, int32_t* radii, uint32_t* counters, void* stream_)
+{
+    if (!dims || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
+        !scratch || !out_color || !out_depth || !out_alpha || !counters)
+        return FS_ERR_INVALID_ARG;
+    const fs_raster_dims d = *dims;
+    int rc = check_forward_args(d, means3D, cov3D, shs, colors_precomp, opacities, radii, cap);
+    if (rc != FS_OK) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    if (legacy_preprocess())
+        rc = launch_binning_legacy(d, means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos,
+                                   tanfov_dev, scale_dev, geom, binning, scratch, cap, radii, counters, st);
+    else
+        rc = launch_binning(d, 1, means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov_dev,
+                            scale_dev, geom, 0, binning, 0, scratch, 0, cap, radii, counters, st);
+    if (rc != FS_OK) return rc;
+    return launch_blend(d, bg, geom, binning, image, scratch, cap, out_color, out_depth, out_alpha, counters, st);
 }
 
 // ---- all views of one call in ONE host call (decoder path) ---------------------------------------------------
 namespace fs {
 constexpr int kMaxStreams = 8;
 struct ForkJoin {  // cached events: fork `main` into the side streams, join them back
-    hipEvent_t ready = nullptr, done[kMaxStreams] = {};
+    hipEvent_t ready = nullptr, done[kMaxStreams] = {}, batch[kMaxViewsInFlight] = {};
     bool ok = false;
     ForkJoin()
     {
         ok = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < kMaxStreams && ok; ++i) ok = hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < kMaxViewsInFlight && ok; ++i) ok = hipEventCreateWithFlags(&batch[i], hipEventDisableTiming) == hipSuccess;
     }
 };
 }  // namespace fs
+
+FS_API int fs_raster_scratch_slots(int32_t v, int32_t n_streams)
+{
+    if (v < 0 || n_streams < 0) return FS_ERR_INVALID_ARG;
+    if (fs::legacy_preprocess()) return n_streams > 1 ? (n_streams < v ? n_streams : (v > 0 ? v : 1)) : 1;
+    return v < 1 ? 1 : (v < fs::kMaxViewsInFlight ? v : fs::kMaxViewsInFlight);
+}
 
 FS_API int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
                                    const float* shs, const float* colors_precomp, const float* opacities,
@@ -1363,6 +1698,9 @@ FS_API int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const 
     if (!bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image || !scratch || !out_color ||
         !out_depth || !out_alpha || !counters)
         return FS_ERR_INVALID_ARG;
+    const fs_raster_dims d = *dims;
+    int rc = check_forward_args(d, means3D, cov3D, shs, colors_precomp, opacities, radii, cap);
+    if (rc != FS_OK) return rc;
     // events belong to the device that was current when they were created: one cached set per (thread, device)
     static thread_local fs::ForkJoin* fj_dev[64] = {};
     int dev_ = 0;
@@ -1371,34 +1709,71 @@ FS_API int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const 
     fs::ForkJoin& fj = *fj_dev[dev_];
     const int ns = n_streams <= 1 ? 0 : (n_streams < v ? n_streams : v);
     hipStream_t main = (hipStream_t)main_stream;
-    if (ns > 0) {
-        if (!fj.ok) { set_last_error("event create", hipGetLastError()); return FS_ERR_LAUNCH; }
-        if (hipEventRecord(fj.ready, main) != hipSuccess) { set_last_error("event record", hipGetLastError()); return FS_ERR_LAUNCH; }
+    if (ns > 0 && !fj.ok) { set_last_error("event create", hipGetLastError()); return FS_ERR_LAUNCH; }
+    const size_t P = (size_t)d.H * d.W;
+    const bool legacy = fs::legacy_preprocess();
+    auto join = [&]() -> int {   // main waits for everything queued on the side streams
         for (int s = 0; s < ns; ++s)
-            if (hipStreamWaitEvent((hipStream_t)streams[s], fj.ready, 0) != hipSuccess) {
-                set_last_error("stream wait", hipGetLastError());
+            if (hipEventRecord(fj.done[s], (hipStream_t)streams[s]) != hipSuccess ||
+                hipStreamWaitEvent(main, fj.done[s], 0) != hipSuccess) {
+                set_last_error("stream join", hipGetLastError());
                 return FS_ERR_LAUNCH;
             }
-    }
-    const size_t P = (size_t)dims->H * dims->W;
-    int rc = FS_OK;
-    for (int i = 0; i < v && rc == FS_OK; ++i) {
-        const int s = ns > 0 ? i % ns : 0;
-        void* st = ns > 0 ? streams[s] : main_stream;
-        rc = fs_raster_forward(dims, means3D, cov3D, shs, colors_precomp, opacities, bg + 3 * (size_t)i,
-                               viewmatrix + 16 * (size_t)i, projmatrix + 16 * (size_t)i, campos + 3 * (size_t)i,
-                               tanfov ? tanfov + 2 * (size_t)i : nullptr, scale ? scale + i : nullptr,
-                               (char*)geom + strides[0] * i, (char*)binning + strides[1] * i,
-                               (char*)image + strides[2] * i, (char*)scratch + strides[3] * s, cap,
-                               out_color + 3 * P * i, out_depth + P * i, out_alpha + P * i,
-                               radii ? radii + (size_t)dims->N * i : nullptr, counters + 2 * (size_t)i, st);
-    }
-    for (int s = 0; s < ns; ++s) {  // join even after a failed launch: never leave `main` unordered
-        if (hipEventRecord(fj.done[s], (hipStream_t)streams[s]) != hipSuccess ||
-            hipStreamWaitEvent(main, fj.done[s], 0) != hipSuccess) {
-            set_last_error("stream join", hipGetLastError());
-            return FS_ERR_LAUNCH;
+        return FS_OK;
+    };
+    auto blend = [&](int i, void* scratch_i, hipStream_t st) {
+        return fs::launch_blend(d, bg + 3 * (size_t)i, (char*)geom + strides[0] * i, (char*)binning + strides[1] * i,
+                                (char*)image + strides[2] * i, scratch_i, cap, out_color + 3 * P * i, out_depth + P * i,
+                                out_alpha + P * i, counters + 2 * (size_t)i, st);
+    };
+    if (legacy) {   // rounds 3 - 5: whole views alternate over the streams, one key area per stream
+        if (ns > 0) {
+            if (hipEventRecord(fj.ready, main) != hipSuccess) { set_last_error("event record", hipGetLastError()); return FS_ERR_LAUNCH; }
+            for (int s = 0; s < ns; ++s)
+                if (hipStreamWaitEvent((hipStream_t)streams[s], fj.ready, 0) != hipSuccess) {
+                    set_last_error("stream wait", hipGetLastError());
+                    return FS_ERR_LAUNCH;
+                }
         }
+        for (int i = 0; i < v && rc == FS_OK; ++i) {
+            const int s = ns > 0 ? i % ns : 0;
+            hipStream_t st = ns > 0 ? (hipStream_t)streams[s] : main;
+            void* scratch_i = (char*)scratch + strides[3] * s;
+            rc = fs::launch_binning_legacy(d, means3D, cov3D, shs, colors_precomp, opacities, viewmatrix + 16 * (size_t)i,
+                                           projmatrix + 16 * (size_t)i, campos + 3 * (size_t)i,
+                                           tanfov ? tanfov + 2 * (size_t)i : nullptr, scale ? scale + i : nullptr,
+                                           (char*)geom + strides[0] * i, (char*)binning + strides[1] * i, scratch_i, cap,
+                                           radii ? radii + (size_t)d.N * i : nullptr, counters + 2 * (size_t)i, st);
+            if (rc == FS_OK) rc = blend(i, scratch_i, st);
+        }
+        const int jr = join();   // join even after a failed launch: never leave `main` unordered
+        return rc != FS_OK ? rc : jr;
+    }
+    // One projection launch set per BATCH of views on `main`, the blends of the batch fan out over the side streams; `main`
+    // goes straight on to the next batch's projection, which overlaps those blends.  View i's key area is scratch slot
+    // i % kMaxViewsInFlight: after kMaxViewsInFlight views the streams are joined before the slots are reused.
+    const int VB = fs::raster_batch();
+    for (int c0 = 0; c0 < v && rc == FS_OK; c0 += fs::kMaxViewsInFlight) {
+        const int c1 = c0 + fs::kMaxViewsInFlight < v ? c0 + fs::kMaxViewsInFlight : v;
+        for (int b0 = c0, k = 0; b0 < c1 && rc == FS_OK; b0 += VB, ++k) {
+            const int nb = b0 + VB < c1 ? VB : c1 - b0;
+            char* const scratch_b = (char*)scratch + strides[3] * (size_t)(b0 - c0);
+            rc = fs::launch_binning(d, nb, means3D, cov3D, shs, colors_precomp, opacities, viewmatrix + 16 * (size_t)b0,
+                                    projmatrix + 16 * (size_t)b0, campos + 3 * (size_t)b0,
+                                    tanfov ? tanfov + 2 * (size_t)b0 : nullptr, scale ? scale + b0 : nullptr,
+                                    (char*)geom + strides[0] * b0, strides[0], (char*)binning + strides[1] * b0, strides[1],
+                                    scratch_b, strides[3], cap, radii ? radii + (size_t)d.N * b0 : nullptr,
+                                    counters + 2 * (size_t)b0, main);
+            if (rc != FS_OK) break;
+            if (ns > 0 && hipEventRecord(fj.batch[k], main) != hipSuccess) { set_last_error("event record", hipGetLastError()); rc = FS_ERR_LAUNCH; break; }
+            for (int i = b0; i < b0 + nb && rc == FS_OK; ++i) {
+                hipStream_t st = ns > 0 ? (hipStream_t)streams[i % ns] : main;
+                if (ns > 0 && hipStreamWaitEvent(st, fj.batch[k], 0) != hipSuccess) { set_last_error("stream wait", hipGetLastError()); rc = FS_ERR_LAUNCH; break; }
+                rc = blend(i, scratch_b + strides[3] * (size_t)(i - b0), st);
+            }
+        }
+        const int jr = join();
+        if (rc == FS_OK) rc = jr;
     }
     return rc;
 }

@@ -257,7 +257,8 @@ class _RenderViews(torch.autograd.Function):
         sz = R._buffer_sizes(N, h, w, cap)
         u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
         geom, binning, image = u8(v * sz[0]), u8(v * sz[1]), u8(v * sz[2])
-        scratch = u8(max(n_streams, 1) * sz[3])
+        # one key area per view in flight (the projection of a whole batch of views is ONE launch, fs_raster_forward_views)
+        scratch = u8(max(R._lib.lib().fs_raster_scratch_slots(v, n_streams if n_streams > 1 else 0), 1) * sz[3])
         radii = torch.empty(v, N, dtype=torch.int32, device=dev)
         counters = torch.empty(v, 2, dtype=torch.int32, device=dev)
         strides = (C.c_size_t * 4)(*sz)

@@ -44,7 +44,7 @@ const char* fs_version(void);
  * it right after loading the library (freesplat_amd/_lib.py does): a stale build would otherwise accept calls with
  * shifted pointers.  3 = round 3 (single-pass binning: scratch = per-tile key areas, counters[1] = largest tile list on
  * overflow, geom without the mask / depth arrays; fused sort + blend). */
-#define FS_ABI_VERSION 5
+#define FS_ABI_VERSION 6
 int fs_abi_version(void);
 /* Last HIP error string observed by a failing call on this thread (never NULL). */
 const char* fs_last_error(void);
@@ -139,14 +139,25 @@ int fs_raster_forward(const fs_raster_dims* dims, const float* means3D, const fl
                       int64_t inst_capacity, float* out_color, float* out_depth, float* out_alpha,
                       int32_t* radii, uint32_t* counters, void* stream);
 
+/* Number of scratch (key-area) buffers fs_raster_forward_views needs for v views on n_streams streams: one per view in
+ * flight, at most 16 (beyond that the call joins its streams and reuses them). */
+int fs_raster_scratch_slots(int32_t v, int32_t n_streams);
+
 /* v views of ONE Gaussian set in one host call (the decoder's path: decoder_splatting_cuda.py:55-75 renders
- * v views per scene).  Per-view arrays are packed: bg [v,3], viewmatrix / projmatrix [v,16], campos [v,3],
- * tanfov [v,2] | NULL, scale [v] | NULL (fs_frame_views fills all of them), out_color [v,3,H,W], out_depth /
- * out_alpha [v,H,W], radii [v,N], counters [v,2].  geom / binning / image hold v buffers strides[0..2] bytes apart
- * (>= the sizes of fs_raster_buffer_sizes), scratch one buffer of strides[3] bytes per stream.
- * n_streams > 1: view i runs on streams[i % n_streams]; the call orders them after the work already queued on
- * main_stream and orders main_stream after all of them (fork / join with events, no host sync), so to the caller
- * the call is stream-ordered on main_stream like every other entry point.  n_streams <= 1: everything on main_stream. */
+ * v views per scene; cuda_splatting.py:89-132 is the per-view loop this replaces).  Per-view arrays are packed:
+ * bg [v,3], viewmatrix / projmatrix [v,16], campos [v,3], tanfov [v,2] | NULL, scale [v] | NULL (fs_frame_views fills all
+ * of them), out_color [v,3,H,W], out_depth / out_alpha [v,H,W], radii [v,N], counters [v,2].  geom / binning / image hold v
+ * buffers strides[0..2] bytes apart (>= the sizes of fs_raster_buffer_sizes); scratch holds
+ * fs_raster_scratch_slots(v, n_streams) key-area buffers strides[3] bytes apart.
+ * ONE launch set for a batch of views (ABI revision 6): the tile counters of the batch are cleared by one launch, every
+ * Gaussian is read once and projected + binned into all cameras of the batch by one launch (preprocess_views_kernel), one
+ * launch scans the tile counts of all its views; then one fused sort + blend launch per view.  Batches hold
+ * FREESPLAT_RASTER_BATCH views (environment, default 16).
+ * n_streams > 1: the projection launch sets run on main_stream, the blend of view i on streams[i % n_streams], ordered after
+ * its batch's projection by an event -- so the next batch's projection overlaps the blends of this one; main_stream is ordered
+ * after all of them before the call returns (fork / join with events, no host sync), so to the caller the call is
+ * stream-ordered on main_stream like every other entry point.  n_streams <= 1: everything on main_stream.
+ * (FREESPLAT_PREPROCESS=legacy in the environment selects the per-view projection kernel of revisions <= 5 for A/B runs.) */
 int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
                             const float* shs, const float* colors_precomp, const float* opacities,
                             const float* bg, const float* viewmatrix, const float* projmatrix,
