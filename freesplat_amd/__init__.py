@@ -4,7 +4,7 @@ Only what the path needs lives here: `csrc/` (hand-written HIP kernels + the C A
 include/freesplat_amd.h), and the host-side mirrors of the reference's operator interfaces:
 
   rasterizer.py   GaussianRasterizationSettings / GaussianRasterizer  (diff_gaussian_rasterization_depth)
-  decoder.py      get_projection_matrix / render_cuda / DecoderSplattingCUDA (src/model/decoder/)
+  decoder.py      frame_views / render_cuda / render_views / DecoderSplattingCUDA (src/model/decoder/)
   compat/         importable `diff_gaussian_rasterization_depth` module for an unmodified reference tree
 
 There is no CPU or eager fallback: the ops raise if libfreesplat_hip.so is missing.

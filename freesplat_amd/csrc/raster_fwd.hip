@@ -214,6 +214,38 @@ __device__ __forceinline__ unsigned long long pack_quad_masks(const QuadForm& f,
     return m;
 }
 
+// The same masks for a rect of at most 4 x 4 tiles (99.8 % of the rects at config 3) in a FIXED layout: nibble 4 * row + col,
+// so that a nibble index maps to its tile with a shift and a mask, plus `nz`: bit (4 * row + col) set iff that tile is an
+// instance (any quadrant bit set; every tile of the rect when culling is off).  The binning passes of bin_wave then walk the SET
+// BITS of nz -- 5.7 instances per Gaussian at config 3 -- instead of every tile of the rect (9.2, and 15.7 for the largest rect
+// of a wavefront, which sets the trip count of all its lanes).
+__device__ __forceinline__ uint32_t spread2(uint32_t x)   // 2-bit groups at 2c -> 4c (c < 4)
+{
+    x = (x | (x << 4)) & 0x0F0Fu;
+    return (x | (x << 2)) & 0x3333u;
+}
+__device__ __forceinline__ unsigned long long pack_quad_masks4(const QuadForm& f, const float4 r0, ushort4 rc, bool cull, uint32_t& nz)
+{
+    unsigned long long m = 0;
+    const int rw = rc.z - rc.x, rh = rc.w - rc.y, cell0 = 2 * rc.x, ncell = 2 * rw;
+    const uint32_t rowfull = (1u << rw) - 1u;
+    nz = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r < rh) {
+            const RowBands rb = row_bands(f, r0, rc.y + r);
+            const uint32_t top = band_cells(rb.top, r0.x, cell0, ncell), bot = band_cells(rb.bot, r0.x, cell0, ncell);
+            m |= (unsigned long long)(spread2(top) | (spread2(bot) << 2)) << (16 * r);
+            uint32_t any = top | bot;                 // cell pairs -> one bit per tile column
+            any = (any | (any >> 1)) & 0x55u;
+            any = (any | (any >> 1)) & 0x33u;
+            any = (any | (any >> 2)) & 0x0Fu;
+            nz |= (cull ? any : rowfull) << (4 * r);
+        }
+    }
+    return m;
+}
+
 // Workgroup-private tile counters: the 256 Gaussians of a workgroup are neighbours on screen
 // (the encoder emits them in pixel order), so their tile rectangles span a small bounding box.
 // Counting happens with LDS atomics inside that box and only one global atomic per touched
@@ -411,10 +443,15 @@ __device__ __forceinline__ void bin_wave(const fs_raster_dims& d, int lane, uint
     const bool cull = (d.flags & FS_RASTER_TILE_CULL) != 0;
     const int gx = (d.W + kTile - 1) / kTile;
     const QuadForm qf = quad_form(r0, r1);
-    const int area = (rect.z - rect.x) * (rect.w - rect.y);
+    const int rw = rect.z - rect.x, rh = rect.w - rect.y;
+    const int area = rw * rh;
     const bool small = area <= 16;
+    // every rect of the wavefront at most 4 x 4 tiles (wave-uniform; nearly always): fixed-layout masks, set-bit walks
+    const bool all4 = __builtin_amdgcn_ballot_w64(valid && (rw > 4 || rh > 4)) == 0ull;
     unsigned long long qm = 0;
-    if (valid && small) qm = pack_quad_masks(qf, r0, rect);
+    uint32_t nz = 0u;
+    if (all4) { if (valid) qm = pack_quad_masks4(qf, r0, rect, cull, nz); }
+    else if (valid && small) qm = pack_quad_masks(qf, r0, rect);
     // key = depth bits : (gaussian id << 4 | quadrant mask); the mask is a function of (id, tile), so
     // ordering by the key is ordering by (depth, id)
     const unsigned long long key_hi = ((unsigned long long)__float_as_uint(r1.w) << 32) | (i << 4);
@@ -433,7 +470,34 @@ __device__ __forceinline__ void bin_wave(const fs_raster_dims& d, int lane, uint
     const int bw = max(0, __builtin_amdgcn_readfirstlane(x1) - bx0), bh = max(0, __builtin_amdgcn_readfirstlane(y1) - by0);
     const int nb = bw * bh;
     if (nb == 0) return;   // (wave-uniform) nothing of this chunk is on screen
-    if (nb <= kWaveBins) {
+    if (nb <= kWaveBins && all4) {
+        for (int k = lane; k < nb; k += 64) s_cnt[k] = 0u;
+        wave_lds_sync();
+        const int cbase = (rect.y - by0) * bw + (rect.x - bx0);   // the rect's first tile among the wavefront's counters
+        for (uint32_t z = nz; z != 0u; z &= z - 1u) {
+            const int k = __builtin_ctz(z);
+            atomicAdd(&s_cnt[cbase + (k >> 2) * bw + (k & 3)], 1u);
+        }
+        wave_lds_sync();
+        for (int k0 = 0; k0 < nb; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < nb) {
+                const uint32_t c = s_cnt[k];
+                const int ky = k / bw, kx = k - ky * bw;
+                s_cnt[k] = c ? atomicAdd(&tile_counts[(by0 + ky) * gx + bx0 + kx], c) : 0u;
+            }
+        }
+        wave_lds_sync();
+        const uint32_t tbase = (uint32_t)(rect.y * gx + rect.x);
+        for (uint32_t z = nz; z != 0u; z &= z - 1u) {
+            const int k = __builtin_ctz(z);
+            const uint32_t m = (uint32_t)(qm >> (4 * k)) & 15u;
+            const uint32_t slot = atomicAdd(&s_cnt[cbase + (k >> 2) * bw + (k & 3)], 1u);
+            // (tile * tile_cap + slot < 2^32: tile_capacity() bounds the product)
+            if (slot < tile_cap) keys[(tbase + (uint32_t)((k >> 2) * gx + (k & 3))) * tile_cap + slot] = key_hi | m;
+        }
+        wave_lds_sync();   // (the wavefront's next view reuses the counters)
+    } else if (nb <= kWaveBins) {
         for (int k = lane; k < nb; k += 64) s_cnt[k] = 0u;
         wave_lds_sync();
         if (valid) {
@@ -474,7 +538,16 @@ __device__ __forceinline__ void bin_wave(const fs_raster_dims& d, int lane, uint
             }
         }
         wave_lds_sync();   // (the wavefront's next view reuses the counters)
-    } else if (valid) {    // a chunk that wraps around an image row of the context view: straight to the global counters
+    } else if (all4) {     // a chunk that wraps around an image row of the context view: straight to the global counters
+        const uint32_t tbase = (uint32_t)(rect.y * gx + rect.x);
+        for (uint32_t z = nz; z != 0u; z &= z - 1u) {
+            const int k = __builtin_ctz(z);
+            const uint32_t m = (uint32_t)(qm >> (4 * k)) & 15u;
+            const uint32_t tile = tbase + (uint32_t)((k >> 2) * gx + (k & 3));
+            const uint32_t slot = atomicAdd(&tile_counts[tile], 1u);
+            if (slot < tile_cap) keys[tile * tile_cap + slot] = key_hi | m;
+        }
+    } else if (valid) {
         int k = 0;
         for (int y = rect.y; y < rect.w; ++y) {
             RowBands rb = {};
@@ -504,11 +577,14 @@ struct ViewBuffers {
     int32_t* radii;                           // [v, N] | nullptr
 };
 
-#ifdef FS_PRE_WAVES      // (A/B builds: make VARIANT=pw5 EXTRA=-DFS_PRE_WAVES=5)
-#define FS_PRE_OCC __attribute__((amdgpu_waves_per_eu(FS_PRE_WAVES, FS_PRE_WAVES)))
-#else
-#define FS_PRE_OCC
+// Six wavefronts per SIMD (80 registers, ~23 of the loop's cold values spilled to scratch): the kernel is bound by the latency
+// of its record stores, LDS atomics and returning global atomics, and occupancy buys more than the spills cost -- same-session
+// A/B at config 3, 16 views per call (profiles/r6_preprocess_ab.txt): unconstrained (109 registers, 4 wavefronts) 4 270 views/s,
+// 5: 4 322, 6: 4 370, 7: 4 346.  (A/B builds: make VARIANT=pw5 EXTRA=-DFS_PRE_WAVES=5)
+#ifndef FS_PRE_WAVES
+#define FS_PRE_WAVES 6
 #endif
+#define FS_PRE_OCC __attribute__((amdgpu_waves_per_eu(FS_PRE_WAVES, FS_PRE_WAVES)))
 template <int CH>
 __global__ __launch_bounds__(256) FS_PRE_OCC void preprocess_views_kernel(
     fs_raster_dims d, int v, const float* __restrict__ means3D, const float* __restrict__ cov3D,
@@ -530,16 +606,28 @@ __global__ __launch_bounds__(256) FS_PRE_OCC void preprocess_views_kernel(
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int chunk = wave % CH;
-    uint32_t* const s_cnt = (uint32_t*)(lds + (size_t)kPerBlock * per_sh) + wave * kWaveBins;
+    uint32_t* const s_cnt_base = (uint32_t*)(lds + (size_t)kPerBlock * per_sh);
+    uint32_t* const s_cnt = s_cnt_base + wave * kWaveBins;
     const int li = chunk * 64 + lane;            // this thread's Gaussian inside the workgroup's slab
     const bool live = li < cnt;
     const uint32_t i = (uint32_t)(base + li);
-    float3 p_in = make_float3(0.0f, 0.0f, 0.0f);
-    float c_in[6] = {0, 0, 0, 0, 0, 0};
-    float op = 0.0f;
-    if (live) {
-        load_mean_cov(d, means3D, cov3D, i, p_in, c_in);
-        op = opacities[i];
+    // mean / covariance / opacity: loaded once, parked in LDS (SoA: conflict-free) and re-read per view -- ten registers that
+    // would otherwise stay live across the whole view loop
+    float* const l_g = (float*)(s_cnt_base + 4 * kWaveBins) + li;   // [10][64 * CH]
+    {
+        float3 p_in = make_float3(0.0f, 0.0f, 0.0f);
+        float c_in[6] = {0, 0, 0, 0, 0, 0};
+        float op = 0.0f;
+        if (live) {
+            load_mean_cov(d, means3D, cov3D, i, p_in, c_in);
+            op = opacities[i];
+        }
+        if (wave < CH) {   // (one wavefront per chunk writes; the others loaded the same rows -- L1 hits -- for nothing: 40 B)
+            l_g[0 * kPerBlock] = p_in.x; l_g[1 * kPerBlock] = p_in.y; l_g[2 * kPerBlock] = p_in.z;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) l_g[(3 + k) * kPerBlock] = c_in[k];
+            l_g[9 * kPerBlock] = op;
+        }
     }
     __syncthreads();   // SH rows staged; the wavefronts go their own ways from here
     const int T = num_tiles(d.H, d.W);
@@ -551,6 +639,12 @@ __global__ __launch_bounds__(256) FS_PRE_OCC void preprocess_views_kernel(
         //  hoisted out of the view loop and stay live across it -- 158 registers instead of ~80)
         int li_ = li, lane_ = lane;
         asm volatile("" : "+v"(li_), "+v"(lane_));
+        const float* const lg = (const float*)(s_cnt_base + 4 * kWaveBins) + li_;
+        const float3 p_in = make_float3(lg[0 * kPerBlock], lg[1 * kPerBlock], lg[2 * kPerBlock]);
+        float c_in[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c_in[k] = lg[(3 + k) * kPerBlock];
+        const float op = lg[9 * kPerBlock];
         const float tanfovx = tanfov_dev ? tanfov_dev[2 * j] : d.tanfovx;
         const float tanfovy = tanfov_dev ? tanfov_dev[2 * j + 1] : d.tanfovy;
         const float wscale = scale_dev ? scale_dev[j] : 1.0f;  // scale-invariant rescale (1/near)
@@ -1550,7 +1644,8 @@ static int launch_binning(const fs_raster_dims& d, int nv, const float* means3D,
         vb.scratch = (char*)scratch; vb.scratch_stride = scratch_stride;
         vb.radii = radii;
         const int ch = nv >= 4 ? 1 : (nv == 2 ? 2 : 4);
-        const size_t lds = (size_t)(64 * ch * M * 3) * sizeof(float) + (size_t)4 * kWaveBins * sizeof(uint32_t);
+        const size_t lds = (size_t)(64 * ch * M * 3) * sizeof(float) + (size_t)4 * kWaveBins * sizeof(uint32_t)
+                           + (size_t)(10 * 64 * ch) * sizeof(float);
         const dim3 grid((d.N + 64 * ch - 1) / (64 * ch));
         ScopedStage prof_(kStPreprocess, st, nv);
 #define FS_LAUNCH_PRE(CH)                                                                                            \

@@ -1,8 +1,9 @@
 """Decoder boundary: camera framing + per-view rasterizer calls.
 
 Host-side mirror of the reference's
-  /root/reference/src/model/decoder/cuda_splatting.py:17-132  (get_projection_matrix, render_cuda)
-  /root/reference/src/geometry/projection.py:233-247          (get_fov)
+  /root/reference/src/model/decoder/cuda_splatting.py:17-132  (get_projection_matrix + render_cuda; the camera framing of
+                                                               :17-44 / :64-87 and get_fov, projection.py:233-247, are ONE
+                                                               HIP launch here: frame_views -> fs_frame_views)
   /root/reference/src/model/decoder/decoder_splatting_cuda.py:35-75 (DecoderSplattingCUDA.forward)
 with the same names, argument meaning and results, so that a caller of `render_cuda` /
 `DecoderSplattingCUDA` can switch over unchanged.  Everything here is plumbing in torch; the
@@ -39,70 +40,16 @@ def _consts(device: torch.device) -> dict:
     if c is None:
         row, col = torch.triu_indices(3, 3)
         c = _const_cache[key] = dict(
-            edge_mid=torch.tensor([[0, 0.5, 1], [1, 0.5, 1], [0.5, 0, 1], [0.5, 1, 1]], dtype=torch.float32,
-                                  device=device),
             triu_row=row.to(device), triu_col=col.to(device))
     return c
 
 
-def get_fov(intrinsics: Tensor) -> Tensor:
-    """[B,3,3] normalised intrinsics -> [B,2] (fov_x, fov_y): angle between the unit rays through the
-    image-edge midpoints (projection.py:233-247)."""
-    inv = torch.linalg.inv_ex(intrinsics).inverse  # same LU as .inverse(), without its host sync
-    mids = _consts(intrinsics.device)["edge_mid"]
-
-    def ray(k):
-        r = torch.einsum("bij,j->bi", inv, mids[k])
-        return r / r.norm(dim=-1, keepdim=True)
-
-    left, right = ray(0), ray(1)
-    top, bottom = ray(2), ray(3)
-    fov_x = (left * right).sum(dim=-1).acos()
-    fov_y = (top * bottom).sum(dim=-1).acos()
-    return torch.stack((fov_x, fov_y), dim=-1)
-
-
-def get_projection_matrix(near: Tensor, far: Tensor, fov_x: Tensor, fov_y: Tensor) -> Tensor:
-    """Symmetric frustum, x/y -> (-1,1), z -> (0,1), w = z (cuda_splatting.py:17-44)."""
-    tan_x = (0.5 * fov_x).tan()
-    tan_y = (0.5 * fov_y).tan()
-    top = tan_y * near
-    bottom = -top
-    right = tan_x * near
-    left = -right
-    (b,) = near.shape
-    P = torch.zeros((b, 4, 4), dtype=torch.float32, device=near.device)
-    P[:, 0, 0] = 2 * near / (right - left)
-    P[:, 1, 1] = 2 * near / (top - bottom)
-    P[:, 0, 2] = (right + left) / (right - left)
-    P[:, 1, 2] = (top + bottom) / (top - bottom)
-    P[:, 3, 2] = 1
-    P[:, 2, 2] = far / (far - near)
-    P[:, 2, 3] = -(far * near) / (far - near)
-    return P
-
-
-def _frame(extrinsics, intrinsics, near, far, scale_invariant: bool):
-    """Per-view matrices exactly as cuda_splatting.py:64-87 builds them."""
-    scale = None
-    if scale_invariant:
-        scale = 1 / near
-        extrinsics = extrinsics.clone()
-        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
-        near = near * scale
-        far = far * scale
-    fov_x, fov_y = get_fov(intrinsics).unbind(dim=-1)
-    tan_fov_x = (0.5 * fov_x).tan()
-    tan_fov_y = (0.5 * fov_y).tan()
-    projection = get_projection_matrix(near, far, fov_x, fov_y).transpose(1, 2)
-    view = torch.linalg.inv_ex(extrinsics).inverse.transpose(1, 2)
-    full = view @ projection
-    return extrinsics, scale, tan_fov_x, tan_fov_y, view.contiguous(), full.contiguous()
-
-
 def frame_views(extrinsics, intrinsics, near, far, scale_invariant: bool = True):
-    """`_frame` for v views in one HIP launch (fs_frame_views): returns (campos [v,3], scale [v], tanfov [v,2],
-    view [v,4,4], full [v,4,4]), all on the device -- nothing of it is needed on the host by render_views."""
+    """The per-view camera matrices of cuda_splatting.py:64-87 (get_fov, projection.py:233-247; get_projection_matrix,
+    cuda_splatting.py:17-44; the 1/near rescale; view = inverse(extrinsics)^T; full = view @ projection^T) for v views in one
+    HIP launch (fs_frame_views, csrc/framing.hip: formed in double, each entry rounded once): returns (campos [v,3], scale [v],
+    tanfov [v,2], view [v,4,4], full [v,4,4]), all on the device -- nothing of it is needed on the host by render_views.
+    (A torch restatement of the reference's fp32 chain lives in tests/util_framing.py as the checker.)"""
     v = extrinsics.shape[0]
     dev = extrinsics.device
     if dev.type != "cuda":
@@ -127,24 +74,24 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
     batch element, each with its own copy of the Gaussians, like the reference.  Returns
     (color [B,3,H,W], depth [B,1,H,W])."""
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
-    extr, scale, tan_x, tan_y, view, full = _frame(extrinsics, intrinsics, near, far, scale_invariant)
+    campos, scale, tanfov, view, full = frame_views(extrinsics, intrinsics, near, far, scale_invariant)
     if scale_invariant:
         gaussian_covariances = gaussian_covariances * (scale[:, None, None, None] ** 2)
         gaussian_means = gaussian_means * scale[:, None, None]
     n = gaussian_sh_coefficients.shape[-1]
     degree = isqrt(n) - 1
     shs = gaussian_sh_coefficients.transpose(-1, -2).contiguous()  # b g xyz n -> b g n xyz
-    b = extr.shape[0]
+    b = view.shape[0]
     h, w = image_shape
-    tan_x_h, tan_y_h = tan_x.tolist(), tan_y.tolist()  # one sync for all views (reference: 2 per view)
-    row, col = _consts(extr.device)["triu_row"], _consts(extr.device)["triu_col"]
+    tan_h = tanfov.tolist()  # one sync for all views (reference: 2 per view)
+    row, col = _consts(view.device)["triu_row"], _consts(view.device)["triu_col"]
     images, depths = [], []
     for i in range(b):
         mean_gradients = torch.zeros_like(gaussian_means[i], requires_grad=True)
         settings = GaussianRasterizationSettings(
-            image_height=h, image_width=w, tanfovx=tan_x_h[i], tanfovy=tan_y_h[i],
+            image_height=h, image_width=w, tanfovx=tan_h[i][0], tanfovy=tan_h[i][1],
             bg=background_color[i], scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i],
-            sh_degree=degree, campos=extr[i, :3, 3], prefiltered=False, debug=False)
+            sh_degree=degree, campos=campos[i], prefiltered=False, debug=False)
         rasterizer = GaussianRasterizer(settings)
         image, radii, depth, _ = rasterizer(
             means3D=gaussian_means[i], means2D=mean_gradients,

@@ -17,7 +17,7 @@ def _load(name):
 
 
 def test_framing_matches_reference():
-    from freesplat_amd.decoder import _frame, get_fov, get_projection_matrix
+    from util_framing import _frame, get_fov, get_projection_matrix
     g = _load("framing.npz")
     np.testing.assert_allclose(get_fov(g["intrinsics"]).numpy(), g["fov"].numpy(), rtol=1e-6)
     extr, scale, tx, ty, view, full = _frame(g["extrinsics"], g["intrinsics"], g["near"], g["far"], True)

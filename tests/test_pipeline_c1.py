@@ -93,7 +93,8 @@ def _render_oracle(x, g, device=None):
     last bit of a few matrix entries, which is enough to reorder the near-coplanar Gaussians of this scene in depth
     -- so image comparisons against the product must use ITS matrices (the framing itself is pinned to the
     reference separately, tests/test_raster_hip.py::test_frame_views_matches_reference_framing)."""
-    from freesplat_amd.decoder import _frame, frame_views
+    from freesplat_amd.decoder import frame_views
+    from util_framing import _frame
     from oracle import raster_oracle as ro
     means, cov, sh, opac = g
     n = x["tgt"].shape[0]

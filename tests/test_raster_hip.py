@@ -488,7 +488,8 @@ def test_splatter_script_scenario(hip_device):
     asks for 25 coefficients; the extension evaluates at most degree 3).  Product (render_cuda, the script's call) vs
     the oracle, plus the structure the script's comments describe (green / blue carry no harmonics)."""
     from freesplat_amd import synthetic
-    from freesplat_amd.decoder import _frame, render_cuda
+    from freesplat_amd.decoder import render_cuda
+    from util_framing import _frame
     from oracle import raster_oracle as ro
     H = W = 128
     frames = 6

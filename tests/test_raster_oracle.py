@@ -9,7 +9,7 @@ import torch
 
 from oracle import raster_oracle as ro
 from oracle.raster_dense_torch import render_dense
-from freesplat_amd.decoder import _frame
+from util_framing import _frame
 from util_raster import oracle_forward, small_scene, view_inputs
 
 C0 = 0.28209479177387814

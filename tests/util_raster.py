@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from freesplat_amd import synthetic
-from freesplat_amd.decoder import _frame
+from util_framing import _frame
 
 
 def view_inputs(scene: dict, cams: dict, i: int, H: int, W: int, bg=(0.0, 0.0, 0.0)) -> dict:
