@@ -1430,7 +1430,12 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
             ge.t00 = pend ? (int)ly * TW + (int)lx : 0;       // tile-local index of tap (0, 0), >= -(TW + 1)
             ge.cid = pend ? ((int)ly + 1) * (TW + 1) + (int)lx + 1 : 0;   // the base's own slot (t00 wraps: (7, y) = (-1, y + 1))
             if (pend) {
+#ifdef FS_SG_FLOOR   // timing-only build (WRONG results): every plane group reads the records of the FIRST one -- 4 planes per view stay
+                     // cache-resident, i.e. the sweep with its record bytes taken out: what the projection + claim + LDS adds cost alone
+                const size_t pl = (size_t)b * D + (size_t)(d0 + gs * gstride);
+#else
                 const size_t pl = (size_t)b * D + (size_t)(dg + gs * gstride);
+#endif
                 const float2 mt = recM[pl * hw + pix];
                 const uint32_t fl = __float_as_uint(mt.y) >> kbit;
                 pend = (fl & 2u) != 0u;                       // (the first pass's own z_k > 0)

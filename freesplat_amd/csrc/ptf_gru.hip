@@ -288,7 +288,12 @@ __device__ __forceinline__ void store_acc(float* __restrict__ dst, int hf, const
         *(float4*)(dst + 8 * g4 + 4 * hf) = make_float4(a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]);
 }
 
-__global__ __launch_bounds__(256) void ptf_gru_bwd_kernel(int n, const float* __restrict__ cat, const float* __restrict__ tab,
+#ifdef FS_GRU_BWD_WAVES    // (A/B builds: make VARIANT=gru2 EXTRA=-DFS_GRU_BWD_WAVES=2 -- 256 registers, ~155 values through scratch)
+#define FS_GRU_BWD_OCC __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD_WAVES, FS_GRU_BWD_WAVES)))
+#else
+#define FS_GRU_BWD_OCC
+#endif
+__global__ __launch_bounds__(256) FS_GRU_BWD_OCC void ptf_gru_bwd_kernel(int n, const float* __restrict__ cat, const float* __restrict__ tab,
                                                           const float* __restrict__ stream, const float* __restrict__ g_fused,
                                                           float* __restrict__ dcat, float* __restrict__ side)
 {

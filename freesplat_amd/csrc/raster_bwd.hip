@@ -218,9 +218,11 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
         // S_yy = sum w dy^2 -- and preprocess_bwd combines them per Gaussian with the conic:
         //   dL/dmean2D = -(W/2, H/2) * (a S_x + b S_y, c S_y + b S_x),   dL/dconic = -1/2 (S_xx, S_xy, S_yy)
         // (linear in the partials, so summing first is the same sum; 9 packed operations per pair instead of 20).
-        const f32x2 dL_dG = (f32x2){c3.x, c3.y} * dLa;
         const f32x2 v_op = G * dLa;
-        const f32x2 wdx = dL_dG * (G * dx), wdy = dL_dG * (G * dy);
+        // w = dL/dG * G = opacity * (dL/dalpha * G) = opacity * v_op: the opacity is per Gaussian, so the moments are summed of
+        // v_op alone and preprocess_bwd multiplies the five sums by it -- 6 instead of 9 packed operations per pair (round 6:
+        // render_bwd 0.515 -> 0.503 ms per view, profiles/r6_bwd_opacity_ab.txt)
+        const f32x2 wdx = v_op * dx, wdy = v_op * dy;
         const f32x2 sxx = wdx * dx, sxy = wdx * dy, syy = wdy * dy;
         va[0] = wdx.x; va[1] = wdy.x; va[2] = sxx.x; va[3] = sxy.x; va[4] = syy.x; va[5] = v_op.x;
         vb[0] = wdx.y; vb[1] = wdy.y; vb[2] = sxx.y; vb[3] = sxy.y; vb[4] = syy.y; vb[5] = v_op.y;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float 
 // (two wavefronts per SIMD: 256 registers + 59 spilled dwords beat one wavefront at 310 registers by 13 %)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void preprocess_bwd_kernel(
     fs_raster_dims d, int V, const float* __restrict__ means3D, const float* __restrict__ cov3D,
-    const float* __restrict__ shs, const float* __restrict__ view_all, const float* __restrict__ proj_all,
+    const float* __restrict__ shs, const float* __restrict__ opacities, const float* __restrict__ view_all, const float* __restrict__ proj_all,
     const float* __restrict__ campos_all, const float* __restrict__ tanfov_dev,
     const float* __restrict__ scale_dev, const char* __restrict__ geom_base, size_t geom_stride,
     const char* __restrict__ grad_base, size_t grad_stride,
@@ -377,6 +379,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float c0[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) c0[k] = cov_full ? cov3D[9 * (size_t)i + kTriu[k]] : cov3D[6 * (size_t)i + k];
+        // (the blend summed the moments of dL/dalpha * G: the Gaussian's opacity completes w = dL/dG * G -- see render_bwd)
+        const float opac = opacities[i];
         float shbuf[48];
         if (have_sh) {
             if (d.flags & FS_RASTER_SH_FP16) {
@@ -402,6 +406,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const ushort4 rc = g.rect[i];
         if (rc.z > rc.x && rc.w > rc.y) {
             const float* ga = grad + (size_t)i * kGradStride;
+            // the five moment sums of the blend (S_x, S_y, S_xx, S_xy, S_yy)
+            const float S0 = ga[0] * opac, S1 = ga[1] * opac, S2 = ga[2] * opac, S3 = ga[3] * opac, S4 = ga[4] * opac;
             float3 p = p0;
             if (scale_dev) { p.x = p.x * wscale; p.y = p.y * wscale; p.z = p.z * wscale; }
             aop += ga[5];
@@ -423,11 +429,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (denom != 0.0f) {
                 const float det_inv = 1.0f / denom;
                 const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
-                gm2x = -0.5f * (float)d.W * (cA * ga[0] + cB * ga[1]);
-                gm2y = -0.5f * (float)d.H * (cC * ga[1] + cB * ga[0]);
+                gm2x = -0.5f * (float)d.W * (cA * S0 + cB * S1);
+                gm2y = -0.5f * (float)d.H * (cC * S1 + cB * S0);
             }
             am2x += gm2x; am2y += gm2y;
-            const float gcx = -0.5f * ga[2], gcy = -0.5f * ga[3], gcz = -0.5f * ga[4];
+            const float gcx = -0.5f * S2, gcy = -0.5f * S3, gcz = -0.5f * S4;
             float gt[3] = {0, 0, 0};
             if (d2inv != 0.0f) {
                 const float dL_da = d2inv * (-c * c * gcx + 2.0f * b * c * gcy + (denom - a * c) * gcz);
@@ -597,7 +603,7 @@ int launch_render_bwd(const fs_raster_dims& d, const float* bg, const void* geom
 
 // screen space -> Gaussian parameters for V views at once (gradients summed over the views)
 int launch_preprocess_bwd(const fs_raster_dims& d, int V, const float* means3D, const float* cov3D, const float* shs,
-                          const float* view, const float* proj, const float* campos, const float* tanfov,
+                          const float* opacities, const float* view, const float* proj, const float* campos, const float* tanfov,
                           const float* scale, const void* geom, size_t geom_stride, const void* grad, size_t grad_stride,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs, float* dL_dcolors,
                           float* dL_dopacities, int accumulate, hipStream_t st)
@@ -606,7 +612,7 @@ int launch_preprocess_bwd(const fs_raster_dims& d, int V, const float* means3D, 
     {
         ScopedStage prof_(kStPreprocessBwd, st, V);
         hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, V, means3D, cov3D, shs,
-                           view, proj, campos, tanfov, scale, (const char*)geom, geom_stride, (const char*)grad,
+                           opacities, view, proj, campos, tanfov, scale, (const char*)geom, geom_stride, (const char*)grad,
                            grad_stride, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs, dL_dcolors, dL_dopacities,
                            accumulate);
     }
@@ -617,7 +623,7 @@ int launch_preprocess_bwd(const fs_raster_dims& d, int V, const float* means3D, 
 }  // namespace
 
 FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
-                              const float* shs, const float* colors_precomp, const float* bg,
+                              const float* shs, const float* colors_precomp, const float* opacities, const float* bg,
                               const float* viewmatrix, const float* projmatrix, const float* campos,
                               const float* tanfov_dev, const float* scale_dev,
                               const void* geom, const void* binning, const void* image, const uint32_t* counters,
@@ -630,7 +636,7 @@ FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, 
     const fs_raster_dims d = *dims;
     if (d.N < 0 || (d.flags & FS_RASTER_NO_BACKWARD_STATE)) return FS_ERR_INVALID_ARG;   // (that forward kept no n_contrib)
     if (d.N == 0) return FS_OK;  // an empty Gaussian set has empty gradients; its arrays may be NULL (as in the forward)
-    if (!means3D || !cov3D || !bg || !viewmatrix || !projmatrix || !campos || !geom ||
+    if (!means3D || !cov3D || !opacities || !bg || !viewmatrix || !projmatrix || !campos || !geom ||
         !binning || !image || !dL_dcolor || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D ||
         !dL_dcov3D || !dL_dopacities)
         return FS_ERR_INVALID_ARG;
@@ -640,7 +646,7 @@ FS_API int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, 
     hipStream_t st = (hipStream_t)stream_;
     int rc = launch_render_bwd(d, bg, geom, binning, image, counters, dL_dcolor, dL_ddepth, (float*)grad_scratch, st);
     if (rc != FS_OK) return rc;
-    return launch_preprocess_bwd(d, 1, means3D, cov3D, shs, viewmatrix, projmatrix, campos, tanfov_dev, scale_dev, geom, 0,
+    return launch_preprocess_bwd(d, 1, means3D, cov3D, shs, opacities, viewmatrix, projmatrix, campos, tanfov_dev, scale_dev, geom, 0,
                                  grad_scratch, 0, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs, dL_dcolors,
                                  dL_dopacities, accumulate, st);
 }
@@ -660,7 +666,7 @@ struct ForkJoinBwd {
 }  // namespace
 
 FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
-                                    const float* shs, const float* colors_precomp, const float* bg,
+                                    const float* shs, const float* colors_precomp, const float* opacities, const float* bg,
                                     const float* viewmatrix, const float* projmatrix, const float* campos,
                                     const float* tanfov, const float* scale, const void* geom, const void* binning,
                                     const void* image, const uint32_t* counters, const size_t strides[3], const float* dL_dcolor,
@@ -674,7 +680,7 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
     const fs_raster_dims d = *dims;
     if (d.N < 0 || (d.flags & FS_RASTER_NO_BACKWARD_STATE)) return FS_ERR_INVALID_ARG;
     if (d.N == 0) return FS_OK;
-    if (!means3D || !cov3D || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
+    if (!means3D || !cov3D || !opacities || !bg || !viewmatrix || !projmatrix || !campos || !geom || !binning || !image ||
         !dL_dcolor || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D || !dL_dcov3D || !dL_dopacities)
         return FS_ERR_INVALID_ARG;
     if ((shs == nullptr) == (colors_precomp == nullptr)) return FS_ERR_INVALID_ARG;
@@ -716,7 +722,7 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
         }
     if (rc != FS_OK) return rc;
     // one pass over the Gaussians for all views
-    return launch_preprocess_bwd(d, v, means3D, cov3D, shs, viewmatrix, projmatrix, campos, tanfov, scale, geom,
+    return launch_preprocess_bwd(d, v, means3D, cov3D, shs, opacities, viewmatrix, projmatrix, campos, tanfov, scale, geom,
                                  strides[0], grad_scratch, grad_stride, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs,
                                  dL_dcolors, dL_dopacities, accumulate, main);
 }

@@ -863,7 +863,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const char* __restrict_
 // compare-exchange is ascending, so an arbitrary length n works in place: partners >= n are
 // virtual +inf and never move.
 // ------------------------------------------------------------------------------------------
-constexpr int kSortLds = 2048;  // 64-bit LDS exchange slots per workgroup (16 KiB: 10 workgroups/CU); exchanges of more keys go in halves
+#ifndef FS_SORT_LDS
+#define FS_SORT_LDS 1792     // a multiple of 256 (A/B builds: -DFS_SORT_LDS=2048 -DFS_BLEND_WAVES=6 = rounds 3 - 5)
+#endif
+constexpr int kSortLds = FS_SORT_LDS;  // keys one LDS sort takes = 64-bit staging slots per workgroup (14 KiB)
 
 template <typename Ptr>
 __device__ __forceinline__ void bitonic_sort_any(Ptr a, uint32_t n)
@@ -1134,14 +1137,29 @@ __device__ __forceinline__ void sort_tile_buckets(const unsigned long long* keys
 #pragma unroll
     for (int w = 0; w < 3; ++w) run += w < wave ? s_red[8 + w] : 0u;
     if (degenerate) {
-        Stages<EPT, CAP>::run(k, t, sk);  // (its exchanges synchronise the workgroup themselves)
-        __syncthreads();
+        if constexpr ((EPT & (EPT - 1)) == 0) {
+            Stages<EPT, CAP>::run(k, t, sk);  // (its exchanges synchronise the workgroup themselves)
+            __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const uint32_t i = (uint32_t)t * EPT + e;
-            if (i < n) {
-                list[i] = (uint32_t)k[e];
-                if (gout) gout[i] = (uint32_t)k[e];
+            for (int e = 0; e < EPT; ++e) {
+                const uint32_t i = (uint32_t)t * EPT + e;
+                if (i < n) {
+                    list[i] = (uint32_t)k[e];
+                    if (gout) gout[i] = (uint32_t)k[e];
+                }
+            }
+        } else {
+            // (the register network needs a power-of-two key count per thread: CAP = 1792 sorts in the LDS staging instead)
+            __syncthreads();   // (`keys` may BE the staging -- sort_tile_partitioned: every thread holds its keys in registers now)
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if ((uint32_t)(e * 256 + t) < n) sk[e * 256 + t] = k[e];
+            __syncthreads();
+            bitonic_sort_any(sk, n);
+            for (uint32_t i = (uint32_t)t; i < n; i += 256u) {
+                const uint32_t wd = (uint32_t)sk[i];
+                list[i] = wd;
+                if (gout) gout[i] = wd;
             }
         }
         return;
@@ -1481,8 +1499,10 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
 // ------------------------------------------------------------------------------------------
 // sort_blend: one workgroup per tile.  All four wavefronts sort the tile's keys in LDS (bucket sort above), the sorted
 // list words stay in LDS, then each wavefront blends its own quadrant from them without another workgroup barrier.
-// LDS: 16 KiB key staging (reused as the four wavefronts' compaction areas once the sort is done) + 8 KiB bucket
-// offsets (reused as the sorted list) = 24.2 KiB -> 6 workgroups per CU, 6 wavefronts per SIMD.
+// LDS: 14 KiB key staging for 1 792 keys (reused as the four wavefronts' compaction areas once the sort is done) + 7 KiB bucket
+// offsets (reused as the sorted list) = 21.6 KiB -> 7 workgroups per CU, 7 wavefronts per SIMD at 68 - 72 registers (round 6;
+// rounds 3 - 5: 2 048 keys, 24.6 KiB, 6 wavefronts at 80 registers -- the longest tile list of config 3 is 1 338 entries.
+// Same-session A/B, profiles/r6_blend_waves_ab.txt: +1.3 % views/s at config 3, +7 % on the close-up workload).
 // Lists longer than the LDS sort's 2048 keys (none in the BASELINE configs; every tile of the c3_closeup workload) are
 // sorted into the saved list in global memory by the two-level distribution sort (sort_tile_partitioned: histogram ->
 // groups of <= 2048 keys -> one LDS bucket sort per group) and blended from there; a tile it declines (thousands of equal
@@ -1491,7 +1511,7 @@ __device__ __forceinline__ void blend_quadrant(const uint32_t* pl, int n, const 
 static_assert(4 * kPairArea * sizeof(float4) <= kSortLds * sizeof(unsigned long long), "compaction areas must fit the key staging");
 template <bool FAST_EXP, bool TRACK>
 #ifndef FS_BLEND_WAVES
-#define FS_BLEND_WAVES 6      // (A/B builds: make VARIANT=w4 EXTRA=-DFS_BLEND_WAVES=4)
+#define FS_BLEND_WAVES 7      // (A/B builds: make VARIANT=w6 EXTRA="-DFS_BLEND_WAVES=6 -DFS_SORT_LDS=2048")
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_BLEND_WAVES, FS_BLEND_WAVES))) void sort_blend_kernel(
     int H, int W, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t tile_cap,
@@ -1520,8 +1540,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_BLEND_WA
         sort_tile_buckets<2>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
     } else if (n <= 1024u) {
         sort_tile_buckets<4>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
-    } else if (n <= 2048u) {
-        sort_tile_buckets<8>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
+    } else if (n <= (uint32_t)kSortLds) {
+        sort_tile_buckets<kSortLds / 256>(kt, TRACK ? gl : nullptr, n, sk, s_cnt, s_red);
     }
 #ifdef FS_LONG_SORT_NETWORKS   // (rounds 1 - 4: register bitonic networks up to 4096 keys, the global-memory network beyond; A/B builds)
     else if (n <= 2560u) {

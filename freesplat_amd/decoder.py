@@ -256,13 +256,13 @@ class _RenderViews(torch.autograd.Function):
             st.last_instances = worst
         ctx.states = states
         ctx.batch = batch
-        ctx.save_for_backward(means, cov6, shs)
+        ctx.save_for_backward(means, cov6, shs, opac)
         ctx.set_materialize_grads(False)
         return color, depth
 
     @staticmethod
     def backward(ctx, g_color, g_depth):
-        means, cov6, shs = ctx.saved_tensors
+        means, cov6, shs, opac = ctx.saved_tensors
         if g_color is None and g_depth is None:
             return (None,) * 14
         v = len(ctx.states)
@@ -292,7 +292,7 @@ class _RenderViews(torch.autograd.Function):
             handles = (C.c_void_p * max(n_streams, 1))(*[s.cuda_stream for s in st.side_streams[:n_streams]])
             p = R._lib.ptr
             R._lib.check(R._lib.lib().fs_raster_backward_views(
-                C.byref(b["dims"]), v, p(means), p(cov6), p(shs), None, p(b["bgs"]), p(b["views"]), p(b["fulls"]),
+                C.byref(b["dims"]), v, p(means), p(cov6), p(shs), None, p(opac), p(b["bgs"]), p(b["views"]), p(b["fulls"]),
                 p(b["campos"]), p(b["tanfov"]), p(b["scale"]), p(b["geom"]), p(b["binning"]), p(b["image"]), p(b["counters"]),
                 strides,
                 p(g_color), p(g_depth), p(scratch), p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]), p(out["shs"]),
@@ -302,7 +302,7 @@ class _RenderViews(torch.autograd.Function):
             view_grads = lambda i: (None if g_color is None else g_color[i], None if g_depth is None else g_depth[i])
             out = None
             for i, rs in enumerate(ctx.states):
-                out = R.rasterize_backward(rs, means, cov6, shs, None, *view_grads(i), out=out, accumulate=i > 0)
+                out = R.rasterize_backward(rs, means, cov6, shs, None, opac, *view_grads(i), out=out, accumulate=i > 0)
         g_shs = out["shs"] if shs.dtype == torch.float32 else out["shs"].to(shs.dtype)
         return (out["means3D"], out["cov3D"], g_shs, out["opacities"]) + (None,) * 10
 

@@ -226,7 +226,7 @@ def rasterize_forward_checked(dims, means3D, cov3D, shs, colors, opacities, bg, 
     return rs, color, depth, alpha
 
 
-def rasterize_backward(rs: RasterState, means3D, cov3D, shs, colors, g_color, g_depth, out=None,
+def rasterize_backward(rs: RasterState, means3D, cov3D, shs, colors, opacities, g_color, g_depth, out=None,
                        accumulate: bool = False):
     """Launch the backward of one view.  `out` = dict of preallocated gradient tensors (for the
     multi-view accumulate path) or None to allocate."""
@@ -250,7 +250,7 @@ def rasterize_backward(rs: RasterState, means3D, cov3D, shs, colors, g_color, g_
         g_depth = g_depth.contiguous()
     p = _lib.ptr
     _lib.check(_lib.lib().fs_raster_backward(
-        C.byref(d), p(means3D), p(cov3D), p(shs), p(colors), p(rs.bg), p(rs.view), p(rs.proj),
+        C.byref(d), p(means3D), p(cov3D), p(shs), p(colors), p(opacities), p(rs.bg), p(rs.view), p(rs.proj),
         p(rs.campos), p(rs.tanfov), p(rs.scale), p(rs.geom), p(rs.binning), p(rs.image), p(rs.counters), p(g_color),
         p(g_depth), p(scratch),
         p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]), p(out["shs"]), p(out["colors"]),
@@ -273,20 +273,20 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                             opacities, bg, view, proj, campos)
         ctx.rs = rs
         ctx.opac_shape = None
-        ctx.save_for_backward(means3D, cov3D, shs, colors_precomp)
+        ctx.save_for_backward(means3D, cov3D, shs, colors_precomp, opacities)
         ctx.mark_non_differentiable(rs.radii)
         ctx.set_materialize_grads(False)
         return color, rs.radii, depth, alpha
 
     @staticmethod
     def backward(ctx, g_color, _g_radii, g_depth, g_alpha):
-        means3D, cov3D, shs, colors = ctx.saved_tensors
+        means3D, cov3D, shs, colors, opacities = ctx.saved_tensors
         if g_alpha is not None:
             raise NotImplementedError("gradient through the accumulated-alpha output is not supported "
                                       "(no reference caller uses it; cuda_splatting.py:120)")
         if g_color is None and g_depth is None:
             return (None,) * 7
-        g = rasterize_backward(ctx.rs, means3D, cov3D, shs, colors, g_color, g_depth)
+        g = rasterize_backward(ctx.rs, means3D, cov3D, shs, colors, opacities, g_color, g_depth)
         g_shs = g["shs"] if (shs is None or shs.dtype == torch.float32) else g["shs"].to(shs.dtype)
         return g["means3D"], g["means2D"], g_shs, g["colors"], g["opacities"], g["cov3D"], None
 

@@ -177,9 +177,11 @@ int fs_raster_forward_views(const fs_raster_dims* dims, int32_t v, const float* 
  * dL_dmeans3D[N,3], dL_dmeans2D[N,3] (screen-space grad
  * sink, z = 0; cuda_splatting.py:94-98), dL_dcov3D[N,6] (off-diagonals carry both symmetric
  * positions), dL_dshs[N,M,3] or dL_dcolors[N,3] (the other NULL), dL_dopacities[N].
+ * `opacities` [N] = the forward's (ABI revision 6: the blend backward sums the geometric moments of dL/dalpha * G and the
+ * per-Gaussian pass multiplies them by the opacity).
  */
 int fs_raster_backward(const fs_raster_dims* dims, const float* means3D, const float* cov3D,
-                       const float* shs, const float* colors_precomp, const float* bg,
+                       const float* shs, const float* colors_precomp, const float* opacities, const float* bg,
                        const float* viewmatrix, const float* projmatrix, const float* campos,
                        const float* tanfov_dev, const float* scale_dev,
                        const void* geom, const void* binning, const void* image, const uint32_t* counters,
@@ -466,7 +468,7 @@ int fs_depth_tail_backward(int32_t B, int32_t D, int32_t h2, int32_t w2, const f
  * parameter gradients (inputs read once, sums in registers, outputs written once; `accumulate` adds to their
  * current contents).  Stream-ordered on main_stream like fs_raster_forward_views. */
 int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
-                             const float* shs, const float* colors_precomp, const float* bg,
+                             const float* shs, const float* colors_precomp, const float* opacities, const float* bg,
                              const float* viewmatrix, const float* projmatrix, const float* campos,
                              const float* tanfov, const float* scale, const void* geom, const void* binning,
                              const void* image, const uint32_t* counters, const size_t strides[3], const float* dL_dcolor,

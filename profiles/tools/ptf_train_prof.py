@@ -4,7 +4,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_ptf_hip import _scene
 from freesplat_amd.ptf import PixelwiseTripletFusion
 dev = torch.device("cuda:0")
-V, h, w = 2, 384, 512
+V, h, w = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2, 384, 512)
 E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=5)
 torch.manual_seed(1)
 m = PixelwiseTripletFusion().to(dev)
@@ -20,4 +20,4 @@ def step():
 for _ in range(3): step()
 torch.cuda.synchronize(); t=time.perf_counter()
 for _ in range(10): step()
-torch.cuda.synchronize(); print("ms/step", (time.perf_counter()-t)*100)
+torch.cuda.synchronize(); print(f"fold {V} views {h}x{w}: ms/step", (time.perf_counter()-t)*100)

@@ -793,4 +793,4 @@ def test_inference_forward_keeps_no_backward_state(hip_device):
                                                   d(vi["bg"]), d(vi["viewmatrix"]), d(vi["projmatrix"]), d(vi["campos"]))
     assert torch.equal(color, c_inf)
     with pytest.raises(_lib.FreeSplatHipError):
-        R.rasterize_backward(rs, d(vi["means3D"]), d(vi["cov3D"]), d(vi["shs"]), None, torch.ones_like(color), None)
+        R.rasterize_backward(rs, d(vi["means3D"]), d(vi["cov3D"]), d(vi["shs"]), None, d(vi["opacities"]), torch.ones_like(color), None)

@@ -236,3 +236,113 @@ def test_gloo_world3_ragged_gather_and_bucket_packing(n_views, N):
     """Three ranks: the trimmed all-gather of ragged view shards (more than one short shard), the reduce-scatter bucket with
     evenly divisible rows (N = 9: one strided copy per tensor) and ragged ones (N = 10, N < world), and its reuse."""
     assert all(ok for _, ok in _run(3, _world3_worker, n_views, N))
+
+
+def _toy_render_views(extrinsics, intrinsics, near, far, image_shape, bg, means, cov, sh, op, **_):
+    """render_views' signature on CPU tensors (the HIP rasterizer cannot run here): [v,3,h,w] colour and [v,1,h,w] depth that
+    depend nonlinearly on every Gaussian tensor and on the view's camera."""
+    h, w = image_shape
+    v = extrinsics.shape[0]
+    feat = torch.cat([means, cov.reshape(-1, 9), sh.reshape(-1, 27), op[:, None]], dim=1)                 # [N,40]
+    cam = extrinsics.reshape(v, 16)[:, :12]                                                                # [v,12]
+    k = torch.arange(1, 4 * h * w + 1, dtype=torch.float32).reshape(1, 1, -1) * 0.01
+    wgt = torch.sin(cam.sum(1)[:, None, None] + k * torch.arange(1, 41, dtype=torch.float32)[None, :, None])   # [v,40,4hw]
+    img = torch.tanh(torch.einsum("nf,vfk->vk", feat, wgt) * 0.1).reshape(v, 4, h, w)
+    return img[:, :3] + bg[:, :, None, None], img[:, 3:4]
+
+
+def _world8_worker(rank, world, port, q):
+    """BASELINE config 4's real split on 8 ranks: 10 context views (shards 2,2,1,1,1,1,1,1) through sharded_cost_volume, 4 target
+    views (four EMPTY shards) through gather_views, reduce_scatter_gaussian_grads and DecoderSplattingCUDA(group=...)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    _init(rank, world, port)
+    try:
+        import inputs
+        from oracle import cost_volume_oracle as cvo
+        from freesplat_amd import decoder as D_
+        from freesplat_amd.cost_volume import sharded_cost_volume
+        from freesplat_amd.encoder_glue import prepare_cost_volume_inputs
+        ok = shard_counts(10, 8) == [2, 2, 1, 1, 1, 1, 1, 1] and shard_counts(4, 8) == [1, 1, 1, 1, 0, 0, 0, 0]
+        # ---- cost volume: 10 context views, the 9 pose-nearest as sources (K = 8) ----
+        V, ncv, h4, w4, Dp, C = 10, 9, 6, 8, 4, 48
+        E, Kn = inputs.cameras(V, h4, w4, baseline=1.2, seed=5)
+        feats = torch.randn(V, C, h4, w4, generator=torch.Generator().manual_seed(9))
+        g = torch.Generator().manual_seed(1)
+        mlp = cvo.mlp_from_state({"mlp__net__0__weight": torch.randn(32, 49, generator=g) * 0.2, "mlp__net__0__bias": torch.randn(32, generator=g) * 0.1,
+                                  "mlp__net__2__weight": torch.randn(32, 32, generator=g) * 0.2, "mlp__net__2__bias": torch.randn(32, generator=g) * 0.1,
+                                  "mlp__net__4__weight": torch.randn(1, 32, generator=g) * 0.2, "mlp__net__4__bias": torch.randn(1, generator=g) * 0.1})
+
+        def rows(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth):
+            return cvo.cost_volume(cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, min_depth, max_depth, Dp, mlp)
+        near, far = torch.full((1, V), 0.5), torch.full((1, V), 15.0)
+        f_ref = feats.clone().requires_grad_(True)
+        ref = rows(**prepare_cost_volume_inputs(E[None], Kn[None], f_ref, near, far, (4 * h4, 4 * w4), ncv))
+        wgt = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2))
+        (ref * wgt).sum().backward()
+        mine = shard_range(V, rank, world)
+        f_loc = feats[mine.start: mine.stop].clone().requires_grad_(True)
+        out = sharded_cost_volume(rows, f_loc, E[None], Kn[None], near, far, (4 * h4, 4 * w4), ncv)
+        ok = ok and out.shape[0] == len(mine) and torch.allclose(out, ref.detach()[mine.start: mine.stop], atol=1e-6)
+        (out * wgt[mine.start: mine.stop]).sum().backward()
+        ok = ok and torch.allclose(f_loc.grad, f_ref.grad[mine.start: mine.stop], atol=1e-5)
+        # ---- 4 target views on 8 ranks: plain gather with four empty shards ----
+        tv = 4
+        tmine = shard_range(tv, rank, world)
+        local = torch.stack([_fake_render(v) for v in tmine]) if len(tmine) else torch.zeros(0, 3, 6, 8)
+        ok = ok and torch.equal(gather_views(local, tv), torch.stack([_fake_render(v) for v in range(tv)]))
+        # ---- Gaussian-gradient reduce-scatter, rows not divisible by 8 ----
+        N = 21
+        gg = torch.Generator().manual_seed(7 + rank)
+        grads = [torch.randn(N, 3, generator=gg), torch.randn(N, 3, 3, generator=gg), torch.randn(N, 3, 9, generator=gg), torch.randn(N, generator=gg)]
+        shards = reduce_scatter_gaussian_grads([t.clone() for t in grads])
+        full = [t.clone() for t in grads]
+        allreduce_gaussian_grads(full)
+        rws = shard_range(N, rank, world)
+        ok = ok and all(torch.allclose(sh, fu[rws.start: rws.stop], atol=1e-5) for sh, fu in zip(shards, full))
+        # ---- the decoder itself: DecoderSplattingCUDA(group=True)._forward_sharded with the CPU stand-in renderer ----
+        D_.render_views = _toy_render_views
+        gen = torch.Generator().manual_seed(3)          # the same scene on every rank (the decoder checks that)
+        Ng = 13
+        leaves = [torch.randn(Ng, 3, generator=gen), torch.randn(Ng, 3, 3, generator=gen), torch.randn(Ng, 3, 9, generator=gen),
+                  torch.rand(Ng, generator=gen)]
+        Et = torch.randn(1, tv, 4, 4, generator=gen)
+        Kt = torch.rand(1, tv, 3, 3, generator=gen)
+        nf = torch.full((1, tv), 0.5), torch.full((1, tv), 15.0)
+        wimg = torch.randn(1, tv, 3, 5, 6, generator=gen)
+        wdep = torch.randn(1, tv, 5, 6, generator=gen)
+        bgc = (0.1, 0.2, 0.3)
+        ref_l = [t.clone().requires_grad_(True) for t in leaves]
+        c_ref, d_ref = _toy_render_views(Et[0], Kt[0], nf[0][0], nf[1][0], (5, 6), torch.tensor(bgc)[None].expand(tv, 3), *ref_l)
+        ((c_ref[None] * wimg).sum() + (d_ref[None, :, 0] / 2 * wdep).sum()).backward()
+        sh_l = [t.clone().requires_grad_(True) for t in leaves]
+        dec = D_.DecoderSplattingCUDA(background_color=bgc, group=True)
+        gs = D_.Gaussians(*(t[None] for t in sh_l))
+        o = dec(gs, Et, Kt, nf[0], nf[1], (5, 6), depth_mode="depth")
+        ok = ok and torch.allclose(o.color[0], c_ref.detach(), atol=1e-6) and torch.allclose(o.depth[0], d_ref.detach()[:, 0] / 2, atol=1e-6)
+        ((o.color * wimg).sum() + (o.depth * wdep).sum()).backward()
+        for a, b_ in zip(sh_l, ref_l):
+            ok = ok and torch.allclose(a.grad, b_.grad, atol=1e-5)
+        # a rank holding a DIFFERENT scene must be refused (Lightning DDP hands every rank its own batch)
+        if world > 1:
+            bad = [t.clone() for t in leaves]
+            if rank == 5:
+                bad[0] = bad[0] + 1.0
+            dec2 = D_.DecoderSplattingCUDA(background_color=bgc, group=True)
+            try:
+                dec2(D_.Gaussians(*(t[None] for t in bad)), Et, Kt, nf[0], nf[1], (5, 6))
+                ok = False
+            except RuntimeError:
+                pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world8_config4_split():
+    """the multi-GPU code paths at the world size they will first meet on hardware, with BASELINE config 4's
+    real numbers -- 10 context views on 8 ranks (2,2,1,1,1,1,1,1), 4 target views on 8 ranks (four ranks render nothing) --
+    through sharded_cost_volume (all-gather of features, reduce-scatter in backward), gather_views, the Gaussian-gradient
+    reduce-scatter and DecoderSplattingCUDA(group=...) forward + backward (outputs and gradients equal the unsharded ones on
+    every rank, empty shards keep the graph connected, a rank with a different scene is refused)."""
+    assert all(ok for _, ok in _run(8, _world8_worker))
