@@ -350,6 +350,8 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
         "config": {"workload": workload, "mode": mode, "image_hw": [H, W], "gaussians": N,
                    "sh_degree": 2, "sh_storage": "fp16" if sh_fp16 else "fp32", "views_per_step_per_gpu": views,
                    "raster_streams": R_NUM_STREAMS,
+                   "projection": "legacy per-view kernel (FREESPLAT_PREPROCESS=legacy)" if os.environ.get("FREESPLAT_PREPROCESS") == "legacy" else
+                                 f"all views of a call in one launch, {os.environ.get('FREESPLAT_RASTER_BATCH', '16')} views per batch",
                    "blend_exp": "hardware v_exp_f32" if _R_FAST() else "contract polynomial",
                    "blend": ("training instantiation (tracks n_contrib, writes the sorted lists for the backward)" if train else
                              "inference instantiation (torch.no_grad: no n_contrib tracking, sorted lists stay in LDS; same image bits)"),
@@ -363,8 +365,12 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
     from freesplat_amd import rasterizer as _Rz
     cap_now = _Rz.default_capacity(N, _state(dev), H, W)
     bsz = _Rz._buffer_sizes(N, H, W, cap_now)
+    slots = int(_lib.lib().fs_raster_scratch_slots(len(mine), R_NUM_STREAMS if R_NUM_STREAMS > 1 else 0))
     out["raster_buffers"] = {"instance_capacity": int(cap_now), "geom_bytes_per_view": bsz[0], "binning_bytes_per_view": bsz[1],
                              "image_bytes_per_view": bsz[2], "scratch_bytes_per_stream": bsz[3],
+                             "scratch_slots_per_call": slots, "scratch_bytes_per_call": slots * bsz[3],
+                             "scratch_note": "one key area (scratch_bytes_per_stream: the field's name since round 3) per view in flight: "
+                                             "the projection + binning of all views of a call is ONE launch (round 6), at most 16 slots",
                              "capacity_retries": capacity_retries,
                              "note": "capacity_retries = warm-up passes repeated after an instance-capacity overflow (first contact "
                                      "with a workload denser than 8 entries per Gaussian); the timed region never retries"}

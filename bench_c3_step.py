@@ -227,6 +227,7 @@ def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_tar
             "glue_ms": None if glue is None else glue["glue_ms_per_step"],
             "glue_frac_of_gpu_time": None if glue is None else glue["glue_frac_of_hotpath_gpu_time"],
             "glue_source": None if glue is None else glue["source"],
+            "glue_measured_in_this_run": False,
             "glue_note": "from the committed rocprofv3 kernel trace of this step, kernels classified by name: glue / (library kernels + "
                          "glue); the stand-ins' kernels are left out of the denominator",
             "loss": float(loss.detach()) if train else None}

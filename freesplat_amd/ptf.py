@@ -109,7 +109,20 @@ def match_view(xyz: Tensor, w2c: Tensor, kpix: Tensor, depth_i: Tensor, h: int, 
 
 # operand tables per GRU module, valid while the parameters keep their storage and version; weak keys: a table must not
 # outlive its module (a new module may get the same id(), the same parameter addresses and the same version counters)
-_KEEP_BYTES = int(os.environ.get("FREESPLAT_PTF_KEEP_BYTES", str(8 << 30)))   # see _PtfFold.forward
+_KEEP_BYTES_ENV = os.environ.get("FREESPLAT_PTF_KEEP_BYTES")   # see _PtfFold.forward
+
+
+def _keep_bytes(device) -> int:
+    """How many bytes of worst-case fold state a training fold may keep untrimmed until its backward: FREESPLAT_PTF_KEEP_BYTES if
+    set, else 1/16 of the memory currently free on the device, capped at 8 GiB (18 GB on an idle MI355X -> 8 GiB; a card with
+    16 GB free keeps 1 GB and trims above it -- ADVICE r5: a fixed 8 GiB could run smaller devices out of memory)."""
+    if _KEEP_BYTES_ENV is not None:
+        return int(_KEEP_BYTES_ENV)
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+    except Exception:
+        return 1 << 30
+    return int(min(8 << 30, free // 16))
 _table_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 LAST_FOLD_COUNTS = None   # device tensor [V,4] (kept, fused, appended, state rows) of the last fused fold: bench accounting
 
@@ -430,11 +443,11 @@ class _PtfFold(torch.autograd.Function):
         # rows that exist (one copy of sum_i n_i rows, ~0.3 ms at 10 views): what the backward holds on to is O(V n).
         # The LAST state is only returned (the backward reads states 0 .. V-2): its G, X, E, D stay views of the worst-case
         # buffer unless that would pin more than 256 MB of rows that do not exist.
-        # ... unless the worst-case buffers are small next to the device's memory (FREESPLAT_PTF_KEEP_BYTES, default 8 GiB: config 3's
+        # ... unless the worst-case buffers are small next to the device's memory (_keep_bytes: FREESPLAT_PTF_KEEP_BYTES, default 1/16 of the free device memory up to 8 GiB: config 3's
         # three views at 968x1296 queue 2.2 GB): then nothing is copied -- the trims were 0.8 ms of rocclr copies per config-3
         # training step (profiles/r5_c3_step_glue.json) for memory a 288 GB device does not miss.
         worst = sum((i + 1) * P for i in range(1, V)) * 86 * 4
-        trim = worst > _KEEP_BYTES
+        trim = worst > _keep_bytes(lat.device)
         for i in range(1, V - 1):
             states[i] = tuple((t[: cnt[i][3]].clone() if trim else t[: cnt[i][3]]) for t in states[i])
         G, X, R, O, E, D = states[V - 1]
