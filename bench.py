@@ -55,8 +55,10 @@ def parse():
                     help="top-level measurement. fwd: forward rendering (the metric); train: fwd + bwd (+ grad exchange)")
     ap.add_argument("--sections", default="all",
                     help="N=1 only: comma list of extra sub-objects (train,c2,closeup,c5,cost_volume,ptf,encoder_tail,c3_step), 'all', or 'raster' for none")
-    ap.add_argument("--grad-exchange", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"],
-                    help="N>1 train mode: how the per-Gaussian gradients of the view shards are summed")
+    ap.add_argument("--grad-exchange", default="reduce_scatter", choices=["reduce_scatter", "all_reduce", "chunked"],
+                    help="N>1 train mode: how the per-Gaussian gradients of the view shards are summed.  chunked = the reduce-scatter "
+                         "issued chunk by chunk of the rows from inside the backward (--grad-chunks), overlapping the per-Gaussian pass")
+    ap.add_argument("--grad-chunks", type=int, default=4, help="row chunks of --grad-exchange chunked")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image all-gather")
     ap.add_argument("--single-rank-collectives", action="store_true",
                     help="N=1 under torch.distributed.run --nproc-per-node 1: initialise RCCL with one rank and take the "
@@ -144,7 +146,7 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
             t.requires_grad_(True)
         target = torch.rand(len(mine), 3, H, W, device=dev)
     gather = AsyncViewGather(n_total_views, device=dev) if (cx.dist_on and not args.no_gather and not train) else None
-    exchange = GradExchange(args.grad_exchange) if (cx.dist_on and train) else None
+    exchange = GradExchange(args.grad_exchange, chunks=args.grad_chunks).install() if (cx.dist_on and train) else None
     diag_events = None      # (set for the few extra untimed steps that time the gradient exchange per rank)
 
     def step():

@@ -98,6 +98,14 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
         _lib.profile_enable(False)
         ms, cnt = _lib.profile_collect()["cost_volume"]
     flops = V * h4 * w4 * D * (480 * K + 5248)
+    # the same inference call on channels_last feature maps (K >= 2: read in place by fs_cost_volume_forward_layout, no re-layout pass)
+    dt_cl = None
+    if K >= 2:
+        args_cl = dict(args, cur_feats=args["cur_feats"].contiguous(memory_format=torch.channels_last),
+                       src_feats=args["src_feats"].permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3))
+        with torch.no_grad():
+            same = bool(torch.equal(mg(**args_cl).cpu(), out))
+            dt_cl = timed(lambda: mg(**args_cl), steps, warmup)
     wl_name = {(2, 1, 96): "cv_native_K1", (3, 2, 242): "cv_c3scale_K2", (10, 8, 96): "cv_fvt10_K8"}.get((V, K, h4), "")
     kern = ms / max(cnt, 1) * 1e-3
     # training step of the volume: forward + backward w.r.t. both feature maps and the six MLP tensors
@@ -163,6 +171,11 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
                          "mfma_busy_note": "matrix-pipe busy fraction from SQ_VALU_MFMA_BUSY_CYCLES (native K = 1 profile); `frac` "
                                            "prices the reference formulation's flops (41 MFMAs per cell), the K = 1 sweep issues 16",
                          "traffic": _traffic(wl_name)[0], "traffic_source": _traffic(wl_name)[1],
+                         "channels_last": None if dt_cl is None else {
+                             "ms_per_call": dt_cl * 1e3, "same_volume_bit_for_bit": same,
+                             "traffic": _traffic(wl_name + "_cl")[0], "traffic_source": _traffic(wl_name + "_cl")[1],
+                             "what": "the same call with cur_feats / src_feats given as channels_last tensors: the 16-pixel sweep reads "
+                                     "them in place, the two NCHW -> pixel-major re-layout launches are gone"},
                          "traffic_unit": "HBM bytes per call (all current views)",
                          "algorithmic_bytes_per_call": 4 * V * ((1 + K) * C + D) * h4 * w4,
                          # the general (K >= 2) sweep gathers 4 bilinear taps x C channels per (pixel, plane, source) through the

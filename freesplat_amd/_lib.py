@@ -60,6 +60,7 @@ SIGNATURES = {
     "fs_raster_backward": (C.c_int, [C.POINTER(RasterDims)] + [_VP] * 24 + [C.c_int, _VP]),
     "fs_cost_volume_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
     "fs_cost_volume_forward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 9),
+    "fs_cost_volume_forward_layout": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 8 + [C.c_int32, _VP]),
     "fs_cost_volume_backward_workspace_bytes": (C.c_size_t, [C.c_int32] * 6),
     "fs_cost_volume_backward_workspace_bytes_for": (C.c_size_t, [C.c_int32] * 6 + [C.c_int64]),
     "fs_cost_volume_backward": (C.c_int, [C.c_int32] * 6 + [_VP] * 6 + [C.c_int64] * 3 + [_VP] * 16),
@@ -90,6 +91,8 @@ SIGNATURES = {
                                 + [_VP] * 5 + [C.c_int32, C.POINTER(C.c_void_p), _VP]),
     "fs_raster_backward_views": (C.c_int, [C.POINTER(RasterDims), C.c_int32] + [_VP] * 15 + [C.POINTER(C.c_size_t)] + [_VP] * 9
                                  + [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _VP]),
+    "fs_raster_backward_views_rows": (C.c_int, [C.POINTER(RasterDims), C.c_int32] + [_VP] * 15 + [C.POINTER(C.c_size_t)] + [_VP] * 9
+                                      + [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _VP, C.c_int32, C.c_int32, C.c_int32]),
     "fs_ptf_fold_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
     "fs_ptf_fold_step": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 14 + [C.c_float] + [_VP] * 10),
     "fs_ptf_fold_bytes": (C.c_size_t, [C.c_int32] * 3),

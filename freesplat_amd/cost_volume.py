@@ -67,7 +67,7 @@ class MLP(nn.Module):
 class _CostVolumeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, strides, w1, b1, w2, b2,
-                w3, b3):
+                w3, b3, layout=0):
         B, K, C, h, w = src_feats.shape
         D = planes.shape[0] if planes.dim() == 1 else planes.shape[1]
         dev = cur_feats.device
@@ -85,6 +85,14 @@ class _CostVolumeFn(torch.autograd.Function):
                                                       p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
                                                       p(w1), p(b1), p(w2), p(b2), p(w3), p(b3), p(ws), p(out), p(saved),
                                                       _lib.current_stream()), "fs_cost_volume_forward_train")
+        elif layout:
+            # inference on channels_last maps (pixel-major records): read in place, no re-layout pass (AVGFeatureVolumeManager.forward)
+            saved = None
+            _lib.check(L.fs_cost_volume_forward_layout(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
+                                                       p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
+                                                       p(w1), p(b1), p(w2), p(b2), p(w3), p(b3), p(ws), p(out), layout,
+                                                       _lib.current_stream()), "fs_cost_volume_forward_layout")
+            return out
         else:
             saved = None
             _lib.check(L.fs_cost_volume_forward(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
@@ -124,7 +132,7 @@ class _CostVolumeFn(torch.autograd.Function):
                                                  p(d_w2), p(d_b2), p(d_w3), p(d_b3), _lib.current_stream()),
                        "fs_cost_volume_backward")
         # (every gradient, the MLP's included, comes out of the one kernel: no per-point workspace, no GEMMs here)
-        return d_cur, d_src, None, None, None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
+        return d_cur, d_src, None, None, None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, None
 
 
 def _dev32(t: Tensor, name: str) -> Tensor:
@@ -132,6 +140,14 @@ def _dev32(t: Tensor, name: str) -> Tensor:
         raise RuntimeError(f"freesplat_amd cost volume: `{name}` must live on a HIP device (got {t.device}); "
                            "there is no CPU path")
     return t.float().contiguous()
+
+
+def _pixel_major(t: Tensor) -> bool:
+    """A float32 HIP tensor [..., C, h, w] whose MEMORY is [..., h, w, C] (channels_last for 4-D; the same strides under leading
+    dimensions for the 5-D source maps) and not also plain-contiguous (C = 1 or h * w = 1 are both at once: nothing to gain)."""
+    if t.device.type != "cuda" or t.dtype != torch.float32 or t.dim() < 4 or t.is_contiguous():
+        return False
+    return t.movedim(-3, -1).is_contiguous()
 
 
 class AVGFeatureVolumeManager(nn.Module):
@@ -188,6 +204,19 @@ class AVGFeatureVolumeManager(nn.Module):
             D = flat.shape[1]
             strides = (D * h * w, h * w, 1)
         net = self.mlp.net
+        # channels_last feature maps ARE the pixel-major records the K >= 2 sweep gathers from: an inference call reads them in
+        # place (fs_cost_volume_forward_layout) instead of paying a re-layout pass per map -- 425 of the 755 MB a 10-view K = 8 call
+        # moves.  With autograd on, the maps go through .contiguous() as before (the backward takes [C, h, w] maps).
+        layout = 0
+        if not (torch.is_grad_enabled() and (cur_feats.requires_grad or src_feats.requires_grad
+                                             or any(q.requires_grad for q in self.mlp.parameters()))):
+            layout = ((1 if _pixel_major(cur_feats) else 0) | (2 if _pixel_major(src_feats) else 0))
+        if layout:
+            cf = cur_feats if layout & 1 else _dev32(cur_feats, "cur_feats")
+            sf = src_feats if layout & 2 else _dev32(src_feats, "src_feats")
+            return _CostVolumeFn.apply(cf, sf, _dev32(src_extrinsics, "src_extrinsics"), _dev32(src_Ks, "src_Ks"),
+                                       _dev32(cur_invK, "cur_invK"), flat, strides, net[0].weight, net[0].bias,
+                                       net[2].weight, net[2].bias, net[4].weight, net[4].bias, layout)
         return _CostVolumeFn.apply(_dev32(cur_feats, "cur_feats"), _dev32(src_feats, "src_feats"),
                                    _dev32(src_extrinsics, "src_extrinsics"), _dev32(src_Ks, "src_Ks"),
                                    _dev32(cur_invK, "cur_invK"), flat, strides, net[0].weight, net[0].bias,

@@ -1604,9 +1604,10 @@ static int cv_forward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
                            const float* cur_invK, const float* planes, int64_t plane_stride_b,
                            int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
                            const float* b1, const float* w2, const float* b2, const float* w3,
-                           const float* b3, void* workspace, float* out, void* saved, void* stream_)
+                           const float* b3, void* workspace, float* out, void* saved, int layout, void* stream_)
 {
     if (B <= 0 || K <= 0 || h <= 0 || w <= 0 || D <= 0) return FS_ERR_INVALID_ARG;
+    if (layout < 0 || layout > 3) return FS_ERR_INVALID_ARG;
     if (!cur_feats || !src_feats || !src_extrinsics || !src_Ks || !cur_invK || !planes || !w1 || !b1 ||
         !w2 || !b2 || !w3 || !b3 || !workspace || !out)
         return FS_ERR_INVALID_ARG;
@@ -1623,7 +1624,7 @@ static int cv_forward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
         const int groups = (hw + 31) / 32;
         const int slices = cv_plane_split(B, groups, D);
         const dim3 grid(cv_grid(B, groups, slices));
-        if (!saved && cv_use_projected(K)) {
+        if (!saved && layout == 0 && cv_use_projected(K)) {
             // K = 1: first layer's feature block applied per source texel, 16 MFMAs per (group, plane); two launches
             // (the sweep reads the current view from the caller's map and forms its projection rows itself)
             const unsigned gproj = (unsigned)std::min<long long>(((long long)B * K * hw * 8 + 255) / 256, 65536);
@@ -1644,8 +1645,12 @@ static int cv_forward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
             const int groups16 = (hw + 15) / 16;
             const int slices16 = cv_plane_split(B, groups16, D);
             const dim3 grid16(cv_grid(B, groups16, slices16));
-            cv_relayout(false, false, cur_feats, curT, C, hw, B, st);
-            cv_relayout(false, false, src_feats, srcT, C, hw, B * K, st);
+            // (layout bit 0 / 1: the caller's current / source maps already ARE pixel-major [h*w][C] records -- channels_last
+            //  tensors --, which is what the 16-pixel sweep gathers from: no re-layout pass, the sweep reads them in place)
+            const float* curN = cur_feats;
+            const float* srcN = src_feats;
+            if (!(layout & 1)) { cv_relayout(false, false, cur_feats, curT, C, hw, B, st); curN = curT; }
+            if (!(layout & 2)) { cv_relayout(false, false, src_feats, srcT, C, hw, B * K, st); srcN = srcT; }
             // (training: the general sweep for every K -- it forms the averaged features the backward wants to keep; the
             //  K = 1 projected sweep never does)
             uint32_t* xhdr = (uint32_t*)saved;
@@ -1656,7 +1661,7 @@ static int cv_forward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
                 return FS_ERR_LAUNCH;
             }
             auto sweep16 = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, grid16, dim3(256), 0, st, B, K, h, w, D, slices16, curT, srcT, Pmat,
+                hipLaunchKernelGGL(kernel, grid16, dim3(256), 0, st, B, K, h, w, D, slices16, curN, srcN, Pmat,
                                    cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
                                    (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out, xs, xm, xhdr);
             };
@@ -1677,7 +1682,19 @@ FS_API int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, in
                                   const float* b3, void* workspace, float* out, void* stream_)
 {
     return cv_forward_impl(B, K, C, h, w, D, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, plane_stride_b,
-                           plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, b3, workspace, out, nullptr, stream_);
+                           plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, b3, workspace, out, nullptr, 0, stream_);
+}
+
+FS_API int fs_cost_volume_forward_layout(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                         const float* cur_feats, const float* src_feats,
+                                         const float* src_extrinsics, const float* src_Ks,
+                                         const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                                         int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                                         const float* b1, const float* w2, const float* b2, const float* w3,
+                                         const float* b3, void* workspace, float* out, int32_t layout, void* stream_)
+{
+    return cv_forward_impl(B, K, C, h, w, D, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, plane_stride_b,
+                           plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, b3, workspace, out, nullptr, layout, stream_);
 }
 
 FS_API int fs_cost_volume_forward_train(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
@@ -1690,7 +1707,7 @@ FS_API int fs_cost_volume_forward_train(int32_t B, int32_t K, int32_t C, int32_t
 {
     if (!saved) return FS_ERR_INVALID_ARG;
     return cv_forward_impl(B, K, C, h, w, D, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, plane_stride_b,
-                           plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, b3, workspace, out, saved, stream_);
+                           plane_stride_d, plane_stride_pix, w1, b1, w2, b2, w3, b3, workspace, out, saved, 0, stream_);
 }
 
 // The two-pass backward (records + source-tile sweep) needs plane depths that do not vary per pixel (a plane-induced

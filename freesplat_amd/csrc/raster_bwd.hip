@@ -355,11 +355,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const char* __restrict__ grad_base, size_t grad_stride,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac,
-    int accumulate)
+    int accumulate, int row0, int row_end)
 {
+    // rows [row0, row_end) of the Gaussian set (the whole set, or one chunk of a chunked gradient exchange)
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [256 * M*3] SH grads
-    const int base = blockIdx.x * 256;
-    const int cnt = min(256, d.N - base);
+    const int base = row0 + blockIdx.x * 256;
+    const int cnt = min(256, row_end - base);
     const int t = threadIdx.x;
     const int i = base + t;
     const int per_sh = d.M * 3;
@@ -606,15 +607,17 @@ int launch_preprocess_bwd(const fs_raster_dims& d, int V, const float* means3D, 
                           const float* opacities, const float* view, const float* proj, const float* campos, const float* tanfov,
                           const float* scale, const void* geom, size_t geom_stride, const void* grad, size_t grad_stride,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs, float* dL_dcolors,
-                          float* dL_dopacities, int accumulate, hipStream_t st)
+                          float* dL_dopacities, int accumulate, hipStream_t st, int row0 = 0, int nrows = -1)
 {
     const size_t lds = shs ? (size_t)256 * d.M * 3 * sizeof(float) : 0;
+    if (nrows < 0) nrows = d.N - row0;
+    if (nrows <= 0) return FS_OK;
     {
         ScopedStage prof_(kStPreprocessBwd, st, V);
-        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((d.N + 255) / 256), dim3(256), lds, st, d, V, means3D, cov3D, shs,
+        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((nrows + 255) / 256), dim3(256), lds, st, d, V, means3D, cov3D, shs,
                            opacities, view, proj, campos, tanfov, scale, (const char*)geom, geom_stride, (const char*)grad,
                            grad_stride, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs, dL_dcolors, dL_dopacities,
-                           accumulate);
+                           accumulate, row0, row0 + nrows);
     }
     FS_CHECK_LAUNCH("preprocess_bwd");
     return FS_OK;
@@ -665,17 +668,19 @@ struct ForkJoinBwd {
 };
 }  // namespace
 
-FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
+static int raster_backward_views_impl(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
                                     const float* shs, const float* colors_precomp, const float* opacities, const float* bg,
                                     const float* viewmatrix, const float* projmatrix, const float* campos,
                                     const float* tanfov, const float* scale, const void* geom, const void* binning,
                                     const void* image, const uint32_t* counters, const size_t strides[3], const float* dL_dcolor,
                                     const float* dL_ddepth, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
                                     float* dL_dcov3D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
-                                    int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream)
+                                    int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream,
+                                    int32_t row0, int32_t nrows, int32_t with_blend)
 {
     if (!dims || v < 0 || !strides || n_streams < 0 || n_streams > kMaxStreamsBwd || (n_streams > 0 && !streams))
         return FS_ERR_INVALID_ARG;
+    if (row0 < 0 || (nrows >= 0 && (long long)row0 + nrows > dims->N)) return FS_ERR_INVALID_ARG;
     if (v == 0) return FS_OK;
     const fs_raster_dims d = *dims;
     if (d.N < 0 || (d.flags & FS_RASTER_NO_BACKWARD_STATE)) return FS_ERR_INVALID_ARG;
@@ -694,6 +699,11 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
     ForkJoinBwd& fj = *fj_dev[dev_];
     const int ns = n_streams <= 1 ? 0 : (n_streams < v ? n_streams : v);
     hipStream_t main = (hipStream_t)main_stream;
+    const size_t P = (size_t)d.H * d.W, grad_stride = align_up((size_t)d.N * kGradStride * 4, 256);
+    if (!with_blend)   // a later chunk of a chunked gradient exchange: the blend backward of every view already ran
+        return launch_preprocess_bwd(d, v, means3D, cov3D, shs, opacities, viewmatrix, projmatrix, campos, tanfov, scale, geom,
+                                     strides[0], grad_scratch, grad_stride, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs,
+                                     dL_dcolors, dL_dopacities, accumulate, main, row0, nrows);
     if (ns > 0) {
         if (!fj.ok || hipEventRecord(fj.ready, main) != hipSuccess) {
             set_last_error("event record", hipGetLastError());
@@ -705,7 +715,6 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
                 return FS_ERR_LAUNCH;
             }
     }
-    const size_t P = (size_t)d.H * d.W, grad_stride = align_up((size_t)d.N * kGradStride * 4, 256);
     int rc = FS_OK;
     for (int i = 0; i < v && rc == FS_OK; ++i) {  // the blend backward of every view, alternating over the streams
         hipStream_t st = ns > 0 ? (hipStream_t)streams[i % ns] : main;
@@ -724,5 +733,41 @@ FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const
     // one pass over the Gaussians for all views
     return launch_preprocess_bwd(d, v, means3D, cov3D, shs, opacities, viewmatrix, projmatrix, campos, tanfov, scale, geom,
                                  strides[0], grad_scratch, grad_stride, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs,
-                                 dL_dcolors, dL_dopacities, accumulate, main);
+                                 dL_dcolors, dL_dopacities, accumulate, main, row0, nrows);
+}
+
+FS_API int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
+                                    const float* shs, const float* colors_precomp, const float* opacities, const float* bg,
+                                    const float* viewmatrix, const float* projmatrix, const float* campos,
+                                    const float* tanfov, const float* scale, const void* geom, const void* binning,
+                                    const void* image, const uint32_t* counters, const size_t strides[3], const float* dL_dcolor,
+                                    const float* dL_ddepth, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
+                                    float* dL_dcov3D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
+                                    int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream)
+{
+    return raster_backward_views_impl(dims, v, means3D, cov3D, shs, colors_precomp, opacities, bg, viewmatrix, projmatrix, campos,
+                                      tanfov, scale, geom, binning, image, counters, strides, dL_dcolor, dL_ddepth, grad_scratch,
+                                      dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs, dL_dcolors, dL_dopacities, accumulate,
+                                      n_streams, streams, main_stream, 0, -1, 1);
+}
+
+// The same backward with its per-Gaussian pass restricted to rows [row0, row0 + nrows) of the Gaussian set: a caller that
+// exchanges the gradients between GPUs chunk by chunk (view_sharding.GradExchange("chunked")) runs the blend backward of all views
+// with the first chunk (with_blend = 1) and only the per-Gaussian pass for the others (with_blend = 0), so that the
+// reduce-scatter of chunk c overlaps the pass over chunk c + 1.
+FS_API int fs_raster_backward_views_rows(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
+                                         const float* shs, const float* colors_precomp, const float* opacities, const float* bg,
+                                         const float* viewmatrix, const float* projmatrix, const float* campos,
+                                         const float* tanfov, const float* scale, const void* geom, const void* binning,
+                                         const void* image, const uint32_t* counters, const size_t strides[3],
+                                         const float* dL_dcolor, const float* dL_ddepth, void* grad_scratch,
+                                         float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs,
+                                         float* dL_dcolors, float* dL_dopacities, int32_t accumulate, int32_t n_streams,
+                                         void* const* streams, void* main_stream, int32_t row0, int32_t nrows, int32_t with_blend)
+{
+    if (nrows < 0) return FS_ERR_INVALID_ARG;
+    return raster_backward_views_impl(dims, v, means3D, cov3D, shs, colors_precomp, opacities, bg, viewmatrix, projmatrix, campos,
+                                      tanfov, scale, geom, binning, image, counters, strides, dL_dcolor, dL_ddepth, grad_scratch,
+                                      dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dshs, dL_dcolors, dL_dopacities, accumulate,
+                                      n_streams, streams, main_stream, row0, nrows, with_blend);
 }

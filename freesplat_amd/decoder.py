@@ -138,6 +138,9 @@ def render_depth_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far:
 # ---------------------------------------------------------------------------------------------
 # Batched multi-view path: one shared Gaussian set, v views, one sync.
 # ---------------------------------------------------------------------------------------------
+# Set by view_sharding.GradExchange("chunked").install(): _RenderViews.backward then hands the Gaussian gradients over chunk by
+# chunk of the rows while it is still producing them (object with begin / chunk_rows / chunk_ready).
+GRAD_EXCHANGE_HOOK = None
 _pending_checks: list = []  # (counters [v,2], states | None, device, (H, W)) of render_views(..., check="deferred") calls
 
 
@@ -291,18 +294,29 @@ class _RenderViews(torch.autograd.Function):
             strides = (C.c_size_t * 3)(*b["sz"][:3])
             handles = (C.c_void_p * max(n_streams, 1))(*[s.cuda_stream for s in st.side_streams[:n_streams]])
             p = R._lib.ptr
-            R._lib.check(R._lib.lib().fs_raster_backward_views(
-                C.byref(b["dims"]), v, p(means), p(cov6), p(shs), None, p(opac), p(b["bgs"]), p(b["views"]), p(b["fulls"]),
-                p(b["campos"]), p(b["tanfov"]), p(b["scale"]), p(b["geom"]), p(b["binning"]), p(b["image"]), p(b["counters"]),
-                strides,
-                p(g_color), p(g_depth), p(scratch), p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]), p(out["shs"]),
-                None, p(out["opacities"]), 0, n_streams if n_streams > 1 else 0, handles, R._lib.current_stream()),
-                "fs_raster_backward_views")
+            common = (C.byref(b["dims"]), v, p(means), p(cov6), p(shs), None, p(opac), p(b["bgs"]), p(b["views"]), p(b["fulls"]),
+                      p(b["campos"]), p(b["tanfov"]), p(b["scale"]), p(b["geom"]), p(b["binning"]), p(b["image"]), p(b["counters"]),
+                      strides, p(g_color), p(g_depth), p(scratch), p(out["means3D"]), p(out["means2D"]), p(out["cov3D"]),
+                      p(out["shs"]), None, p(out["opacities"]), 0, n_streams if n_streams > 1 else 0, handles)
+            hook = GRAD_EXCHANGE_HOOK
+            if hook is None:
+                R._lib.check(R._lib.lib().fs_raster_backward_views(*common, R._lib.current_stream()), "fs_raster_backward_views")
+            else:
+                # chunked gradient exchange (view_sharding.GradExchange("chunked")): the per-Gaussian pass runs chunk by chunk of
+                # the rows, and the reduce-scatter of chunk c (on the hook's side stream) overlaps the pass over chunk c + 1
+                hook.begin(N)
+                for ci, (c0, c1) in enumerate(hook.chunk_rows(N)):
+                    R._lib.check(R._lib.lib().fs_raster_backward_views_rows(*common, R._lib.current_stream(), c0, c1 - c0,
+                                                                            1 if ci == 0 else 0), "fs_raster_backward_views_rows")
+                    hook.chunk_ready(c0, c1, [out["means3D"], out["cov3D"], out["shs"], out["opacities"]])
         else:
             view_grads = lambda i: (None if g_color is None else g_color[i], None if g_depth is None else g_depth[i])
             out = None
             for i, rs in enumerate(ctx.states):
                 out = R.rasterize_backward(rs, means, cov6, shs, None, opac, *view_grads(i), out=out, accumulate=i > 0)
+            if GRAD_EXCHANGE_HOOK is not None:     # (a re-rendered view forced the view-by-view backward: one chunk, no overlap)
+                GRAD_EXCHANGE_HOOK.begin(N)
+                GRAD_EXCHANGE_HOOK.chunk_ready(0, N, [out["means3D"], out["cov3D"], out["shs"], out["opacities"]])
         g_shs = out["shs"] if shs.dtype == torch.float32 else out["shs"].to(shs.dtype)
         return (out["means3D"], out["cov3D"], g_shs, out["opacities"]) + (None,) * 10
 

@@ -217,20 +217,91 @@ def reduce_scatter_gaussian_grads(grads: list[Optional[Tensor]], group=None) -> 
     return out
 
 
+def chunk_row_ranges(n_rows: int, n_chunks: int) -> list[tuple[int, int]]:
+    """Contiguous row chunks [c0, c1) of a chunked gradient exchange: boundaries at multiples of 256 rows (the per-Gaussian
+    backward pass works in 256-row workgroups), the last chunk takes the remainder; empty chunks are dropped."""
+    n_chunks = max(1, int(n_chunks))
+    per = -(-n_rows // n_chunks)
+    per = -(-per // 256) * 256
+    return [(c0, min(n_rows, c0 + per)) for c0 in range(0, n_rows, per)] if n_rows > 0 else []
+
+
+def chunked_owned_rows(n_rows: int, rank: int, world: int, n_chunks: int) -> list[range]:
+    """The rows rank `rank` owns after a CHUNKED reduce-scatter: its shard_range of every chunk (interleaved over the set,
+    not one contiguous block: a sharded optimizer must use this map with GradExchange("chunked"))."""
+    out = []
+    for c0, c1 in chunk_row_ranges(n_rows, n_chunks):
+        r = shard_range(c1 - c0, rank, world)
+        out.append(range(c0 + r.start, c0 + r.stop))
+    return out
+
+
 class GradExchange:
     """The gradient exchange of a view-sharded training step, by name: "all_reduce" sums in place (every rank ends
-    with every row), "reduce_scatter" returns the row shards this rank owns."""
+    with every row), "reduce_scatter" returns the row shards this rank owns, "chunked" is the reduce-scatter issued CHUNK BY CHUNK
+    of the rows from inside the rasterizer's backward (install() hooks decoder._RenderViews.backward): the per-Gaussian pass
+    over chunk c + 1 (fs_raster_backward_views_rows) runs while chunk c is summed over the ranks on a side stream.  Calling
+    the exchange after backward() then only waits for the side stream and returns, per tensor, the concatenation of this
+    rank's pieces (rows chunked_owned_rows(N, rank, world, chunks)).  Built for the first 8-GPU run to A/B against
+    "reduce_scatter" (VERDICT r5 item 7); on one GPU it can only be checked for correctness."""
 
-    def __init__(self, kind: str = "reduce_scatter", group=None):
-        if kind not in ("reduce_scatter", "all_reduce"):
+    def __init__(self, kind: str = "reduce_scatter", group=None, chunks: int = 4):
+        if kind not in ("reduce_scatter", "all_reduce", "chunked"):
             raise ValueError(kind)
-        self.kind, self.group = kind, group
+        self.kind, self.group, self.chunks = kind, group, int(chunks)
+        self._pieces, self._stream, self._n = None, None, 0
+
+    # ---- chunked: the hook interface of decoder._RenderViews.backward ----
+    def install(self) -> "GradExchange":
+        if self.kind == "chunked":
+            from . import decoder
+            decoder.GRAD_EXCHANGE_HOOK = self
+        return self
+
+    def uninstall(self) -> None:
+        from . import decoder
+        if decoder.GRAD_EXCHANGE_HOOK is self:
+            decoder.GRAD_EXCHANGE_HOOK = None
+
+    def begin(self, n_rows: int) -> None:
+        self._pieces, self._n = [], n_rows
+
+    def chunk_rows(self, n_rows: int) -> list[tuple[int, int]]:
+        return chunk_row_ranges(n_rows, self.chunks)
+
+    def chunk_ready(self, c0: int, c1: int, tensors: list[Tensor]) -> None:
+        """Rows [c0, c1) of the gradient tensors are final on the current stream: sum them over the ranks on the side stream."""
+        dev = tensors[0].device
+        if dev.type != "cuda":
+            self._pieces.append(reduce_scatter_gaussian_grads([t[c0:c1] for t in tensors], self.group))
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(ev)
+            for t in tensors:
+                t.record_stream(self._stream)
+            self._pieces.append(reduce_scatter_gaussian_grads([t[c0:c1] for t in tensors], self.group))
 
     def __call__(self, grads: list[Optional[Tensor]]):
         if self.kind == "all_reduce":
             allreduce_gaussian_grads(grads, self.group)
             return grads
-        return reduce_scatter_gaussian_grads(grads, self.group)
+        if self.kind == "reduce_scatter":
+            return reduce_scatter_gaussian_grads(grads, self.group)
+        if self._pieces is None:
+            raise RuntimeError('GradExchange("chunked"): no backward ran through the hook since the last call (install() it, and '
+                               "render through decoder.render_views)")
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        pieces, self._pieces = self._pieces, None
+        if not pieces:
+            return [None if g is None else g[:0] for g in grads]
+        out = [torch.cat([pc[j] for pc in pieces]) for j in range(len(pieces[0]))]
+        it = iter(out)
+        return [None if g is None else next(it) for g in grads]
 
 
 class _GatherViewsFn(torch.autograd.Function):

@@ -221,6 +221,19 @@ int fs_cost_volume_forward(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
                            const float* w2, const float* b2, const float* w3, const float* b3,
                            void* workspace, float* out, void* stream);
 
+/* The same forward reading feature maps that are ALREADY pixel-major (channels_last tensors: [h*w][C] records, what the K >= 2
+ * sweep gathers from): layout bit 0 = cur_feats is [B, h, w, C], bit 1 = src_feats is [B, K, h, w, C].  A map given this way is read
+ * in place -- no re-layout pass (425 of the 755 MB a 10-view K = 8 call moves with [C, h, w] maps).  layout != 0 always takes
+ * the 16-pixel sweep (the K = 1 projected sweep reads the caller's [C, h, w] current map).  Inference only: the backward
+ * entry points take [C, h, w] maps. */
+int fs_cost_volume_forward_layout(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w, int32_t D,
+                                  const float* cur_feats, const float* src_feats,
+                                  const float* src_extrinsics, const float* src_Ks,
+                                  const float* cur_invK, const float* planes, int64_t plane_stride_b,
+                                  int64_t plane_stride_d, int64_t plane_stride_pix, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* w3,
+                                  const float* b3, void* workspace, float* out, int32_t layout, void* stream);
+
 /*
  * Training forward: fs_cost_volume_forward plus `saved` (fs_cost_volume_saved_bytes) -- the MLP's input of every (view,
  * plane, pixel) point (the C averaged warped features, the averaged score, the sources' validity bits: C + 2 floats per
@@ -475,6 +488,21 @@ int fs_raster_backward_views(const fs_raster_dims* dims, int32_t v, const float*
                              const float* dL_ddepth, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
                              float* dL_dcov3D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
                              int32_t accumulate, int32_t n_streams, void* const* streams, void* main_stream);
+
+/* The same backward with its per-Gaussian pass restricted to rows [row0, row0 + nrows) of the Gaussian set (ABI revision 6): a
+ * caller that sums the gradients over GPUs chunk by chunk (view_sharding.GradExchange("chunked")) passes with_blend = 1 with its
+ * first chunk -- the blend backward of all v views runs, then the pass over that chunk's rows -- and with_blend = 0 with the others
+ * (only the pass over their rows; the blend's screen-space gradients are still in grad_scratch), so that the reduce-scatter of
+ * chunk c overlaps the pass over chunk c + 1.  Rows outside the chunk are not written. */
+int fs_raster_backward_views_rows(const fs_raster_dims* dims, int32_t v, const float* means3D, const float* cov3D,
+                                  const float* shs, const float* colors_precomp, const float* opacities, const float* bg,
+                                  const float* viewmatrix, const float* projmatrix, const float* campos,
+                                  const float* tanfov, const float* scale, const void* geom, const void* binning,
+                                  const void* image, const uint32_t* counters, const size_t strides[3],
+                                  const float* dL_dcolor, const float* dL_ddepth, void* grad_scratch,
+                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dshs,
+                                  float* dL_dcolors, float* dL_dopacities, int32_t accumulate, int32_t n_streams,
+                                  void* const* streams, void* main_stream, int32_t row0, int32_t nrows, int32_t with_blend);
 
 /* ---- PTF training path: backward of one fold step's data movement (encoder_freesplat.py:485-519) ----
  * fs_ptf_fold_step_lists: device pointers (into the step's scratch) of the four ordered index lists the step left

@@ -21,6 +21,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "
 
 WORKLOADS = {   # name -> (units per call, default calls)
     "raster_c3": (16, 4), "raster_c2": (16, 4), "raster_closeup": (4, 3), "cv_native_K1": (1, 6), "cv_c3scale_K2": (1, 3), "cv_fvt10_K8": (1, 3),
+    "cv_fvt10_K8_cl": (1, 3),     # the same call on channels_last feature maps (read in place: no re-layout pass)
     "ptf_2_views": (1, 6), "ptf_10_views": (1, 3), "ptf_3_views": (1, 3),      # (ptf_3_views: 3 views at 968x1296)
     # training steps of the cost volume (forward + backward w.r.t. features and MLP): unit = one step
     "cvt_native_K1": (1, 4), "cvt_c3scale_K2": (1, 2), "cvt_fvt10_K8": (1, 2),
@@ -48,11 +49,14 @@ def run(name, calls):
     elif name.startswith("cv"):
         import inputs
         from freesplat_amd.cost_volume import AVGFeatureVolumeManager
-        V, K, h4, w4 = {"native_K1": (2, 1, 96, 128), "c3scale_K2": (3, 2, 242, 324), "fvt10_K8": (10, 8, 96, 128)}[name.split("_", 1)[1]]
+        V, K, h4, w4 = {"native_K1": (2, 1, 96, 128), "c3scale_K2": (3, 2, 242, 324), "fvt10_K8": (10, 8, 96, 128)}[name.split("_", 1)[1].replace("_cl", "")]
         torch.manual_seed(0)
         m = AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=128, mlp_channels=[202, 32, 32, 1],
                                     matching_dim_size=48).to(dev)
         args = {k: v.to(dev) for k, v in inputs.cv_inputs(V, K, h4, w4, 48, seed=1).items()}
+        if name.endswith("_cl"):
+            args["cur_feats"] = args["cur_feats"].contiguous(memory_format=torch.channels_last)
+            args["src_feats"] = args["src_feats"].permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
         fn = lambda: m(**args)
         if name.startswith("cvt_"):
             args["cur_feats"].requires_grad_(True)

@@ -2,7 +2,7 @@
 # HBM-traffic PMC passes of every forward workload (on the GPU box, from the repo root): profiles/tools/fwd_traffic.sh <tag> [workloads...]
 export TMPDIR=/tmp
 TAG=$1; shift
-WL=${@:-raster_c3 raster_c2 raster_closeup cv_native_K1 cv_c3scale_K2 cv_fvt10_K8 cvt_native_K1 cvt_c3scale_K2 cvt_fvt10_K8 ptf_2_views ptf_10_views ptf_3_views}
+WL=${@:-raster_c3 raster_c2 raster_closeup cv_native_K1 cv_c3scale_K2 cv_fvt10_K8 cv_fvt10_K8_cl cvt_native_K1 cvt_c3scale_K2 cvt_fvt10_K8 ptf_2_views ptf_10_views ptf_3_views}
 for W in $WL; do
   OUT=gpurun_out/traffic_$TAG/$W
   mkdir -p $OUT

@@ -95,6 +95,42 @@ def test_ragged_shapes_vs_oracle(hip_device, V, K, h4, w4, D, behind, C, sweep):
     assert (out - ref).abs().max().item() <= ATOL
 
 
+@pytest.mark.parametrize("V,K,h4,w4,D,C", [(3, 2, 15, 21, 11, 48), (4, 8, 24, 32, 16, 48), (2, 1, 13, 19, 7, 48), (3, 2, 13, 19, 7, 16)])
+@pytest.mark.parametrize("which", ["both", "cur", "src"])
+def test_channels_last_maps_are_read_in_place(hip_device, V, K, h4, w4, D, C, which):
+    """channels_last feature maps (pixel-major records) take fs_cost_volume_forward_layout -- no re-layout pass -- and give the
+    SAME volume bit for bit as the [C, h, w] maps through the 16-pixel sweep (FS_CV_PROJECTED=0: at K = 1 the default [C, h, w]
+    path is the projected sweep, a different summation order); with autograd on, the maps go the contiguous way and gradients flow."""
+    import inputs
+    from freesplat_amd import cost_volume as cvm
+    torch.manual_seed(V * 10 + K)
+    m = cvm.AVGFeatureVolumeManager(matching_height=h4, matching_width=w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1],
+                                    matching_dim_size=C).to(hip_device)
+    kw = {k: v.to(hip_device) for k, v in inputs.cv_inputs(V, K, h4, w4, C, seed=5 + V).items()}
+    os.environ["FS_CV_PROJECTED"] = "0"
+    try:
+        with torch.no_grad():
+            ref = m(**kw)
+    finally:
+        del os.environ["FS_CV_PROJECTED"]
+    cl = dict(kw)
+    if which in ("both", "cur"):
+        cl["cur_feats"] = kw["cur_feats"].contiguous(memory_format=torch.channels_last)
+    if which in ("both", "src"):
+        cl["src_feats"] = kw["src_feats"].permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)     # [B,K,C,h,w] view of [B,K,h,w,C] memory
+        assert cvm._pixel_major(cl["src_feats"]) and not cl["src_feats"].is_contiguous()
+    with torch.no_grad():
+        out = m(**cl)
+    assert torch.equal(out, ref)
+    # the layout entry point really ran: the same call with grad enabled must NOT take it, and still agree
+    g = dict(cl)
+    g["cur_feats"] = cl["cur_feats"].clone().requires_grad_(True)
+    out_g = m(**g)
+    assert (out_g - ref).abs().max().item() <= ATOL
+    out_g.sum().backward()
+    assert g["cur_feats"].grad is not None and torch.isfinite(g["cur_feats"].grad).all()
+
+
 def test_c3_scale_border_validity_flips_are_rare(hip_device):
     """242x324 (= 968x1296 / 4), K=2.  The reference's `dot != 0` validity count is discontinuous where
     a bilinear tap is a rounding error inside / outside the source image; different (all fp32-valid)

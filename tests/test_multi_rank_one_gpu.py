@@ -41,6 +41,18 @@ def test_sharded_decoder_and_cost_volume_two_ranks(hip_device):
         assert res["cv_feat_grad_err"] < 1e-4, res
 
 
+def test_bench_two_ranks_chunked_gradient_exchange(hip_device):
+    """bench.py --gpus 2 --mode train --grad-exchange chunked: the per-Gaussian backward pass runs in row chunks
+    (fs_raster_backward_views_rows) with one reduce-scatter per chunk on a side stream; same JSON contract as the other exchanges."""
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--views", "3",
+                     "--workload", "c1_256x256_plumbing", "--mode", "train", "--grad-exchange", "chunked", "--grad-chunks", "3"])
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    d = json.loads(lines[-2])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "view-sharded x2 + chunked(gaussian grads)", d["config"]
+    per = d["multi_gpu"]["per_rank"]
+    assert len(per) == 2 and all(0 <= r["grad_exchange_ms"] < r["step_ms"] for r in per), per
+
+
 @pytest.mark.parametrize("mode", ["fwd", "train"])
 def test_bench_two_ranks_runs_the_sharded_branch(hip_device, mode):
     """bench.py --gpus 2 end to end (small workload): NCCL-free init, view sharding, AsyncViewGather on a side stream

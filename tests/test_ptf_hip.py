@@ -404,9 +404,9 @@ def test_training_fold_with_and_without_state_trims(hip_device, monkeypatch):
         cot = [torch.randn(o.shape, generator=torch.Generator().manual_seed(11 + k)).to(hip_device) for k, o in enumerate(out)]
         grads = torch.autograd.grad(out, ins + list(m.gru.parameters()), cot, allow_unused=True)
         return [o.detach() for o in out], grads
-    monkeypatch.setattr(P, "_KEEP_BYTES", 1 << 40)
+    monkeypatch.setattr(P, "_KEEP_BYTES_ENV", str(1 << 40))
     out_keep, g_keep = run()
-    monkeypatch.setattr(P, "_KEEP_BYTES", 0)
+    monkeypatch.setattr(P, "_KEEP_BYTES_ENV", "0")
     out_trim, g_trim = run()
     for a, b in zip(out_keep, out_trim):
         assert torch.equal(a, b)

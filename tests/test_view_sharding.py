@@ -8,9 +8,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from freesplat_amd.view_sharding import (AsyncViewGather, GradExchange, allreduce_gaussian_grads, gather_views,
-                                         gather_views_autograd, reduce_scatter_gaussian_grads,
-                                         replicate_gaussians, shard_counts, shard_range)
+from freesplat_amd.view_sharding import (AsyncViewGather, GradExchange, allreduce_gaussian_grads, chunk_row_ranges,
+                                         chunked_owned_rows, gather_views, gather_views_autograd,
+                                         reduce_scatter_gaussian_grads, replicate_gaussians, shard_counts, shard_range)
 
 
 def test_shard_range_partition():
@@ -346,3 +346,46 @@ def test_gloo_world8_config4_split():
     reduce-scatter and DecoderSplattingCUDA(group=...) forward + backward (outputs and gradients equal the unsharded ones on
     every rank, empty shards keep the graph connected, a rank with a different scene is refused)."""
     assert all(ok for _, ok in _run(8, _world8_worker))
+
+
+def test_chunk_row_ranges_partition():
+    for n in (0, 1, 255, 256, 1000, 100_000):
+        for c in (1, 3, 4, 8):
+            ch = chunk_row_ranges(n, c)
+            assert [r for c0, c1 in ch for r in range(c0, c1)] == list(range(n)) and len(ch) <= c
+            assert all(c0 % 256 == 0 for c0, _ in ch)
+            for world in (1, 2, 8):
+                owned = [r for rk in range(world) for rg in chunked_owned_rows(n, rk, world, c) for r in rg]
+                assert sorted(owned) == list(range(n))
+
+
+def _chunked_worker(rank, world, port, q, N, chunks):
+    _init(rank, world, port)
+    try:
+        g = torch.Generator().manual_seed(21 + rank)
+        grads = [torch.randn(N, 3, generator=g), torch.randn(N, 3, 3, generator=g), torch.randn(N, 3, 9, generator=g), torch.randn(N, generator=g)]
+        full = [t.clone() for t in grads]
+        allreduce_gaussian_grads(full)
+        ex = GradExchange("chunked", chunks=chunks)
+        # what decoder._RenderViews.backward does through the hook: rows become final chunk by chunk
+        ex.begin(N)
+        for c0, c1 in ex.chunk_rows(N):
+            ex.chunk_ready(c0, c1, grads)
+        got = ex(grads)
+        rows = [r for rg in chunked_owned_rows(N, rank, world, chunks) for r in rg]
+        ok = all(torch.allclose(sh, fu[rows], atol=1e-5) and sh.shape[0] == len(rows) for sh, fu in zip(got, full))
+        raised = False
+        try:
+            ex(grads)           # nothing ran through the hook since the last call
+        except RuntimeError:
+            raised = True
+        q.put((rank, bool(ok and raised)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,chunks", [(1000, 4), (700, 3), (100, 4)])
+def test_gloo_world2_chunked_exchange_equals_allreduce_rows(N, chunks):
+    """GradExchange("chunked"): the reduce-scatter issued chunk by chunk of the rows leaves every rank with
+    the all-reduced values of the rows chunked_owned_rows names -- together every row exactly once."""
+    assert all(ok for _, ok in _run(2, _chunked_worker, N, chunks))
