@@ -653,6 +653,8 @@ def headline(full: dict) -> dict:
             for k in ("max_abs_err_vs_oracle", "max_rel_err_vs_oracle"):
                 if k in p:
                     e["err"] = _num(p[k], 2)
+            if "cells_above_1e-4" in p:      # (the one cost-volume cell in 10 M whose err is a border validity flip: say how many)
+                e["cells_above_1e-4"] = p["cells_above_1e-4"]
             if "same_count_and_order" in p:
                 e["order_ok"] = p["same_count_and_order"]
                 e["views_cmp"] = p.get("views_compared")

@@ -19,9 +19,11 @@
 //     - K >= 2, cost_volume16_kernel: 16-pixel wavefronts, lane = (pixel, channel quarter) with the four lanes of a pixel
 //       adjacent, so that a tap load reads 64 contiguous bytes per quad (the sweep is bound by the delivery of its taps:
 //       1.7x fewer cycles per load instruction than with (pixel, parity) lanes), v_mfma_f32_16x16x4_f32;
-//     - backward (round 4: two passes, no global float atomics on the source maps): cost_volume_bwd_kernel -- 32 pixels x
-//       parity on texel-major [y][x][parity][C/2] records, forward recomputed per plane, the six MLP gradients on the matrix
-//       cores, d cur, and one record per (pixel, plane) point -- then cv_src_grad_kernel, whose single-wavefront workgroups
+//     - backward (round 4: two passes, no global float atomics on the source maps): pass 1 -- cost_volume16_bwd_kernel (round 6:
+//       the forward's 16-pixel lane orders, v_mfma_f32_16x16x4_f32, natural-order records; FS_CV_BWD16=0 or a saved-activation
+//       call: cost_volume_bwd_kernel, 32 pixels x parity on texel-major [y][x][parity][C/2] records) -- recomputes the forward per
+//       plane and forms the six MLP gradients on the matrix cores, d cur, and one record per (pixel, plane) point -- then
+//       cv_src_grad_kernel, whose single-wavefront workgroups
 //       own 8 x 8 tiles of SOURCE texels and collect, plane by plane, from the pixels whose taps cover them (found through
 //       the inverse plane homography), accumulating in LDS.  (Per-pixel plane depths or K > 16: the round-3 one-kernel
 //       form, which scatters with 192-byte atomic records.)
@@ -100,10 +102,10 @@ static inline void cv_relayout(bool parity, bool back, const float* src, float* 
     auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, src, dst, hw, n_maps); };
     if (C == 48) {
         if (parity) { if (back) go(cv_relayout_tiled_kernel<48, true, true>); else go(cv_relayout_tiled_kernel<48, true, false>); }
-        else go(cv_relayout_tiled_kernel<48, false, false>);
+        else { if (back) go(cv_relayout_tiled_kernel<48, false, true>); else go(cv_relayout_tiled_kernel<48, false, false>); }
     } else {   // (C == 16: the entry points accept nothing else)
         if (parity) { if (back) go(cv_relayout_tiled_kernel<16, true, true>); else go(cv_relayout_tiled_kernel<16, true, false>); }
-        else go(cv_relayout_tiled_kernel<16, false, false>);
+        else { if (back) go(cv_relayout_tiled_kernel<16, false, true>); else go(cv_relayout_tiled_kernel<16, false, false>); }
     }
 }
 
@@ -234,6 +236,7 @@ __device__ __forceinline__ float lrelu(float x) { return fmaf(0.495f, fabsf(x), 
 // ==========================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+
 // SAVE (training forward): the MLP's input of every (pixel, plane) point -- the averaged warped features x = favg / cnt,
 // the averaged score and the sources' (valid, in-front) bits -- is kept for the backward, which then starts from it
 // instead of gathering K x 4 taps again (chunk-planar in the backward's channel order: cost_volume_bwd_kernel).
@@ -363,6 +366,8 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
             // 64-bit multiply-adds (a source map is far below 4 GB)
             const char* base = (const char*)(srcN + (((size_t)b * K + k) * hw) * C);
             const uint32_t off0 = pr.off + 16u * (uint32_t)c;
+            // (tap by tap behind a branch each: with three wavefronts per SIMD that beats having a source's taps in flight together --
+            //  the backward's form, 2 wavefronts per SIMD -- which costs the third wavefront: profiles/r6_cv_fwd_taps_ab.txt)
 #pragma unroll
             for (int tap = 0; tap < 4; ++tap) {
                 const int ox = tap & 1, oy = tap >> 1;
@@ -1201,6 +1206,584 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
 
 
 // ==========================================================================================
+// Backward pass 1 on 16-pixel wavefronts (round 6; replaces cost_volume_bwd_kernel<., true, false> for the two-pass form).
+// Same lane orders as the K >= 2 forward sweep above: the gather runs with lane = (pixel j, channel quarter c), the matrix
+// cores with lane = (pixel n, quarter g), and v_mfma_f32_16x16x4_f32 throughout.  What that buys over the 32-pixel kernel:
+//   * FOUR of the six products need no transposition at all: an accumulator of layer l (lane (n, g), register r = unit
+//     16 blk + 4 g + r of pixel n) IS the B operand of the next product in either direction --
+//        z1 = W1 x,  z2 = W2 h1,  dh1 = W2^T dz2,  dx = W1^T dz1
+//     (k-step (blk, r), quarter g  <->  unit 16 blk + 4 g + r), and dx comes out in the operand order of x itself: register
+//     (rb, r) = channel 16 rb + 4 g + r, i.e. one float4 CHUNK of the record in natural channel order;
+//   * the two weight gradients contract over the POINTS, which must lie along k: the factors (dz2, h1, dz1: [32 units][16 px],
+//     x: [C channels][16 px]) pass through wavefront-private LDS tiles laid out so that ONE ds_read_b128 returns the operands
+//     of all four k-steps of a 16 x 16 block (pixel 4 kk + s -> lane quarter kk, k-step s), conflict-free both ways: float
+//     index of (row i of the block, pixel p) = 64 (p >> 2) + 4 (i ^ (p >> 2)) + (p & 3);
+//   * exact block cuts: the C channels are C/16 blocks of 16 (dW1: 2 x C/16 x 4, dx: C/16 x 8 MFMAs), the score and bias
+//     columns of dW1, db2, dw3, db3 are per-lane running sums in the accumulator layout (reduced over the pixels once, at the
+//     end) -- 122 MFMAs of 32 cycles per 16 pixels = 7.8 k matrix-pipe cycles per 32 points against 8.8 k, no column-sum tiles;
+//   * every weight operand (W1, W2 and their transposes) is read from an LDS image in MFMA A-operand order -- one lane-consecutive
+//     ds_read_b32 where its MFMA is; in registers (82 of them), or staged a phase ahead, the kernel spilled at two wavefronts per
+//     SIMD and every scratch reload inside the plane loop is a memory round trip in front of an MFMA;
+//   * all taps of a source are loaded back to back behind wave-uniform tests (two at a time), then blended: at two wavefronts per
+//     SIMD the forward's tap-by-tap form left the taps' latency exposed (9.6 -> 8.1 ms at config-3 scale, 11.9 -> 7.1 ms at K = 8);
+//   * the record's stores are issued in front of dW1's MFMAs, not at the end of the plane: the memory counter is in-order, so the
+//     next plane's first tap wait also waited for them.
+// Measured against the 32-pixel kernel (profiles/r6_cv_bwd16.txt): config-3 scale 7.0 - 7.3 -> 6.7 ms, 10 views K = 8 7.5 -> 6.1 ms.
+// A workgroup covers one 32-pixel group (the same XCD-aware order as before) as two 16-pixel halves in turn; its four wavefronts
+// share the planes.  Records leave in NATURAL channel order ([view, plane][chunk of 4 channels][pixel]); cv_src_grad_kernel<C, true>
+// reads them.  d cur is summed over the workgroup's wavefronts in LDS and leaves as plain stores when the planes are not split
+// over workgroups.
+// ==========================================================================================
+template <int C>
+#ifdef FS_BWD16_ONE_WAVE     // (A/B build: one wavefront per SIMD with the whole 512-register file)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void cost_volume16_bwd_kernel(
+#else
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void cost_volume16_bwd_kernel(
+#endif
+    int B, int K, int h, int w, int D, int slices, const float* __restrict__ curN, const float* __restrict__ srcN,
+    const float* __restrict__ Pmat, const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
+    long long ps_d, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ g_out,
+    float* __restrict__ d_curN, float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2,
+    float* __restrict__ gb2, float* __restrict__ gw3, float* __restrict__ gb3, float4* __restrict__ recS,
+    float2* __restrict__ recM)
+{
+    constexpr int NS = C / 16;          // tap load instructions per tap = 16-channel blocks
+    constexpr int NR = C / 4;           // channels per lane
+    constexpr int NT = NR + 1;          // k-steps of layer 1 (the last one: dot, 1, 0, 0)
+    constexpr int RB = C / 16;          // channel blocks of dx / dW1
+    // LDS (floats): operand images of W2^T and W1^T, the small vectors, then one region per wavefront
+    constexpr int kA2T = 0, kA1T = 16 * 64, kA2 = kA1T + RB * 8 * 64, kA1 = kA2 + 16 * 64, kVec = kA1 + 2 * NT * 64, kWts = kVec + 160;
+    // (the dz1 tile takes the dz2 tile's place: dW2's reads of dz2 are issued before dz1 is written, and a wavefront's LDS operations
+    //  execute in order)
+    constexpr int kTD2 = 0, kTD1 = 0, kTH1 = 512, kTX = 1024, kCur = kTX + RB * 256, kCurG = kCur + NR * 64, kWave = kCurG + NR * 64;
+    constexpr int kAccRegs = 16 + 2 * RB * 4;   // dW2 + dW1 accumulator registers
+    static_assert((kWts + 4 * kWave) * 4 <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
+    static_assert(kAccRegs * 64 + 33 * 4 <= kWave && 16 * C <= kWave, "final staging exceeds the wavefront's tiles");
+    __shared__ __attribute__((aligned(16))) float s_all[kWts + 4 * kWave];
+    const int hw = h * w;
+    const int groups = (hw + 31) / 32;
+    const CvBlock blk_ = cv_block(B, groups, slices);
+    if (!blk_.ok) return;   // (workgroup-uniform)
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {        // A operand of dh1: row n of block bo, k = unit u(t, g)
+        const int l = e & 63, t = (e >> 6) & 7, bo = e >> 9, nn = l & 15, gg = l >> 4;
+        s_all[kA2T + e] = w2[(16 * (t >> 2) + 4 * gg + (t & 3)) * 32 + 16 * bo + nn];
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {        // A operand of layer 2: row = unit 16 blk + n, k = unit u(t, g)
+        const int l = e & 63, t = (e >> 6) & 7, blk = e >> 9, nn = l & 15, gg = l >> 4;
+        s_all[kA2 + e] = w2[(16 * blk + nn) * 32 + 16 * (t >> 2) + 4 * gg + (t & 3)];
+    }
+    for (int e = threadIdx.x; e < 2 * NT * 64; e += 256) {    // A operand of layer 1: row = unit 16 blk + n, k = feature (t, g)
+        const int l = e & 63, q = e >> 6, blk = q / NT, t = q - blk * NT, nn = l & 15, gg = l >> 4, u = 16 * blk + nn;
+        s_all[kA1 + e] = t < NR ? w1[u * (C + 1) + 16 * (t >> 2) + 4 * gg + (t & 3)] : (gg == 0 ? w1[u * (C + 1) + C] : (gg == 1 ? b1[u] : 0.0f));
+    }
+    for (int e = threadIdx.x; e < RB * 8 * 64; e += 256) {    // A operand of dx: row = channel 16 rb + n, k = unit u(t, g)
+        const int l = e & 63, t = (e >> 6) & 7, rb = e >> 9, nn = l & 15, gg = l >> 4;
+        s_all[kA1T + e] = w1[(16 * (t >> 2) + 4 * gg + (t & 3)) * (C + 1) + 16 * rb + nn];
+    }
+    if (threadIdx.x < 32) {
+        s_all[kVec + threadIdx.x] = w3[threadIdx.x];
+        s_all[kVec + 32 + threadIdx.x] = b2[threadIdx.x];
+        s_all[kVec + 64 + threadIdx.x] = w1[threadIdx.x * (C + 1) + C];
+    }
+    const int b = blk_.b;
+    // the projection rows of the first group of four sources (lane c of a quad projects source min(c, K - 1)): [4][12]
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 48) {
+        const int e = threadIdx.x - 64, q = e / 12;
+        s_all[kVec + 96 + e] = Pmat[((size_t)b * K + min(q, K - 1)) * 12 + (e - 12 * q)];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane >> 2, c = lane & 3;      // gather order
+    const int n = lane & 15, g = lane >> 4;     // operand order
+    const int pull = (4 * n + g) * 4;           // operand lane (n, g) takes gather lane 4 n + g
+    const int pull0 = (4 * n) * 4;              // ... or a quad-uniform value of pixel n
+    float* const wv_ = s_all + kWts + wave * kWave;
+    float* const tD2 = wv_ + kTD2, * const tH1 = wv_ + kTH1, * const tD1 = wv_ + kTD1, * const tX = wv_ + kTX;
+    float4* const sCur = (float4*)(wv_ + kCur), * const sCurG = (float4*)(wv_ + kCurG);
+    const float* const sA2T = s_all + kA2T + lane, * const sA1T = s_all + kA1T + lane, * const sA2 = s_all + kA2 + lane,
+                * const sA1 = s_all + kA1 + lane;
+    // tile addresses: accumulator register (blk, r) of lane (n, g) = row 4 g + r of block blk, pixel n
+    const int kq = n >> 2;
+    int wr_at[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wr_at[r] = 64 * kq + 16 * g + 4 * (r ^ kq) + (n & 3);
+    const int rd_at = 64 * g + ((n ^ g) << 2);                    // b128: row n of a block, pixels 4 g .. 4 g + 3
+    const int xw_at = 64 * (j >> 2) + 16 * c + (j & 3), xw_k = j >> 2;   // x tile from the gather order: + 256 blk + 4 ((r & 3) ^ xw_k)
+
+    // (every MFMA's weight operand comes from its LDS image: one lane-consecutive ds_read_b32 each; in registers -- 82 of them --
+    //  the kernel spilled at two wavefronts per SIMD)
+    const float4* const sW3 = (const float4*)(s_all + kVec) + g, * const sB2 = (const float4*)(s_all + kVec + 32) + g,
+                * const sW1d = (const float4*)(s_all + kVec + 64) + g;        // [blk]: + 4 blk  (units 16 blk + 4 g + 0..3)
+
+    const float* iK = cur_invK + (size_t)b * 16;
+    const float inv_w = (float)(1.0 / (double)w), inv_h = (float)(1.0 / (double)h);
+    const int dchunk = (D + slices * 4 - 1) / (slices * 4);
+    const int d0 = min(D, (blk_.slice * 4 + wave) * dchunk), d1 = min(D, d0 + dchunk);
+
+    // running sums that live across both halves and all planes
+    f32x4 acc2[2][2], acc1[2][RB];      // dW2[16 rb + 4 g + r][16 cb + n],  dW1[16 rb + 4 g + r][channel 16 cb + n]
+    float s_dot[2][4], s_b1[2][4], s_b2[2][4], s_w3[2][4], s_b3 = 0.0f;   // unit 16 blk + 4 g + r, this lane's pixels
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc2[rb][cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int cb = 0; cb < RB; ++cb) acc1[rb][cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s_dot[rb][r] = 0.0f; s_b1[rb][r] = 0.0f; s_b2[rb][r] = 0.0f; s_w3[rb][r] = 0.0f; }
+    }
+    const float4* const sPq = (const float4*)(s_all + kVec + 96) + 3 * c;
+
+    float dcur[NR];    // d cur of the half in flight, operand order (channel 16 (t >> 2) + 4 g + (t & 3) of pixel n)
+#ifdef FS_CV_TRACE   // [0] gather, [1] x hand-over + layer 1, [2] layer 2 .. dh1 (+ dW2), [3] dz1, dx, dW1, [4] planes, [5] total
+    unsigned long long tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0, tbn = 0;
+    const unsigned long long tb_start = cv_stamp((float)lane);
+#endif
+    for (int half = 0; half < 2; ++half) {
+        const int pix0 = blk_.grp * 32 + 16 * half;
+        const int pix = pix0 + j, pix_m = pix0 + n;
+        const bool live = pix < hw, live_m = pix_m < hw;
+        const int pu = live ? pix % w : 0, pv = live ? pix / w : 0;
+        {   // the current feature, parked in LDS in both lane orders (24 registers less across the sweep)
+            const float4* q = (const float4*)(curN + ((size_t)b * hw + (live ? pix : 0)) * C) + c;   // gather order: quarter c of pixel j
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sCurG[64 * s + lane] = q[4 * s];
+            const float4* qm = (const float4*)(curN + ((size_t)b * hw + (live_m ? pix_m : 0)) * C) + g;   // operand order, parked in LDS
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sCur[64 * s + lane] = qm[4 * s];
+        }
+#pragma unroll
+        for (int t = 0; t < NR; ++t) dcur[t] = 0.0f;
+        const float ux = (float)pu + 0.5f, vy = (float)pv + 0.5f;
+        const float rx = iK[0] * ux + iK[1] * vy + iK[2];
+        const float ry = iK[4] * ux + iK[5] * vy + iK[6];
+        const float rz = iK[8] * ux + iK[9] * vy + iK[10];
+        const float* const gp = g_out + (size_t)b * D * hw + (live_m ? pix_m : 0);
+        float go_next = (d0 < d1 && live_m) ? gp[(size_t)d0 * hw] : 0.0f;
+        float depth_next = planes[b * ps_b + min(d0, D - 1) * ps_d];     // (two-pass form: one depth per plane, wave-uniform; one plane ahead)
+
+        for (int d = d0; d < d1; ++d) {
+            const float depth = depth_next;
+            depth_next = planes[b * ps_b + min(d + 1, d1 - 1) * ps_d];
+            FS_CV_T(tq0, depth);
+            const float go = go_next;
+            go_next = live_m ? gp[(size_t)min(d + 1, d1 - 1) * hw] : 0.0f;
+            // ---------------- forward recompute: gather (the forward sweep's code, plus the backward's bits) ----------------
+            float favg[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) favg[r] = 0.0f;
+            float dot_sum = 0.0f, cnt = 0.0f;
+            uint32_t flags = 0, rare = 0;   // bit 2k = source k valid (dot != 0), bit 2k+1 = in front (z > 0); rare: bit 2k
+            struct Proj { uint32_t off; float tx, ty; uint32_t bits; };
+            auto project = [&](const float* P) __attribute__((always_inline)) -> Proj {
+                const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+                const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+                const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+                const float qz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+                const float zz = qz + 1e-8f;
+                const float sc = (fabsf(qz) > 1e-8f) ? 1.0f / zz : 1.0f;
+                const float uvx = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qx, sc)), inv_w), 1.0f);
+                const float uvy = __fsub_rn(__fmul_rn(__fmul_rn(2.0f, __fmul_rn(qy, sc)), inv_h), 1.0f);
+                const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvx, 1.0f), (float)w), 1.0f), 0.5f);
+                const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uvy, 1.0f), (float)h), 1.0f), 0.5f);
+                const float fx0 = floorf(ix), fy0 = floorf(iy);
+                const bool xin0 = fx0 >= 0.0f && fx0 <= (float)(w - 1), xin1 = fx0 >= -1.0f && fx0 <= (float)(w - 2);
+                const bool yin0 = fy0 >= 0.0f && fy0 <= (float)(h - 1), yin1 = fy0 >= -1.0f && fy0 <= (float)(h - 2);
+                const int x0 = xin0 || xin1 ? (int)fx0 : 0, y0 = yin0 || yin1 ? (int)fy0 : 0;
+                Proj pr;
+                pr.off = (uint32_t)((y0 * w + x0) * C) * 4u;
+                pr.tx = ix - fx0; pr.ty = iy - fy0;
+                pr.bits = (xin0 ? 1u : 0u) | (xin1 ? 2u : 0u) | (yin0 ? 4u : 0u) | (yin1 ? 8u : 0u) | (zz > 0.0f ? 16u : 0u);
+                return pr;
+            };
+            auto taps = [&](int k, const Proj pr, float (&wv)[NR]) __attribute__((always_inline)) {
+                const bool xin0 = pr.bits & 1u, xin1 = pr.bits & 2u, yin0 = pr.bits & 4u, yin1 = pr.bits & 8u;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) wv[r] = 0.0f;
+                const char* base = (const char*)(srcN + (((size_t)b * K + k) * hw) * C);
+                const uint32_t off0 = pr.off + 16u * (uint32_t)c;
+                // The taps of a source in flight together, two at a time: wave-uniform tests (a source, or a tap, that no pixel of the
+                // wavefront sees costs no load instruction), the loads issued back to back -- a tap outside the image reads texel 0
+                // with weight 0 --, then the blends.  (Tap by tap, each behind its own branch and wait, the two wavefronts of a SIMD
+                // spent most of a plane's time in 4 K serial memory round trips.)
+                const bool any_ok = live && (xin0 || xin1) && (yin0 || yin1);
+#ifdef FS_BWD16_NO_TAPS   // (timing-only build, WRONG results: the sweep without its tap loads)
+                if (false) {
+#else
+                if (__builtin_amdgcn_ballot_w64(any_ok) != 0ull) {
+#endif
+#ifndef FS_BWD16_TAPS_IN_FLIGHT
+#define FS_BWD16_TAPS_IN_FLIGHT 2      // taps of a source loaded together (4: measured the same, 5 more spilled registers)
+#endif
+                    constexpr int TF = FS_BWD16_TAPS_IN_FLIGHT;
+#pragma unroll
+                    for (int t0 = 0; t0 < 4; t0 += TF) {
+                        float4 v[TF][NS];
+                        float wt[TF];
+#pragma unroll
+                        for (int tt = 0; tt < TF; ++tt) {
+                            const int tap = t0 + tt, ox = tap & 1, oy = tap >> 1;
+                            const bool ok = live && (ox ? xin1 : xin0) && (oy ? yin1 : yin0);
+                            wt[tt] = ok ? (ox ? pr.tx : 1.0f - pr.tx) * (oy ? pr.ty : 1.0f - pr.ty) : 0.0f;
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) v[tt][s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            const float4* q = (const float4*)(base + (ok ? off0 + (uint32_t)((oy * w + ox) * C) * 4u : 16u * (uint32_t)c));
+                            if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {     // (a tap no pixel of the wavefront has: no load instructions)
+#pragma unroll
+                                for (int s = 0; s < NS; ++s) v[tt][s] = q[4 * s];
+                            }
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < TF; ++tt)
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) {
+                                wv[4 * s] = fmaf(wt[tt], v[tt][s].x, wv[4 * s]); wv[4 * s + 1] = fmaf(wt[tt], v[tt][s].y, wv[4 * s + 1]);
+                                wv[4 * s + 2] = fmaf(wt[tt], v[tt][s].z, wv[4 * s + 2]); wv[4 * s + 3] = fmaf(wt[tt], v[tt][s].w, wv[4 * s + 3]);
+                            }
+                    }
+                }
+            };
+            auto gather = [&](int k, const Proj pr) __attribute__((always_inline)) {
+                float wv[NR];
+                taps(k, pr, wv);
+                const bool front = pr.bits & 16u;
+                float part = 0.0f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const float4 cu = sCurG[64 * s + lane];
+                    part += wv[4 * s] * cu.x; part += wv[4 * s + 1] * cu.y; part += wv[4 * s + 2] * cu.z; part += wv[4 * s + 3] * cu.w;
+                }
+                part += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(part), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+                part += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(part), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+                const float dotk = front ? part : 0.0f;
+                flags |= (front ? 2u : 0u) << (2 * k);
+                // in front, some tap inside the source image, and still an exactly zero score (all-zero features): the score's
+                // gradient reaches the current feature although the source is not averaged -- re-gathered below
+                if (live && front && dotk == 0.0f && (pr.bits & 3u) && (pr.bits & 12u)) rare |= 1u << (2 * k);
+                if (dotk != 0.0f) {
+                    flags |= 1u << (2 * k);
+                    cnt += 1.0f;
+                    dot_sum += dotk;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) favg[r] += wv[r];
+                }
+            };
+            for (int k0 = 0; k0 < K; k0 += 4) {
+                float Pk[12];
+                if (k0 == 0) {
+                    const float4 p0 = sPq[0], p1 = sPq[1], p2 = sPq[2];
+                    Pk[0] = p0.x; Pk[1] = p0.y; Pk[2] = p0.z; Pk[3] = p0.w; Pk[4] = p1.x; Pk[5] = p1.y; Pk[6] = p1.z; Pk[7] = p1.w;
+                    Pk[8] = p2.x; Pk[9] = p2.y; Pk[10] = p2.z; Pk[11] = p2.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) Pk[e] = Pmat[((size_t)b * K + min(k0 + c, K - 1)) * 12 + e];
+                }
+                const Proj mine = project(Pk);
+                auto from = [&](auto sel) __attribute__((always_inline)) {
+                    constexpr int q = decltype(sel)::value, ctl = q * 0x55;       // quad_perm: every lane reads lane q of its quad
+                    Proj pr;
+                    pr.off = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine.off, ctl, 0xF, 0xF, true);
+                    pr.tx = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.tx), ctl, 0xF, 0xF, true));
+                    pr.ty = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mine.ty), ctl, 0xF, 0xF, true));
+                    pr.bits = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine.bits, ctl, 0xF, 0xF, true);
+                    return pr;
+                };
+                gather(k0, from(std::integral_constant<int, 0>{}));
+                if (k0 + 1 < K) gather(k0 + 1, from(std::integral_constant<int, 1>{}));
+                if (k0 + 2 < K) gather(k0 + 2, from(std::integral_constant<int, 2>{}));
+                if (k0 + 3 < K) gather(k0 + 3, from(std::integral_constant<int, 3>{}));
+            }
+            const float inv_g = 1.0f / (cnt + 1e-8f);
+            const float dot_g = dot_sum * inv_g;
+            FS_CV_T(tq1, dot_g + favg[0] + favg[NR - 1]);
+            // The matrix part below is laid out as PHASES separated by scheduling barriers: every phase first issues the LDS reads
+            // of the NEXT phase's operands (weight images, tile rows), then runs its MFMAs -- left to itself the scheduler put each
+            // ds_read / ds_bpermute directly in front of the MFMA that uses it (s_waitcnt lgkmcnt(0) before almost every MFMA).
+#define FS_PHASE() __builtin_amdgcn_sched_barrier(0)
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 0: x = favg / cnt into its tile (B operand of dW1) and, by ds_bpermute, to the operand order; W1 operands ----
+            float xop[NT];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float x = favg[r] * inv_g;
+                xop[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(x)));
+                tX[256 * (r >> 2) + xw_at + 4 * ((r & 3) ^ xw_k)] = x;
+            }
+            xop[NR] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(c == 0 ? dot_g : (c == 1 ? 1.0f : 0.0f))));
+            const uint32_t flags_m = (uint32_t)__builtin_amdgcn_ds_bpermute(pull0, (int)flags);
+            const float dot_m = __int_as_float(__builtin_amdgcn_ds_bpermute(pull0, __float_as_int(dot_g)));
+#define FS_WA(q) sA1[(q) * 64]
+            FS_PHASE();
+            // ---- phase 1: W2 operands, b2, w3 on their way; layer 1 ----
+#define FS_WB(q) sA2[(q) * 64]
+            const float4 b2A = sB2[0], b2B = sB2[4], w3A = sW3[0], w3B = sW3[4];
+            FS_PHASE();
+            f32x4 z1[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) z1[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(FS_WA(NT * blk + t), xop[t], z1[blk], 0, 0, 0);
+            FS_PHASE();
+            FS_CV_T(tq2, z1[0][0] + z1[1][3]);
+            // ---- phase 2: h1 (to its tile), W2^T operands on their way; layer 2 ----
+            const float inv = 1.0f / ((float)__builtin_popcount(flags_m & 0x55555555u) + 1e-8f);
+            uint32_t pos1 = 0;      // lrelu'(z1) as a bit per (blk, r)
+            f32x4 h1[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pos1 |= (z1[blk][r] > 0.0f ? 1u : 0u) << (4 * blk + r);
+                    h1[blk][r] = lrelu(z1[blk][r]);
+                    tH1[256 * blk + wr_at[r]] = h1[blk][r];
+                }
+#define FS_WC(q) sA2T[(q) * 64]
+            FS_PHASE();
+            f32x4 z2[2] = {f32x4{b2A.x, b2A.y, b2A.z, b2A.w}, f32x4{b2B.x, b2B.y, b2B.z, b2B.w}};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) z2[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(FS_WB(8 * blk + t), h1[t >> 2][t & 3], z2[blk], 0, 0, 0);
+            FS_PHASE();
+            // ---- phase 3: dz2 (to its tile) and the sums over it; the h1 / dz2 tile rows (dW2 operands) on their way; dh1 ----
+            f32x4 dz2[2];
+            {
+                const float w3v[2][4] = {{w3A.x, w3A.y, w3A.z, w3A.w}, {w3B.x, w3B.y, w3B.z, w3B.w}};
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = z2[blk][r];
+                        dz2[blk][r] = go * w3v[blk][r] * dlrelu(z);
+                        s_w3[blk][r] = fmaf(go, lrelu(z), s_w3[blk][r]);
+                        s_b2[blk][r] += dz2[blk][r];
+                        tD2[256 * blk + wr_at[r]] = dz2[blk][r];
+                    }
+            }
+            if (g == 0) s_b3 += go;
+            wave_lds_sync();
+            const float4 H0 = *(const float4*)(tH1 + rd_at), H1 = *(const float4*)(tH1 + 256 + rd_at);
+            const float4 E0 = *(const float4*)(tD2 + rd_at), E1 = *(const float4*)(tD2 + 256 + rd_at);
+            FS_PHASE();
+            f32x4 dz1[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int bo = 0; bo < 2; ++bo) dz1[bo] = __builtin_amdgcn_mfma_f32_16x16x4f32(FS_WC(8 * bo + t), dz2[t >> 2][t & 3], dz1[bo], 0, 0, 0);
+            FS_PHASE();
+            FS_CV_T(tq3, dz1[0][0] + dz1[1][3]);
+            // ---- phase 4: W1^T operands on their way; dW2 (independent of dz1: the matrix pipe runs while dh1 drains) ----
+#define FS_WD(q) sA1T[(q) * 64]
+            const float4 w1dA = sW1d[0], w1dB = sW1d[4];
+            FS_PHASE();
+            {
+                const float av[2][4] = {{E0.x, E0.y, E0.z, E0.w}, {E1.x, E1.y, E1.z, E1.w}};
+                const float hv[2][4] = {{H0.x, H0.y, H0.z, H0.w}, {H1.x, H1.y, H1.z, H1.w}};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#ifdef FS_BWD16_NO_DW     // (timing-only build, WRONG weight gradients: the sweep without its two outer-product phases)
+                            acc2[rb][cb][s] += av[rb][s] + hv[cb][s];
+#else
+                            acc2[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][s], hv[cb][s], acc2[rb][cb], 0, 0, 0);
+#endif
+            }
+            FS_PHASE();
+            // ---- phase 5: dz1 (to its tile) and the sums over it; its tile rows and x's (dW1 operands) on their way; dx ----
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dz1[blk][r] *= ((pos1 >> (4 * blk + r)) & 1u) ? 1.0f : 0.01f;
+                    s_b1[blk][r] += dz1[blk][r];
+                    s_dot[blk][r] = fmaf(dz1[blk][r], dot_m, s_dot[blk][r]);
+                    tD1[256 * blk + wr_at[r]] = dz1[blk][r];
+                }
+            wave_lds_sync();
+            const float4 F0 = *(const float4*)(tD1 + rd_at), F1 = *(const float4*)(tD1 + 256 + rd_at);
+            float4 X4[RB];
+#pragma unroll
+            for (int cb = 0; cb < RB; ++cb) X4[cb] = *(const float4*)(tX + 256 * cb + rd_at);
+            FS_PHASE();
+            // dx = W1^T dz1: register (rb, r) = channel 16 rb + 4 g + r of pixel n
+            f32x4 dx[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) dx[rb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) dx[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(FS_WD(8 * rb + t), dz1[t >> 2][t & 3], dx[rb], 0, 0, 0);
+            FS_PHASE();
+            // ---- phase 6: the current feature (record) on its way, d dot; dW1 ----
+            float4 cv4[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) cv4[rb] = sCur[64 * rb + lane];
+            float ddot;
+            {
+                float a = w1dA.x * dz1[0][0];
+                a = fmaf(w1dA.y, dz1[0][1], a); a = fmaf(w1dA.z, dz1[0][2], a); a = fmaf(w1dA.w, dz1[0][3], a);
+                a = fmaf(w1dB.x, dz1[1][0], a); a = fmaf(w1dB.y, dz1[1][1], a); a = fmaf(w1dB.z, dz1[1][2], a); a = fmaf(w1dB.w, dz1[1][3], a);
+                a += __shfl_xor(a, 16, 64);
+                ddot = a + __shfl_xor(a, 32, 64);
+            }
+            // ---- the record of the point leaves HERE, in front of dW1's MFMAs: at the end of the plane its stores were still in flight
+            //      at the next plane's first tap wait (the memory counter is in-order), ~1.5 k cycles per plane ----
+            const float di = ddot * inv;
+            if (live_m) {
+                const size_t pl = (size_t)b * D + d;
+                float4* rp = recS + (pl * (C / 4) + g) * hw + pix_m;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const float4 cv = cv4[rb];
+                    rp[(size_t)(4 * rb) * hw] = make_float4(fmaf(di, cv.x, dx[rb][0] * inv), fmaf(di, cv.y, dx[rb][1] * inv),
+                                                            fmaf(di, cv.z, dx[rb][2] * inv), fmaf(di, cv.w, dx[rb][3] * inv));
+                }
+                if (g == 0) recM[pl * hw + pix_m] = make_float2(di, __uint_as_float(flags_m));
+            }
+            FS_PHASE();
+            {
+                const float av[2][4] = {{F0.x, F0.y, F0.z, F0.w}, {F1.x, F1.y, F1.z, F1.w}};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < RB; ++cb) {
+                            const float xv = s == 0 ? X4[cb].x : (s == 1 ? X4[cb].y : (s == 2 ? X4[cb].z : X4[cb].w));
+#ifdef FS_BWD16_NO_DW
+                            acc1[rb][cb][s] += av[rb][s] + xv;
+#else
+                            acc1[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][s], xv, acc1[rb][cb], 0, 0, 0);
+#endif
+                        }
+            }
+            FS_PHASE();
+#undef FS_PHASE
+#undef FS_WA
+#undef FS_WB
+#undef FS_WC
+#undef FS_WD
+            wave_lds_sync();   // (the next plane overwrites the tiles)
+            __builtin_amdgcn_s_setprio(1);
+#ifdef FS_CV_TRACE
+            {
+                FS_CV_T(tq4, acc1[0][0][0] + acc1[1][RB - 1][3] + dx[0][0]);
+                tb0 += tq1 - tq0; tb1 += tq2 - tq1; tb2 += tq3 - tq2; tb3 += tq4 - tq3; tbn += 1;
+            }
+#endif
+            // d cur = d dot / cnt * sum_k [z_k > 0] warped_k; for every source that counts [z_k > 0] = valid_k: the sum is cnt * x
+            // (x comes back from its tile -- lane (n, g)'s operand-order values sit at the accumulator-order addresses -- instead of
+            //  staying in 12 registers through the whole matrix part)
+#pragma unroll
+            for (int t = 0; t < NR; ++t) dcur[t] = fmaf(ddot, tX[256 * (t >> 2) + wr_at[t & 3]], dcur[t]);
+            if (__builtin_amdgcn_ballot_w64(rare != 0u) != 0ull) {      // (never taken on real data; wave-uniform)
+                const float ddot_g = __int_as_float(__builtin_amdgcn_ds_bpermute((lane >> 2) * 4, __float_as_int(ddot)));
+                for (int k = 0; k < K; ++k) {
+                    if (__builtin_amdgcn_ballot_w64(((rare >> (2 * k)) & 1u) != 0u) == 0ull) continue;
+                    float Pk[12];
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) Pk[e] = Pmat[((size_t)b * K + k) * 12 + e];
+                    float wv[NR];
+                    taps(k, project(Pk), wv);
+                    const float cd = ((rare >> (2 * k)) & 1u) ? inv_g * ddot_g : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        dcur[r] += __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(cd * wv[r])));
+                }
+            }
+        }
+        // ---- this half's d cur: the four wavefronts' planes summed through the (now free) tiles ([pixel][channel]); plain stores
+        //      when no other workgroup shares the pixels ----
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < NR; ++t) wv_[n * C + 16 * (t >> 2) + 4 * g + (t & 3)] = dcur[t];
+        __syncthreads();
+        {
+            const int npx = max(0, min(16, hw - pix0));
+            float* const dst = d_curN + ((size_t)b * hw + pix0) * C;
+            for (int e = threadIdx.x; e < npx * C; e += 256) {
+                const float v = s_all[kWts + e] + s_all[kWts + kWave + e] + s_all[kWts + 2 * kWave + e] + s_all[kWts + 3 * kWave + e];
+                if (slices > 1) atomicAdd(dst + e, v); else dst[e] = v;
+            }
+        }
+        __syncthreads();
+    }
+#ifdef FS_CV_TRACE
+    {
+        const int wid = (int)blockIdx.x * 4 + wave;
+        if (lane == 0 && wid < kCvTraceWaves) {
+            unsigned long long* o = g_cvb_trace + 6 * (size_t)wid;
+            o[0] = tb0; o[1] = tb1; o[2] = tb2; o[3] = tb3; o[4] = tbn; o[5] = cv_stamp((float)lane) - tb_start;
+        }
+    }
+#endif
+    // ---- the six MLP gradients: per wavefront into its region, summed over the wavefronts, one atomic per weight ----
+    {
+        float* const stg = wv_;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[((2 * rb + cb) * 4 + r) * 64 + lane] = acc2[rb][cb][r];
+#pragma unroll
+            for (int cb = 0; cb < RB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[(16 + (RB * rb + cb) * 4 + r) * 64 + lane] = acc1[rb][cb][r];
+        }
+        // the per-lane sums: over the 16 pixels of the lane's row (lanes n + 16 g: xor 1, 2, 4, 8), then lane n == 0 of each g
+        auto row_sum = [&](float v) __attribute__((always_inline)) {
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            return v;
+        };
+        float* const sums = stg + kAccRegs * 64;     // [kind 0..3][unit 32], then b3
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v0 = row_sum(s_dot[blk][r]), v1 = row_sum(s_b1[blk][r]), v2 = row_sum(s_b2[blk][r]), v3 = row_sum(s_w3[blk][r]);
+                if (n == 0) {
+                    const int u = 16 * blk + 4 * g + r;
+                    sums[u] = v0; sums[32 + u] = v1; sums[64 + u] = v2; sums[96 + u] = v3;
+                }
+            }
+        {
+            float v = row_sum(s_b3);     // (only the g == 0 row counted)
+            if (lane == 0) sums[128] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const float* const st0 = s_all + kWts;
+        for (int e = threadIdx.x; e < kAccRegs * 64; e += 256) {
+            const float v = st0[e] + st0[kWave + e] + st0[2 * kWave + e] + st0[3 * kWave + e];
+            const int idx = e >> 6, l = e & 63, r = idx & 3, row4 = l >> 4, col = l & 15;
+            if (idx < 16) {
+                const int rb = idx >> 3, cb = (idx >> 2) & 1;
+                atomicAdd(&gw2[(16 * rb + 4 * row4 + r) * 32 + 16 * cb + col], v);
+            } else {
+                const int q = (idx - 16) >> 2, rb = q / RB, cb = q - rb * RB;
+                atomicAdd(&gw1[(16 * rb + 4 * row4 + r) * (C + 1) + 16 * cb + col], v);
+            }
+        }
+        if (threadIdx.x < 129) {
+            const int e = kAccRegs * 64 + threadIdx.x;
+            const float v = st0[e] + st0[kWave + e] + st0[2 * kWave + e] + st0[3 * kWave + e];
+            const int kind = threadIdx.x >> 5, u = threadIdx.x & 31;
+            if (threadIdx.x == 128) atomicAdd(gb3, v);
+            else if (kind == 0) atomicAdd(&gw1[u * (C + 1) + C], v);
+            else if (kind == 1) atomicAdd(&gb1[u], v);
+            else if (kind == 2) atomicAdd(&gb2[u], v);
+            else atomicAdd(&gw3[u], v);
+        }
+    }
+}
+
+// ==========================================================================================
 // Backward, second pass (round 4): the source-feature gradient WITHOUT global atomics.
 //   d src_k[t] = sum over (pixel p, plane d) whose bilinear taps cover texel t of
 //                w_tap * (valid_k * dfavg'(p, d) + [z_k > 0] * ddot'(p, d) * cur(p))
@@ -1293,7 +1876,9 @@ __device__ unsigned long long g_sg_stats[8];   // [3] whole-image fallbacks, [4]
 // pixels (plane by lane);
 // the four boxes are computed by 16 lanes at once (lane 4 g + q: corner q of plane g, quad reductions).  The loads of the
 // next 64 pixels are issued before the taps of the current 64 are added.
-template <int C>
+// NAT: the records (and the current map of the rare path) are in natural channel order -- cost_volume16_bwd_kernel's -- instead of
+// the 32-pixel kernel's [parity][C/2] order.
+template <int C, bool NAT>
 __global__ __launch_bounds__(64) void cv_src_grad_kernel(
     int B, int K, int h, int w, int D, int chunks, int tiles_x, int tiles_y, const float* __restrict__ curT,
     const float4* __restrict__ recS, const float2* __restrict__ recM, const float* __restrict__ Pmat,
@@ -1506,7 +2091,7 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
         }
     }
     wave_lds_sync();
-    // ---- the tile leaves once, in the caller's [C, h, w] layout (slot q = parity * C/2 + s  ->  channel 2 s + parity) ----
+    // ---- the tile leaves once, in the caller's [C, h, w] layout (slot q = parity * C/2 + s  ->  channel 2 s + parity; NAT: q) ----
     {
         float* const dmap = d_src + (((size_t)b * K + k) * C) * hw;
         const int ty = lane / TW, tx = lane % TW;
@@ -1518,7 +2103,7 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int q = 4 * s + e, ch = 2 * (q % HC) + q / HC;
+                const int q = 4 * s + e, ch = NAT ? q : 2 * (q % HC) + q / HC;
                 if (inside) { if (chunks > 1) atomicAdd(dpx + (size_t)ch * hw, vv[e]); else dpx[(size_t)ch * hw] = vv[e]; }
             }
         }
@@ -1801,8 +2386,12 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
         set_last_error("cost volume backward memset", hipGetLastError());
         return FS_ERR_LAUNCH;
     }
-    cv_relayout(true, false, cur_feats, curT, C, hw, B, st);
-    cv_relayout(true, false, src_feats, srcT, C, hw, B * K, st);
+    // pass 1 of the two-pass form: the 16-pixel kernel on natural-order maps (round 6), FS_CV_BWD16=0 or a saved-activation
+    // call: the 32-pixel kernel on [parity][C/2] records
+    bool bwd16 = two_pass && !saved;
+    if (const char* e = getenv("FS_CV_BWD16")) bwd16 = bwd16 && atoi(e) != 0;
+    cv_relayout(!bwd16, false, cur_feats, curT, C, hw, B, st);
+    cv_relayout(!bwd16, false, src_feats, srcT, C, hw, B * K, st);
     const int groups = (hw + 31) / 32;
     const int bslices = cv_bwd_plane_split(B, groups, D);
     auto sweep = [&](auto kernel) {
@@ -1817,19 +2406,27 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
                            (const float4*)recS, (const float2*)recM, Pmat, Ginv, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, d_src_feats);
     };
-    if (two_pass) {
+    auto sweep16 = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
+                           Pmat, cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d, w1, b1, w2, b2, w3,
+                           grad_out, d_curT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM);
+    };
+    if (bwd16) {
+        if (C == 48) { sweep16(cost_volume16_bwd_kernel<48>); tile_sweep(cv_src_grad_kernel<48, true>); }
+        else { sweep16(cost_volume16_bwd_kernel<16>); tile_sweep(cv_src_grad_kernel<16, true>); }
+    } else if (two_pass) {
         if (C == 48) {
             if (saved) sweep(cost_volume_bwd_kernel<24, true, true>); else sweep(cost_volume_bwd_kernel<24, true, false>);
-            tile_sweep(cv_src_grad_kernel<48>);
+            tile_sweep(cv_src_grad_kernel<48, false>);
         } else {
             if (saved) sweep(cost_volume_bwd_kernel<8, true, true>); else sweep(cost_volume_bwd_kernel<8, true, false>);
-            tile_sweep(cv_src_grad_kernel<16>);
+            tile_sweep(cv_src_grad_kernel<16, false>);
         }
     } else {
         if (C == 48) sweep(cost_volume_bwd_kernel<24, false, false>); else sweep(cost_volume_bwd_kernel<8, false, false>);
         cv_relayout(true, true, d_srcT, d_src_feats, C, hw, B * K, st);
     }
-    cv_relayout(true, true, d_curT, d_cur_feats, C, hw, B, st);
+    cv_relayout(!bwd16, true, d_curT, d_cur_feats, C, hw, B, st);
     FS_CHECK_LAUNCH("cost_volume_backward");
     return FS_OK;
 }

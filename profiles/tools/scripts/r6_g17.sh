@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for lib in "" _notaps _nodw _branchy; do
+  for which in c3 fvt10; do
+  echo "== lib$lib $which"
+  rm -rf /tmp/prof_x
+  FREESPLAT_LIB=$GRAFT_REPO_ROOT/freesplat_amd/libfreesplat_hip$lib.so rocprofv3 --kernel-trace -d /tmp/prof_x -o x --output-format csv -- python profiles/tools/cv_train_prof.py $which 4 2>&1 | grep "train step"
+  python profiles/tools/kstats.py /tmp/prof_x | head -5
+  done
+done

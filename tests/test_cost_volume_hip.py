@@ -261,15 +261,17 @@ _ORACLE_CACHE = {}
 
 def _set_form(monkeypatch, form):
     """saved: the training forward keeps the MLP's inputs (FREESPLAT_CV_SAVE=1; the default from K = 5 sources up),
-    two-pass backward; two_pass: the backward recomputes the forward (FREESPLAT_CV_SAVE=0); atomic: the one-kernel
-    scatter form (FS_CV_BWD_ATOMIC=1)."""
+    two-pass backward (pass 1: the 32-pixel kernel from saved inputs); two_pass: the backward recomputes the forward
+    (FREESPLAT_CV_SAVE=0; pass 1: round 6's 16-pixel kernel); two_pass_32px: the same with round 4's 32-pixel pass 1
+    (FS_CV_BWD16=0); atomic: the one-kernel scatter form (FS_CV_BWD_ATOMIC=1)."""
     monkeypatch.setenv("FREESPLAT_CV_SAVE", "1" if form == "saved" else "0")
+    monkeypatch.setenv("FS_CV_BWD16", "0" if form == "two_pass_32px" else "1")
     if form == "atomic":
         monkeypatch.setenv("FS_CV_BWD_ATOMIC", "1")
 
 
 @pytest.mark.parametrize("case", list(BWD_CASES))
-@pytest.mark.parametrize("form", ["saved", "two_pass", "atomic"])
+@pytest.mark.parametrize("form", ["saved", "two_pass", "two_pass_32px", "atomic"])
 def test_backward_tight_vs_float64_oracle(hip_device, case, form, monkeypatch):
     """Every gradient of the volume (both feature maps, the six MLP tensors) against autograd of the reference-pinned
     oracle run in float64, at K = 8, K = 2, a turned-round source, C = 16 and the native 96x128 / D = 128 size, with the
@@ -345,7 +347,7 @@ def test_backward_forms_agree_with_zero_features(hip_device, monkeypatch):
     kw["src_feats"][:, 0, :, 10:20, 3:12] = 0.0
     g = torch.randn(V, D, h4, w4, generator=torch.Generator().manual_seed(4)).to(hip_device)
     res = {}
-    for form in ("saved", "two_pass", "atomic"):
+    for form in ("saved", "two_pass", "two_pass_32px", "atomic"):
         _set_form(monkeypatch, form)
         a = {k: v.to(hip_device) for k, v in kw.items()}
         a["cur_feats"].requires_grad_(True)
@@ -353,7 +355,7 @@ def test_backward_forms_agree_with_zero_features(hip_device, monkeypatch):
         m.zero_grad()
         (m(**a) * g).sum().backward()
         res[form] = [a["cur_feats"].grad.cpu(), a["src_feats"].grad.cpu()] + [p.grad.cpu().clone() for p in m.parameters()]
-    for form in ("saved", "two_pass"):
+    for form in ("saved", "two_pass", "two_pass_32px"):
         for x, y in zip(res[form], res["atomic"]):
             scale = y.abs().max().item() + 1e-30
             assert ((x - y).abs().max().item() / scale) < 1e-4, form
