@@ -24,12 +24,17 @@ from . import _lib
 def save_activations(K: int) -> bool:
     """Whether a training forward keeps the MLP's input of every (view, plane, pixel) point for the backward
     (fs_cost_volume_forward_train: C + 2 floats per point, what autograd keeps of the averaged features) or the backward
-    gathers the K sources' taps again.  Opt-in (FREESPLAT_CV_SAVE=1, read at every call): measured on the final kernels
-    (profiles/r4_cv_bwd_form_ab2.txt, forward + backward) it buys nothing -- 10 views, K = 8: 17.65 ms saved vs 17.6
-    recomputed; config-3 scale, K = 2: 13.5 vs 13.5; native, K = 1: 1.40 vs 1.39 -- because the backward's first pass is
-    bound by its 137 MFMAs and LDS transposes per 32 points, not by the gather its second wavefront per SIMD hides, while
-    the forward pays 0.4 - 0.8 ms for writing the activations."""
-    return os.environ.get("FREESPLAT_CV_SAVE", "0") == "1"
+    gathers the K sources' taps again.  Default: from K = 4 sources per view up; FREESPLAT_CV_SAVE=0 / 1 forces either (read at
+    every call).  Measured in round 6 (profiles/r6_cv_saved_ab.txt; rocprofv3, forward sweep + pass 1 of the backward): 10 views,
+    K = 8: 3.56 + 6.06 ms recomputed, 4.74 + 2.75 ms saved (training step 15.3 -> 13.4 ms); config-3 scale, K = 2: 2.75 + 6.80 against
+    3.89 + 6.30 (13.0 -> 13.5 ms); native, K = 1: 1.32 -> 1.43 ms -- the write costs the forward ~1.1 ms per 3 - 6 GB, the gather
+    costs pass 1 ~0.25 ms per source at config-3 scale and ~0.4 ms per source in the tap-bound K = 8 regime.  (Rounds 4 - 5 read
+    torch.is_grad_enabled() inside the Function's forward -- always False there -- so the saved path never ran through this module
+    and its "buys nothing" was an A/A measurement.)"""
+    e = os.environ.get("FREESPLAT_CV_SAVE")
+    if e in ("0", "1"):
+        return e == "1"
+    return K >= 4
 
 
 class _Backprojector(nn.Module):
@@ -77,8 +82,8 @@ class _CostVolumeFn(torch.autograd.Function):
         p = _lib.ptr
         # A backward will follow: with many sources per view the training forward keeps the MLP's input of every point and
         # the backward starts from it instead of gathering all taps again (save_activations)
-        train = (torch.is_grad_enabled() and any(ctx.needs_input_grad) and strides[2] == 0 and K <= 16
-                 and save_activations(K))
+        # (ctx.needs_input_grad is all False under no_grad; torch.is_grad_enabled() is always False INSIDE a Function's forward)
+        train = any(ctx.needs_input_grad) and strides[2] == 0 and K <= 16 and save_activations(K)
         if train:
             saved = torch.empty(L.fs_cost_volume_saved_bytes(B, C, h, w, D), dtype=torch.uint8, device=dev)
             _lib.check(L.fs_cost_volume_forward_train(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),

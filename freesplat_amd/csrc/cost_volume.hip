@@ -239,7 +239,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // SAVE (training forward): the MLP's input of every (pixel, plane) point -- the averaged warped features x = favg / cnt,
 // the averaged score and the sources' (valid, in-front) bits -- is kept for the backward, which then starts from it
-// instead of gathering K x 4 taps again (chunk-planar in the backward's channel order: cost_volume_bwd_kernel).
+// instead of gathering K x 4 taps again (chunk-planar, natural channel order: cost_volume16_bwd_kernel<C, true>).
 template <int C, bool SAVE>
 __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
     int B, int K, int h, int w, int D, int slices, const float* __restrict__ curN, const float* __restrict__ srcN,
@@ -430,15 +430,14 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
         const float inv = 1.0f / (cnt + 1e-8f);                          // :595-598
         FS_CV_T(t_gath, favg[0] + favg[NR - 1] + inv + dot_sum);
         if (SAVE && live) {
-            // channel 16 s + 4 c + i = parity i & 1, slot 8 s + 2 c + (i >> 1): float4 chunk 2 s + (c >> 1) of that parity's
-            // C/8 chunks, elements 2 (c & 1) + {0, 1}: two lanes of a quad fill one float4, 16 pixels are 256 contiguous bytes
+            // natural channel order, chunk-planar: this lane's channels 16 s + 4 c + 0..3 are float4 chunk 4 s + c of the point's
+            // C/4 chunks ([view, plane][chunk][pixel]: 16 pixels of a chunk are 256 contiguous bytes) -- what a lane (n, g) of
+            // cost_volume16_bwd_kernel<C, true> takes as its layer-1 operands, one float4 per 16-channel block
             const size_t pl = (size_t)b * D + d;
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-                    *(float2*)(xs + ((pl * (C / 4) + (size_t)hf * (C / 8) + 2 * s + (c >> 1)) * hw + pix) * 4 + 2 * (c & 1)) =
-                        make_float2(favg[4 * s + hf] * inv, favg[4 * s + 2 + hf] * inv);
+                ((float4*)xs)[(pl * (C / 4) + 4 * s + c) * hw + pix] =
+                    make_float4(favg[4 * s] * inv, favg[4 * s + 1] * inv, favg[4 * s + 2] * inv, favg[4 * s + 3] * inv);
             if (c == 0) xm[pl * hw + pix] = make_float2(dot_sum * inv, __uint_as_float(flags));
         }
         // ---- to the operand order: lane (n, g) takes quarter g of pixel n ----
@@ -779,7 +778,7 @@ __device__ __forceinline__ constexpr int row_half(int i) { return (i >> 2) & 1; 
 //     adds the 16 entries of its unit that it reads as MFMA operands) and of a half-height tile of g * h2 (neighbouring
 //     pixels pre-added with one DPP step) -- two accumulators instead of 32, and z2 is dead as soon as it is computed;
 //   * dW2 and dW1 are accumulated in two phases that share the dz tile (dz2, then dz1); lrelu'(z1) is kept as a bit mask.
-template <int HC, bool SPLIT, bool SAVED>
+template <int HC, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
     int B, int K, int h, int w, int D, int slices, const float* __restrict__ curT, const float* __restrict__ srcT,
     const float* __restrict__ Pmat,
@@ -788,10 +787,8 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
     const float* __restrict__ g_out, float* __restrict__ d_curT, float* __restrict__ d_srcT,
     float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
-    float* __restrict__ gw3, float* __restrict__ gb3, float4* __restrict__ recS, float2* __restrict__ recM,
-    const float4* __restrict__ xs, const float2* __restrict__ xm, const uint32_t* __restrict__ xhdr)
+    float* __restrict__ gw3, float* __restrict__ gb3, float4* __restrict__ recS, float2* __restrict__ recM)
 {
-    static_assert(SPLIT || !SAVED, "the saved-activation backward exists in the two-pass form only");
     constexpr int C = 2 * HC;
     constexpr int NBLK = (HC + 1 + 15) / 16;  // row blocks of the permuted W1^T
     constexpr int XW = 2 * (HC + 1);          // features of a point: C channels, dot, 1
@@ -879,69 +876,45 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
         f32x16 z1;
         float inv, xlast;
         uint32_t flags = 0, rare = 0;   // SPLIT: bit 2k = source k valid (dot != 0), bit 2k+1 = in front of it (z > 0); rare: bit 2k
-        if (SAVED) {
-            // the training forward kept the MLP's input of this point (cost_volume16_kernel<C, true>): no gather at all
-            const size_t pl = (size_t)b * D + d;
-            const float2 mt = live ? xm[pl * hw + pix] : make_float2(0.0f, 0.0f);
-            flags = __float_as_uint(mt.y);
-            inv = 1.0f / ((float)__builtin_popcount(flags & 0x55555555u) + 1e-8f);
-            xlast = hf ? 1.0f : mt.x;
-            if (xhdr[0] != 0u) rare = (flags >> 1) & ~flags & 0x55555555u;   // in front but not averaged: re-gathered below
+        {
+        float favg[HC];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z1[r] = 0.0f;
-            const float4* xp = xs + (pl * (C / 4) + (size_t)hf * (HC / 4)) * hw + (live ? pix : 0);
+        for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
+        float dot_sum = 0.0f, cnt = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            warp_source<HC>(W, srcT + (((size_t)b * K + k) * hw) * C, w, h, hf, live, depth, rx, ry, rz,
+                             Pmat + ((size_t)b * K + k) * 12, inv_w, inv_h);
+            float part = 0.0f;
 #pragma unroll
-            for (int s4 = 0; s4 < HC / 4; ++s4) {
-                const float4 v4 = live ? xp[(size_t)s4 * hw] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                const float xv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int s = 4 * s4 + i;
-                    tx[p * XS + 2 * s + hf] = xv[i];
-                    z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + 2 * s + hf], xv[i], z1, 0, 0, 0);
-                }
+            for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
+            float dotk = part + __shfl_xor(part, 32, 64);
+            dotk = (W.zz > 0.0f) ? dotk : 0.0f;
+            if (SPLIT) {
+                flags |= (W.zz > 0.0f ? 2u : 0u) << (2 * k);
+                // in front, some tap inside the source image, and still an exactly zero score (all-zero features): the
+                // score's gradient reaches the current feature although the source is not averaged -- see below
+                if (W.zz > 0.0f && dotk == 0.0f && (W.ok[0] || W.ok[1] || W.ok[2] || W.ok[3])) rare |= 1u << (2 * k);
             }
-            tx[p * XS + C + hf] = xlast;
-            z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + C + hf], xlast, z1, 0, 0, 0);
-        } else {
-            float favg[HC];
+            if (dotk != 0.0f) {
+                if (SPLIT) flags |= 1u << (2 * k);
+                cnt += 1.0f;
+                dot_sum += dotk;
 #pragma unroll
-            for (int s = 0; s < HC; ++s) favg[s] = 0.0f;
-            float dot_sum = 0.0f, cnt = 0.0f;
-            for (int k = 0; k < K; ++k) {
-                warp_source<HC>(W, srcT + (((size_t)b * K + k) * hw) * C, w, h, hf, live, depth, rx, ry, rz,
-                                 Pmat + ((size_t)b * K + k) * 12, inv_w, inv_h);
-                float part = 0.0f;
-#pragma unroll
-                for (int s = 0; s < HC; ++s) part += W.wv[s] * cur[s];
-                float dotk = part + __shfl_xor(part, 32, 64);
-                dotk = (W.zz > 0.0f) ? dotk : 0.0f;
-                if (SPLIT) {
-                    flags |= (W.zz > 0.0f ? 2u : 0u) << (2 * k);
-                    // in front, some tap inside the source image, and still an exactly zero score (all-zero features): the
-                    // score's gradient reaches the current feature although the source is not averaged -- see below
-                    if (W.zz > 0.0f && dotk == 0.0f && (W.ok[0] || W.ok[1] || W.ok[2] || W.ok[3])) rare |= 1u << (2 * k);
-                }
-                if (dotk != 0.0f) {
-                    if (SPLIT) flags |= 1u << (2 * k);
-                    cnt += 1.0f;
-                    dot_sum += dotk;
-#pragma unroll
-                    for (int s = 0; s < HC; ++s) favg[s] += W.wv[s];
-                }
+                for (int s = 0; s < HC; ++s) favg[s] += W.wv[s];
             }
-            inv = 1.0f / (cnt + 1e-8f);
-            xlast = hf ? 1.0f : dot_sum * inv;
+        }
+        inv = 1.0f / (cnt + 1e-8f);
+        xlast = hf ? 1.0f : dot_sum * inv;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z1[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) z1[r] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < HC; ++s) {
-                const float x = favg[s] * inv;
-                tx[p * XS + 2 * s + hf] = x;      // the point's features for the dW1 products below
-                z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + 2 * s + hf], x, z1, 0, 0, 0);
-            }
-            tx[p * XS + C + hf] = xlast;
-            z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + C + hf], xlast, z1, 0, 0, 0);
+        for (int s = 0; s < HC; ++s) {
+            const float x = favg[s] * inv;
+            tx[p * XS + 2 * s + hf] = x;      // the point's features for the dW1 products below
+            z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + 2 * s + hf], x, z1, 0, 0, 0);
+        }
+        tx[p * XS + C + hf] = xlast;
+        z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[p * XS + C + hf], xlast, z1, 0, 0, 0);
         }
         // h1 replaces z1 (lrelu' survives as a bit per unit) and goes to its tile at once
         uint32_t pos1 = 0;
@@ -1234,7 +1207,9 @@ __global__ __launch_bounds__(256, 2) void cost_volume_bwd_kernel(
 // reads them.  d cur is summed over the workgroup's wavefronts in LDS and leaves as plain stores when the planes are not split
 // over workgroups.
 // ==========================================================================================
-template <int C>
+// SAVED: the training forward kept the MLP's inputs (cost_volume16_kernel<C, true>: x, the averaged score, the validity bits) --
+// no gather here at all: three float4 loads per lane and plane instead of 4 K taps.
+template <int C, bool SAVED>
 #ifdef FS_BWD16_ONE_WAVE     // (A/B build: one wavefront per SIMD with the whole 512-register file)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void cost_volume16_bwd_kernel(
 #else
@@ -1246,7 +1221,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ g_out,
     float* __restrict__ d_curN, float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2,
     float* __restrict__ gb2, float* __restrict__ gw3, float* __restrict__ gb3, float4* __restrict__ recS,
-    float2* __restrict__ recM)
+    float2* __restrict__ recM, const float4* __restrict__ xs, const float2* __restrict__ xm, const uint32_t* __restrict__ xhdr)
 {
     constexpr int NS = C / 16;          // tap load instructions per tap = 16-channel blocks
     constexpr int NR = C / 4;           // channels per lane
@@ -1469,7 +1444,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     for (int r = 0; r < NR; ++r) favg[r] += wv[r];
                 }
             };
-            for (int k0 = 0; k0 < K; k0 += 4) {
+            for (int k0 = 0; !SAVED && k0 < K; k0 += 4) {
                 float Pk[12];
                 if (k0 == 0) {
                     const float4 p0 = sPq[0], p1 = sPq[1], p2 = sPq[2];
@@ -1504,26 +1479,45 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             __builtin_amdgcn_s_setprio(0);
             // ---- phase 0: x = favg / cnt into its tile (B operand of dW1) and, by ds_bpermute, to the operand order; W1 operands ----
             float xop[NT];
+            uint32_t flags_m;
+            float dot_m;
+            if (SAVED) {
+                // from the training forward: lane (n, g)'s operand-order x is chunk 4 rb + g of the point, one float4 per block
+                const size_t pl = (size_t)b * D + d;
+                const float2 mt = live_m ? xm[pl * hw + pix_m] : make_float2(0.0f, 0.0f);
+                dot_m = mt.x;
+                flags_m = __float_as_uint(mt.y);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const float x = favg[r] * inv_g;
-                xop[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(x)));
-                tX[256 * (r >> 2) + xw_at + 4 * ((r & 3) ^ xw_k)] = x;
+                for (int rb = 0; rb < RB; ++rb) {
+                    const float4 v4 = live_m ? xs[(pl * (C / 4) + 4 * rb + g) * hw + pix_m] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    xop[4 * rb] = v4.x; xop[4 * rb + 1] = v4.y; xop[4 * rb + 2] = v4.z; xop[4 * rb + 3] = v4.w;
+                }
+#pragma unroll
+                for (int t = 0; t < NR; ++t) tX[256 * (t >> 2) + wr_at[t & 3]] = xop[t];
+                xop[NR] = g == 0 ? dot_m : (g == 1 ? 1.0f : 0.0f);
+                // a source in front that is not averaged MAY have had an exactly zero score with taps inside (the forward raised the
+                // header flag if any did): re-gathered below; one whose taps are all outside contributes zeros there
+                if (xhdr[0] != 0u) rare = __builtin_amdgcn_ds_bpermute((lane >> 2) * 4, (int)((flags_m >> 1) & ~flags_m & 0x55555555u));
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float x = favg[r] * inv_g;
+                    xop[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(x)));
+                    tX[256 * (r >> 2) + xw_at + 4 * ((r & 3) ^ xw_k)] = x;
+                }
+                xop[NR] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(c == 0 ? dot_g : (c == 1 ? 1.0f : 0.0f))));
+                flags_m = (uint32_t)__builtin_amdgcn_ds_bpermute(pull0, (int)flags);
+                dot_m = __int_as_float(__builtin_amdgcn_ds_bpermute(pull0, __float_as_int(dot_g)));
             }
-            xop[NR] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(c == 0 ? dot_g : (c == 1 ? 1.0f : 0.0f))));
-            const uint32_t flags_m = (uint32_t)__builtin_amdgcn_ds_bpermute(pull0, (int)flags);
-            const float dot_m = __int_as_float(__builtin_amdgcn_ds_bpermute(pull0, __float_as_int(dot_g)));
-#define FS_WA(q) sA1[(q) * 64]
             FS_PHASE();
             // ---- phase 1: W2 operands, b2, w3 on their way; layer 1 ----
-#define FS_WB(q) sA2[(q) * 64]
             const float4 b2A = sB2[0], b2B = sB2[4], w3A = sW3[0], w3B = sW3[4];
             FS_PHASE();
             f32x4 z1[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) z1[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(FS_WA(NT * blk + t), xop[t], z1[blk], 0, 0, 0);
+                for (int blk = 0; blk < 2; ++blk) z1[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(sA1[(NT * blk + t) * 64], xop[t], z1[blk], 0, 0, 0);
             FS_PHASE();
             FS_CV_T(tq2, z1[0][0] + z1[1][3]);
             // ---- phase 2: h1 (to its tile), W2^T operands on their way; layer 2 ----
@@ -1538,13 +1532,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     h1[blk][r] = lrelu(z1[blk][r]);
                     tH1[256 * blk + wr_at[r]] = h1[blk][r];
                 }
-#define FS_WC(q) sA2T[(q) * 64]
             FS_PHASE();
             f32x4 z2[2] = {f32x4{b2A.x, b2A.y, b2A.z, b2A.w}, f32x4{b2B.x, b2B.y, b2B.z, b2B.w}};
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) z2[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(FS_WB(8 * blk + t), h1[t >> 2][t & 3], z2[blk], 0, 0, 0);
+                for (int blk = 0; blk < 2; ++blk) z2[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(sA2[(8 * blk + t) * 64], h1[t >> 2][t & 3], z2[blk], 0, 0, 0);
             FS_PHASE();
             // ---- phase 3: dz2 (to its tile) and the sums over it; the h1 / dz2 tile rows (dW2 operands) on their way; dh1 ----
             f32x4 dz2[2];
@@ -1570,11 +1563,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int bo = 0; bo < 2; ++bo) dz1[bo] = __builtin_amdgcn_mfma_f32_16x16x4f32(FS_WC(8 * bo + t), dz2[t >> 2][t & 3], dz1[bo], 0, 0, 0);
+                for (int bo = 0; bo < 2; ++bo) dz1[bo] = __builtin_amdgcn_mfma_f32_16x16x4f32(sA2T[(8 * bo + t) * 64], dz2[t >> 2][t & 3], dz1[bo], 0, 0, 0);
             FS_PHASE();
             FS_CV_T(tq3, dz1[0][0] + dz1[1][3]);
             // ---- phase 4: W1^T operands on their way; dW2 (independent of dz1: the matrix pipe runs while dh1 drains) ----
-#define FS_WD(q) sA1T[(q) * 64]
             const float4 w1dA = sW1d[0], w1dB = sW1d[4];
             FS_PHASE();
             {
@@ -1616,7 +1608,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) dx[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(FS_WD(8 * rb + t), dz1[t >> 2][t & 3], dx[rb], 0, 0, 0);
+                for (int rb = 0; rb < RB; ++rb) dx[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(sA1T[(8 * rb + t) * 64], dz1[t >> 2][t & 3], dx[rb], 0, 0, 0);
             FS_PHASE();
             // ---- phase 6: the current feature (record) on its way, d dot; dW1 ----
             float4 cv4[RB];
@@ -1663,10 +1655,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             FS_PHASE();
 #undef FS_PHASE
-#undef FS_WA
-#undef FS_WB
-#undef FS_WC
-#undef FS_WD
             wave_lds_sync();   // (the next plane overwrites the tiles)
             __builtin_amdgcn_s_setprio(1);
 #ifdef FS_CV_TRACE
@@ -1681,7 +1669,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int t = 0; t < NR; ++t) dcur[t] = fmaf(ddot, tX[256 * (t >> 2) + wr_at[t & 3]], dcur[t]);
             if (__builtin_amdgcn_ballot_w64(rare != 0u) != 0ull) {      // (never taken on real data; wave-uniform)
-                const float ddot_g = __int_as_float(__builtin_amdgcn_ds_bpermute((lane >> 2) * 4, __float_as_int(ddot)));
+                // (gather order: pixel j's d dot / cnt from operand lane j)
+                const float di_g = __int_as_float(__builtin_amdgcn_ds_bpermute((lane >> 2) * 4, __float_as_int(di)));
                 for (int k = 0; k < K; ++k) {
                     if (__builtin_amdgcn_ballot_w64(((rare >> (2 * k)) & 1u) != 0u) == 0ull) continue;
                     float Pk[12];
@@ -1689,7 +1678,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     for (int e = 0; e < 12; ++e) Pk[e] = Pmat[((size_t)b * K + k) * 12 + e];
                     float wv[NR];
                     taps(k, project(Pk), wv);
-                    const float cd = ((rare >> (2 * k)) & 1u) ? inv_g * ddot_g : 0.0f;
+                    const float cd = ((rare >> (2 * k)) & 1u) ? di_g : 0.0f;
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
                         dcur[r] += __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(cd * wv[r])));
@@ -2174,8 +2163,8 @@ FS_API size_t fs_cost_volume_workspace_bytes(int32_t B, int32_t K, int32_t C, in
 }
 
 // layout of the training forward's `saved` buffer: a 256-byte header (word 0: some source had an exactly zero score with
-// taps inside its image), then x = favg / cnt as [B*D][C/4 float4 chunks][h*w] (parity-major chunks: the backward's
-// channel order), then (averaged score, validity bits) as [B*D][h*w] float2
+// taps inside its image), then x = favg / cnt as [B*D][C/4 float4 chunks][h*w] (chunk q = channels 4 q .. 4 q + 3: natural order,
+// what cost_volume16_bwd_kernel<C, true> reads), then (averaged score, validity bits) as [B*D][h*w] float2
 static inline size_t cv_saved_xs_bytes(int B, int C, int h, int w, int D) { return align_up((size_t)B * D * h * w * C * sizeof(float), 256); }
 FS_API size_t fs_cost_volume_saved_bytes(int32_t B, int32_t C, int32_t h, int32_t w, int32_t D)
 {
@@ -2361,9 +2350,6 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
     float* Ginv = (float*)((char*)recM + align_up((size_t)B * D * hw * 2 * sizeof(float), 256));
     const bool two_pass = cv_bwd_two_pass(K, plane_stride_pix);
     if (!two_pass) saved = nullptr;   // (the one-kernel scatter form needs every source's taps: it recomputes the forward)
-    const uint32_t* xhdr = (const uint32_t*)saved;
-    const float4* xs = saved ? (const float4*)((const char*)saved + 256) : nullptr;
-    const float2* xm = saved ? (const float2*)((const char*)saved + 256 + cv_saved_xs_bytes(B, C, h, w, D)) : nullptr;
     const int tiles_x = (w + kSgTW - 1) / kSgTW, tiles_y = (h + kSgTH - 1) / kSgTH, tiles = tiles_x * tiles_y;
     // plane chunks of the source-tile sweep: one (plain stores) when there are enough tiles to fill the chip (256 CUs x
     // 11 single-wavefront workgroups), else enough chunks for one full round (their tiles then leave through atomics
@@ -2388,8 +2374,12 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
     }
     // pass 1 of the two-pass form: the 16-pixel kernel on natural-order maps (round 6), FS_CV_BWD16=0 or a saved-activation
     // call: the 32-pixel kernel on [parity][C/2] records
-    bool bwd16 = two_pass && !saved;
+    bool bwd16 = two_pass;
     if (const char* e = getenv("FS_CV_BWD16")) bwd16 = bwd16 && atoi(e) != 0;
+    if (!bwd16) saved = nullptr;   // (the saved activations are in the 16-pixel kernel's chunk order: the other forms recompute)
+    const uint32_t* xhdr = (const uint32_t*)saved;
+    const float4* xs = saved ? (const float4*)((const char*)saved + 256) : nullptr;
+    const float2* xm = saved ? (const float2*)((const char*)saved + 256 + cv_saved_xs_bytes(B, C, h, w, D)) : nullptr;
     cv_relayout(!bwd16, false, cur_feats, curT, C, hw, B, st);
     cv_relayout(!bwd16, false, src_feats, srcT, C, hw, B * K, st);
     const int groups = (hw + 31) / 32;
@@ -2398,7 +2388,7 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
         hipLaunchKernelGGL(kernel, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b,
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
-                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM, xs, xm, xhdr);
+                           d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM);
     };
     auto tile_sweep = [&](auto kernel) {
         const unsigned grid = 8u * (unsigned)B * (unsigned)((tiles + 7) >> 3) * (unsigned)K * (unsigned)chunks;
@@ -2409,21 +2399,26 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
     auto sweep16 = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(cv_grid(B, groups, bslices)), dim3(256), 0, st, B, K, h, w, D, bslices, curT, srcT,
                            Pmat, cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d, w1, b1, w2, b2, w3,
-                           grad_out, d_curT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM);
+                           grad_out, d_curT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM, xs, xm, xhdr);
     };
     if (bwd16) {
-        if (C == 48) { sweep16(cost_volume16_bwd_kernel<48>); tile_sweep(cv_src_grad_kernel<48, true>); }
-        else { sweep16(cost_volume16_bwd_kernel<16>); tile_sweep(cv_src_grad_kernel<16, true>); }
+        if (C == 48) {
+            if (saved) sweep16(cost_volume16_bwd_kernel<48, true>); else sweep16(cost_volume16_bwd_kernel<48, false>);
+            tile_sweep(cv_src_grad_kernel<48, true>);
+        } else {
+            if (saved) sweep16(cost_volume16_bwd_kernel<16, true>); else sweep16(cost_volume16_bwd_kernel<16, false>);
+            tile_sweep(cv_src_grad_kernel<16, true>);
+        }
     } else if (two_pass) {
         if (C == 48) {
-            if (saved) sweep(cost_volume_bwd_kernel<24, true, true>); else sweep(cost_volume_bwd_kernel<24, true, false>);
+            sweep(cost_volume_bwd_kernel<24, true>);
             tile_sweep(cv_src_grad_kernel<48, false>);
         } else {
-            if (saved) sweep(cost_volume_bwd_kernel<8, true, true>); else sweep(cost_volume_bwd_kernel<8, true, false>);
+            sweep(cost_volume_bwd_kernel<8, true>);
             tile_sweep(cv_src_grad_kernel<16, false>);
         }
     } else {
-        if (C == 48) sweep(cost_volume_bwd_kernel<24, false, false>); else sweep(cost_volume_bwd_kernel<8, false, false>);
+        if (C == 48) sweep(cost_volume_bwd_kernel<24, false>); else sweep(cost_volume_bwd_kernel<8, false>);
         cv_relayout(true, true, d_srcT, d_src_feats, C, hw, B * K, st);
     }
     cv_relayout(!bwd16, true, d_curT, d_cur_feats, C, hw, B, st);
