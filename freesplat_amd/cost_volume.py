@@ -30,7 +30,7 @@ def save_activations(K: int) -> bool:
     3.89 + 6.30 (13.0 -> 13.5 ms); native, K = 1: 1.32 -> 1.43 ms -- the write costs the forward ~1.1 ms per 3 - 6 GB, the gather
     costs pass 1 ~0.25 ms per source at config-3 scale and ~0.4 ms per source in the tap-bound K = 8 regime.  (Rounds 4 - 5 read
     torch.is_grad_enabled() inside the Function's forward -- always False there -- so the saved path never ran through this module
-    and its "buys nothing" was an A/A measurement.)"""
+    and its "buys nothing" was an A/A measurement; the module's forward now decides, in the caller's grad mode.)"""
     e = os.environ.get("FREESPLAT_CV_SAVE")
     if e in ("0", "1"):
         return e == "1"
@@ -69,10 +69,13 @@ class MLP(nn.Module):
         self.net = nn.Sequential(*layers)
 
 
+CALLS = {"forward_train": 0}     # how often the activation-keeping forward ran (tests: the path is alive, and only when a backward can follow)
+
+
 class _CostVolumeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK, planes, strides, w1, b1, w2, b2,
-                w3, b3, layout=0):
+                w3, b3, layout=0, train=False):
         B, K, C, h, w = src_feats.shape
         D = planes.shape[0] if planes.dim() == 1 else planes.shape[1]
         dev = cur_feats.device
@@ -82,9 +85,11 @@ class _CostVolumeFn(torch.autograd.Function):
         p = _lib.ptr
         # A backward will follow: with many sources per view the training forward keeps the MLP's input of every point and
         # the backward starts from it instead of gathering all taps again (save_activations)
-        # (ctx.needs_input_grad is all False under no_grad; torch.is_grad_enabled() is always False INSIDE a Function's forward)
-        train = any(ctx.needs_input_grad) and strides[2] == 0 and K <= 16 and save_activations(K)
+        # (`train` comes from the caller: INSIDE a Function's forward torch.is_grad_enabled() is always False, and
+        #  ctx.needs_input_grad reports the parameters' requires_grad even under no_grad)
+        train = bool(train) and strides[2] == 0 and K <= 16 and save_activations(K)
         if train:
+            CALLS["forward_train"] += 1
             saved = torch.empty(L.fs_cost_volume_saved_bytes(B, C, h, w, D), dtype=torch.uint8, device=dev)
             _lib.check(L.fs_cost_volume_forward_train(B, K, C, h, w, D, p(cur_feats), p(src_feats), p(src_extrinsics),
                                                       p(src_Ks), p(cur_invK), p(planes), strides[0], strides[1], strides[2],
@@ -137,7 +142,7 @@ class _CostVolumeFn(torch.autograd.Function):
                                                  p(d_w2), p(d_b2), p(d_w3), p(d_b3), _lib.current_stream()),
                        "fs_cost_volume_backward")
         # (every gradient, the MLP's included, comes out of the one kernel: no per-point workspace, no GEMMs here)
-        return d_cur, d_src, None, None, None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, None
+        return d_cur, d_src, None, None, None, None, None, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, None, None
 
 
 def _dev32(t: Tensor, name: str) -> Tensor:
@@ -212,9 +217,11 @@ class AVGFeatureVolumeManager(nn.Module):
         # channels_last feature maps ARE the pixel-major records the K >= 2 sweep gathers from: an inference call reads them in
         # place (fs_cost_volume_forward_layout) instead of paying a re-layout pass per map -- 425 of the 755 MB a 10-view K = 8 call
         # moves.  With autograd on, the maps go through .contiguous() as before (the backward takes [C, h, w] maps).
+        # a backward can follow this call: grad mode on (read HERE, outside the autograd Function) and something requires grad
+        train = torch.is_grad_enabled() and (cur_feats.requires_grad or src_feats.requires_grad
+                                             or any(q.requires_grad for q in self.mlp.parameters()))
         layout = 0
-        if not (torch.is_grad_enabled() and (cur_feats.requires_grad or src_feats.requires_grad
-                                             or any(q.requires_grad for q in self.mlp.parameters()))):
+        if not train:
             layout = ((1 if _pixel_major(cur_feats) else 0) | (2 if _pixel_major(src_feats) else 0))
         if layout:
             cf = cur_feats if layout & 1 else _dev32(cur_feats, "cur_feats")
@@ -225,7 +232,7 @@ class AVGFeatureVolumeManager(nn.Module):
         return _CostVolumeFn.apply(_dev32(cur_feats, "cur_feats"), _dev32(src_feats, "src_feats"),
                                    _dev32(src_extrinsics, "src_extrinsics"), _dev32(src_Ks, "src_Ks"),
                                    _dev32(cur_invK, "cur_invK"), flat, strides, net[0].weight, net[0].bias,
-                                   net[2].weight, net[2].bias, net[4].weight, net[4].bias)
+                                   net[2].weight, net[2].bias, net[4].weight, net[4].bias, 0, train)
 
 
 def sharded_cost_volume(manager, local_feats: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,

@@ -474,3 +474,30 @@ def test_depth_planes_kernel_is_bitwise_generate_depth_planes(hip_device, D, nea
         dev = m.generate_depth_planes(2, kw["min_depth"], kw["max_depth"])
     assert got.shape == cpu.shape == (2, D, h4, w4) and torch.equal(got.cpu(), cpu)
     assert ((got - dev).abs() <= 1.2e-7 * dev.abs()).all()
+
+
+@pytest.mark.gpu
+def test_saved_activation_forward_runs_only_when_a_backward_can_follow(hip_device, monkeypatch):
+    """The activation-keeping forward (fs_cost_volume_forward_train) is taken from K = 4 sources up when a backward can follow
+    -- decided in the module's forward, in the caller's grad mode -- and never under no_grad (rounds 4 - 5 tested
+    torch.is_grad_enabled() inside the autograd Function, where it is always False: the path was dead; ctx.needs_input_grad
+    alone would have saved 3 GB per inference call, it reports the parameters even under no_grad)."""
+    import inputs
+    from freesplat_amd import cost_volume as CV
+    monkeypatch.delenv("FREESPLAT_CV_SAVE", raising=False)
+    V, K, h4, w4, D, C = 5, 4, 24, 32, 16, 48
+    torch.manual_seed(1)
+    m = CV.AVGFeatureVolumeManager(h4, w4, num_depth_bins=D, mlp_channels=[202, 32, 32, 1], matching_dim_size=C).to(hip_device)
+    a = {k: v.to(hip_device) for k, v in inputs.cv_inputs(V, K, h4, w4, C, seed=3).items()}
+    n0 = CV.CALLS["forward_train"]
+    with torch.no_grad():
+        ref = m(**a)
+    assert CV.CALLS["forward_train"] == n0                       # inference: the plain forward
+    out = m(**a)                                                  # grad mode on, the MLP's parameters require grad
+    assert CV.CALLS["forward_train"] == n0 + 1
+    assert torch.equal(out.detach(), ref)                         # same volume either way
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    a2 = {k: (v[:, :2].contiguous() if k.startswith("src_") else v) for k, v in a.items()}    # K = 2: recomputing form
+    m(**a2)
+    assert CV.CALLS["forward_train"] == n0 + 1
