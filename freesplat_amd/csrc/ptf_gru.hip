@@ -45,8 +45,10 @@ static_assert(kFwdUsed == 696 && kBias == 704, "operand table layout");
 
 // The ring: G = this wavefront's rows of the chunk after the current one.  FS_AOP(pos) = operand row `pos` of the stream
 // (pos a compile-time constant after unrolling; the switch to a new chunk folds away everywhere else).
-#define FS_RING_SETUP(STREAM, NCHUNKS)                                                                                   \
+#define FS_RING_SETUP(STREAM, NCHUNKS, TOTAL, LA)                                                                        \
     __shared__ float s_ring[2 * kCh * 64];                                                                               \
+    constexpr int kRingTotal = (TOTAL), kRingLA = (LA);                                                                  \
+    float Q[8];   /* LA > 0: operand rows pos .. pos + LA - 1 already read (slot pos % 8) */                            \
     float G[kCh / 4];                                                                                                    \
     auto load_chunk = [&](int c) {                                                                                       \
         _Pragma("unroll") for (int j = 0; j < kCh / 4; ++j)                                                              \
@@ -58,9 +60,18 @@ static_assert(kFwdUsed == 696 && kBias == 704, "operand table layout");
         if (c + 1 < (NCHUNKS)) load_chunk(c + 1);                                                                        \
         __syncthreads();                                                                                                 \
     };                                                                                                                   \
-    load_chunk(0);
-#define FS_AOP(pos) (((pos) % kCh == 0 ? switch_chunk((pos) / kCh) : (void)0), \
-                     s_ring[((((pos) / kCh) & 1) * kCh + (pos) % kCh) * 64 + lane])
+    load_chunk(0);                                                                                                       \
+    _Pragma("unroll") for (int q_ = 0; q_ < kRingLA; ++q_) FS_RING_FETCH(q_);
+// row `pos` of the stream from the ring (switching to its chunk first where a chunk starts)
+#define FS_RING_ROW(pos) (((pos) % kCh == 0 ? switch_chunk((pos) / kCh) : (void)0), \
+                          s_ring[((((pos) / kCh) & 1) * kCh + (pos) % kCh) * 64 + lane])
+#define FS_RING_FETCH(pos) ((pos) < kRingTotal ? (void)(Q[(pos) & 7] = FS_RING_ROW(pos)) : (void)0)
+// The operand of MFMA `pos`.  LA = 0: read where it is used (the forward: two wavefronts per SIMD hide the LDS round trip).  LA > 0
+// (the backward: ONE wavefront per SIMD): row pos + LA is read HERE, LA MFMAs ahead of its use, and a scheduling barrier keeps
+// the read in front of this MFMA -- left alone the scheduler issues a ds_read at most two MFMAs before its use and the single
+// wavefront waits out the LDS round trip in front of every other MFMA pair.  The stream is consumed strictly in order.
+#define FS_AOP(pos) (kRingLA == 0 ? FS_RING_ROW(pos) \
+                                  : (FS_RING_FETCH((pos) + kRingLA), __builtin_amdgcn_sched_barrier(0), Q[(pos) & 7]))
 
 // gates on the hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp each; |error| of a gate ~2e-7, the fold's bar is
 // 1e-4): the libm forms are ~30 VALU instructions each, 96 per lane and 32 pairs, and fp32 VALU work does not overlap
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int t = grp * 32 + p;
     const bool live = t < n;
     FS_BIAS_SETUP(tab)
-    FS_RING_SETUP(tab, kFwdChunks)
+    FS_RING_SETUP(tab, kFwdChunks, kFwdUsed, 0)
     // sources of this pair: `row` = a materialised row, or (GATHER) the state latent / the view latent
     const float* row = GATHER ? nullptr : cat + (size_t)(live ? t : 0) * 176;
     const long long gm = GATHER ? ga.fuse_idx[live ? t : 0] : 0, gp = GATHER ? ga.fuse_pix[live ? t : 0] : 0;
@@ -288,6 +299,9 @@ __device__ __forceinline__ void store_acc(float* __restrict__ dst, int hf, const
         *(float4*)(dst + 8 * g4 + 4 * hf) = make_float4(a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]);
 }
 
+#ifndef FS_GRU_BWD_LA
+#define FS_GRU_BWD_LA 4    // operand rows read this many MFMAs ahead in the backward (0: A/B, the scheduler's own placement)
+#endif
 #ifdef FS_GRU_BWD_WAVES    // (A/B builds: make VARIANT=gru2 EXTRA=-DFS_GRU_BWD_WAVES=2 -- 256 registers, ~155 values through scratch)
 #define FS_GRU_BWD_OCC __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD_WAVES, FS_GRU_BWD_WAVES)))
 #else
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(256) FS_GRU_BWD_OCC void ptf_gru_bwd_kernel(int n, 
     const bool live = t < n;             // (a wavefront beyond n stays for the barriers, computes on row 0, stores nothing)
     const size_t tr = (size_t)(live ? t : 0);
     FS_BIAS_SETUP(tab)
-    FS_RING_SETUP(stream, kStreamChunks)
+    FS_RING_SETUP(stream, kStreamChunks, kStreamUsed, FS_GRU_BWD_LA)
     const float* row = cat + tr * 176;
     float* sd = side + tr * kSide;       // (dead pairs compute on row 0 and store nothing)
 
