@@ -1867,7 +1867,14 @@ __device__ unsigned long long g_sg_stats[8];   // [3] whole-image fallbacks, [4]
 // next 64 pixels are issued before the taps of the current 64 are added.
 // NAT: the records (and the current map of the rare path) are in natural channel order -- cost_volume16_bwd_kernel's -- instead of
 // the 32-pixel kernel's [parity][C/2] order.
-template <int C, bool NAT>
+// FORM 1 (round 6): the tile's gradient lives in REGISTERS -- lane = texel of the 8 x 8 tile, C accumulators each -- and a batch's taps
+// reach it through LDS once instead of four read-modify-writes: every pixel lane writes its record to a staging row (C/4
+// ds_write_b128) and appends (pixel lane, weight) to the list of each texel its taps cover (a ds_add_rtn_u32 slot counter per
+// texel, kSgCap entries; a tap that finds its texel's list full goes round again), then every texel lane walks its list and blends
+// the staged records it names (C/4 ds_read_b128 per entry).  No claim rounds, no accumulator writes: per 64 visited pixels
+// 12 b128 writes + ~4.5 x 12 b128 reads instead of 48 + 48 (a ds_write_b128 costs 13 LDS cycles, a read 4).
+constexpr int kSgCap = 8;
+template <int C, bool NAT, int FORM>
 __global__ __launch_bounds__(64) void cv_src_grad_kernel(
     int B, int K, int h, int w, int D, int chunks, int tiles_x, int tiles_y, const float* __restrict__ curT,
     const float4* __restrict__ recS, const float2* __restrict__ recM, const float* __restrict__ Pmat,
@@ -1876,8 +1883,11 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
 {
     constexpr int TW = kSgTW, TH = kSgTH, NT = TW * TH, NV = C / 4, ST = C + 4, HC = C / 2, G = kSgG;
     constexpr int kClaim = (TW + 1) * (TH + 1) + 3;   // bases (lx, ly) in [-1, TW - 1] x [-1, TH - 1]
-    __shared__ __attribute__((aligned(16))) float acc[NT * ST];
-    __shared__ uint32_t claim_[kClaim];
+    static_assert(FORM == 0 || NT == 64, "the register form keeps one texel per lane");
+    __shared__ __attribute__((aligned(16))) float acc[NT * ST];          // FORM 0: the accumulators; FORM 1: the batch's staged records
+    __shared__ uint32_t claim_[FORM == 0 ? kClaim : 64];                 // FORM 1: entries in each texel's list
+    __shared__ uint2 lst_[FORM == 0 ? 1 : 64 * kSgCap];                  // FORM 1: (pixel lane, weight bits)
+    float4 accr[NV];                                                     // FORM 1: this lane's texel
     const int hw = h * w, T = tiles_x * tiles_y;
     // XCD x (= workgroup id % 8) owns the x-th contiguous range of tiles of every view: the workgroups in flight on an XCD
     // -- the same tiles of all K sources, which read the same records -- share one L2
@@ -1891,7 +1901,13 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int tw_ = min(TW, w - tx0), th_ = min(TH, h - ty0);
     const int lane = threadIdx.x;
-    for (int e = lane; e < NT * ST / 4; e += 64) ((float4*)acc)[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (FORM == 0) {
+        for (int e = lane; e < NT * ST / 4; e += 64) ((float4*)acc)[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+        claim_[lane] = 0u;
+#pragma unroll
+        for (int s = 0; s < NV; ++s) accr[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     wave_lds_sync();
     volatile uint32_t* const claim = claim_;
     const float* P = Pmat + ((size_t)b * K + k) * 12;
@@ -2036,6 +2052,49 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
         };
         // ---- the adds: claim rounds, then four taps of C/4 float4 read-modify-writes ----
         auto process = [&](const Geo& ge, const float4 (&S)[NV]) __attribute__((always_inline)) {
+            if (FORM == 1) {
+                if (__builtin_amdgcn_ballot_w64(ge.pend) == 0ull) return;
+                if (ge.pend) {
+#pragma unroll
+                    for (int s = 0; s < NV; ++s) ((float4*)(acc + lane * ST))[s] = S[s];
+                }
+                uint32_t todo = ge.pend ? ge.okm : 0u;
+                do {
+#pragma unroll
+                    for (int tap = 0; tap < 4; ++tap) {
+                        const int ox = tap & 1, oy = tap >> 1;
+                        if (todo & (1u << tap)) {
+                            const int tt = ge.t00 + oy * TW + ox;
+                            const uint32_t slot = atomicAdd(&claim_[tt], 1u);
+                            if (slot < (uint32_t)kSgCap) {
+                                const float wt = (ox ? ge.tx : 1.0f - ge.tx) * (oy ? ge.ty : 1.0f - ge.ty);
+                                lst_[tt * kSgCap + slot] = make_uint2((uint32_t)lane, __float_as_uint(wt));
+                                todo &= ~(1u << tap);
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                    const int nl = (int)min(claim[lane], (uint32_t)kSgCap);
+#pragma unroll 1
+                    for (int e = 0; e < kSgCap; ++e) {
+                        if (__builtin_amdgcn_ballot_w64(e < nl) == 0ull) break;
+                        if (e < nl) {
+                            const uint2 en = lst_[lane * kSgCap + e];
+                            const float wt = __uint_as_float(en.y);
+                            const float4* sp = (const float4*)(acc + en.x * ST);
+#pragma unroll
+                            for (int s = 0; s < NV; ++s) {
+                                const float4 v = sp[s];
+                                accr[s].x = fmaf(wt, v.x, accr[s].x); accr[s].y = fmaf(wt, v.y, accr[s].y);
+                                accr[s].z = fmaf(wt, v.z, accr[s].z); accr[s].w = fmaf(wt, v.w, accr[s].w);
+                            }
+                        }
+                    }
+                    claim[lane] = 0u;
+                    wave_lds_sync();
+                } while (__builtin_amdgcn_ballot_w64(todo != 0u) != 0ull);
+                return;
+            }
             bool pend = ge.pend;
             while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
 #ifdef FS_CV_SG_STATS
@@ -2088,7 +2147,7 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
         float* const dpx = dmap + (size_t)(ty0 + ty) * w + (tx0 + tx);
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
-            const float4 v = ((const float4*)(acc + (lane < NT ? lane : 0) * ST))[s];
+            const float4 v = FORM == 1 ? accr[s] : ((const float4*)(acc + (lane < NT ? lane : 0) * ST))[s];
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -2390,6 +2449,8 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
                            (long long)plane_stride_d, (long long)plane_stride_pix, w1, b1, w2, b2, w3, grad_out,
                            d_curT, d_srcT, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, recS, recM);
     };
+    // pass 2's form: 1 = register accumulators fed through per-texel lists (round 6), 0 = LDS read-modify-writes behind claim rounds
+    static const int sg_form = [] { const char* e = getenv("FS_CV_SG_FORM"); return e ? atoi(e) : 1; }() && kSgTW * kSgTH == 64 ? 1 : 0;
     auto tile_sweep = [&](auto kernel) {
         const unsigned grid = 8u * (unsigned)B * (unsigned)((tiles + 7) >> 3) * (unsigned)K * (unsigned)chunks;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, st, B, K, h, w, D, chunks, tiles_x, tiles_y, curT,
@@ -2404,18 +2465,18 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
     if (bwd16) {
         if (C == 48) {
             if (saved) sweep16(cost_volume16_bwd_kernel<48, true>); else sweep16(cost_volume16_bwd_kernel<48, false>);
-            tile_sweep(cv_src_grad_kernel<48, true>);
+            if (sg_form) tile_sweep(cv_src_grad_kernel<48, true, 1>); else tile_sweep(cv_src_grad_kernel<48, true, 0>);
         } else {
             if (saved) sweep16(cost_volume16_bwd_kernel<16, true>); else sweep16(cost_volume16_bwd_kernel<16, false>);
-            tile_sweep(cv_src_grad_kernel<16, true>);
+            if (sg_form) tile_sweep(cv_src_grad_kernel<16, true, 1>); else tile_sweep(cv_src_grad_kernel<16, true, 0>);
         }
     } else if (two_pass) {
         if (C == 48) {
             sweep(cost_volume_bwd_kernel<24, true>);
-            tile_sweep(cv_src_grad_kernel<48, false>);
+            tile_sweep(cv_src_grad_kernel<48, false, 0>);
         } else {
             sweep(cost_volume_bwd_kernel<8, true>);
-            tile_sweep(cv_src_grad_kernel<16, false>);
+            tile_sweep(cv_src_grad_kernel<16, false, 0>);
         }
     } else {
         if (C == 48) sweep(cost_volume_bwd_kernel<24, false>); else sweep(cost_volume_bwd_kernel<8, false>);
