@@ -1873,7 +1873,10 @@ __device__ unsigned long long g_sg_stats[8];   // [3] whole-image fallbacks, [4]
 // texel, kSgCap entries; a tap that finds its texel's list full goes round again), then every texel lane walks its list and blends
 // the staged records it names (C/4 ds_read_b128 per entry).  No claim rounds, no accumulator writes: per 64 visited pixels
 // 12 b128 writes + ~4.5 x 12 b128 reads instead of 48 + 48 (a ds_write_b128 costs 13 LDS cycles, a read 4).
-constexpr int kSgCap = 8;
+#ifndef FS_SG_CAP
+#define FS_SG_CAP 8
+#endif
+constexpr int kSgCap = FS_SG_CAP;
 template <int C, bool NAT, int FORM>
 __global__ __launch_bounds__(64) void cv_src_grad_kernel(
     int B, int K, int h, int w, int D, int chunks, int tiles_x, int tiles_y, const float* __restrict__ curT,
@@ -2050,51 +2053,59 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
             }
 #endif
         };
-        // ---- the adds: claim rounds, then four taps of C/4 float4 read-modify-writes ----
-        auto process = [&](const Geo& ge, const float4 (&S)[NV]) __attribute__((always_inline)) {
-            if (FORM == 1) {
-                if (__builtin_amdgcn_ballot_w64(ge.pend) == 0ull) return;
-                if (ge.pend) {
+        // ---- FORM 1: records to the staging rows, taps to their texels' lists; then every texel lane blends its list ----
+        struct Taps { int t00; float tx, ty; uint32_t todo; };
+        auto place_taps = [&](Taps& tp) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int s = 0; s < NV; ++s) ((float4*)(acc + lane * ST))[s] = S[s];
+            for (int tap = 0; tap < 4; ++tap) {
+                const int ox = tap & 1, oy = tap >> 1;
+                if (tp.todo & (1u << tap)) {
+                    const int tt = tp.t00 + oy * TW + ox;
+                    const uint32_t slot = atomicAdd(&claim_[tt], 1u);
+                    if (slot < (uint32_t)kSgCap) {
+                        const float wt = (ox ? tp.tx : 1.0f - tp.tx) * (oy ? tp.ty : 1.0f - tp.ty);
+                        lst_[tt * kSgCap + slot] = make_uint2((uint32_t)lane, __float_as_uint(wt));
+                        tp.todo &= ~(1u << tap);
+                    }
                 }
-                uint32_t todo = ge.pend ? ge.okm : 0u;
-                do {
-#pragma unroll
-                    for (int tap = 0; tap < 4; ++tap) {
-                        const int ox = tap & 1, oy = tap >> 1;
-                        if (todo & (1u << tap)) {
-                            const int tt = ge.t00 + oy * TW + ox;
-                            const uint32_t slot = atomicAdd(&claim_[tt], 1u);
-                            if (slot < (uint32_t)kSgCap) {
-                                const float wt = (ox ? ge.tx : 1.0f - ge.tx) * (oy ? ge.ty : 1.0f - ge.ty);
-                                lst_[tt * kSgCap + slot] = make_uint2((uint32_t)lane, __float_as_uint(wt));
-                                todo &= ~(1u << tap);
-                            }
-                        }
-                    }
-                    wave_lds_sync();
-                    const int nl = (int)min(claim[lane], (uint32_t)kSgCap);
-#pragma unroll 1
-                    for (int e = 0; e < kSgCap; ++e) {
-                        if (__builtin_amdgcn_ballot_w64(e < nl) == 0ull) break;
-                        if (e < nl) {
-                            const uint2 en = lst_[lane * kSgCap + e];
-                            const float wt = __uint_as_float(en.y);
-                            const float4* sp = (const float4*)(acc + en.x * ST);
-#pragma unroll
-                            for (int s = 0; s < NV; ++s) {
-                                const float4 v = sp[s];
-                                accr[s].x = fmaf(wt, v.x, accr[s].x); accr[s].y = fmaf(wt, v.y, accr[s].y);
-                                accr[s].z = fmaf(wt, v.z, accr[s].z); accr[s].w = fmaf(wt, v.w, accr[s].w);
-                            }
-                        }
-                    }
-                    claim[lane] = 0u;
-                    wave_lds_sync();
-                } while (__builtin_amdgcn_ballot_w64(todo != 0u) != 0ull);
-                return;
             }
+        };
+        auto put_records = [&](const Geo& ge, const float4 (&S)[NV]) __attribute__((always_inline)) -> Taps {
+            if (ge.pend) {
+#pragma unroll
+                for (int s = 0; s < NV; ++s) ((float4*)(acc + lane * ST))[s] = S[s];
+            }
+            Taps tp{ge.t00, ge.tx, ge.ty, ge.pend ? ge.okm : 0u};
+            place_taps(tp);
+            return tp;
+        };
+        auto blend_lists = [&](Taps tp) __attribute__((always_inline)) {
+            for (;;) {
+                wave_lds_sync();
+                const int nl = (int)min(claim[lane], (uint32_t)kSgCap);
+#pragma unroll 1
+                for (int e = 0; e < kSgCap; ++e) {
+                    if (__builtin_amdgcn_ballot_w64(e < nl) == 0ull) break;
+                    if (e < nl) {
+                        const uint2 en = lst_[lane * kSgCap + e];
+                        const float wt = __uint_as_float(en.y);
+                        const float4* sp = (const float4*)(acc + en.x * ST);
+#pragma unroll
+                        for (int s = 0; s < NV; ++s) {
+                            const float4 v = sp[s];
+                            accr[s].x = fmaf(wt, v.x, accr[s].x); accr[s].y = fmaf(wt, v.y, accr[s].y);
+                            accr[s].z = fmaf(wt, v.z, accr[s].z); accr[s].w = fmaf(wt, v.w, accr[s].w);
+                        }
+                    }
+                }
+                claim[lane] = 0u;
+                wave_lds_sync();
+                if (__builtin_amdgcn_ballot_w64(tp.todo != 0u) == 0ull) break;
+                place_taps(tp);          // (taps that found their texel's list full: the staged records are still there)
+            }
+        };
+        // ---- FORM 0: the adds: claim rounds, then four taps of C/4 float4 read-modify-writes ----
+        auto process = [&](const Geo& ge, const float4 (&S)[NV]) __attribute__((always_inline)) {
             bool pend = ge.pend;
             while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
 #ifdef FS_CV_SG_STATS
@@ -2126,6 +2137,19 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
                 pend = pend && !win;
             }
         };
+        if constexpr (FORM == 1) {
+            // one record buffer: the next batch's loads are issued as soon as this batch's records sit in their staging rows, and
+            // are in flight while the lists are blended (a second register buffer costs the third wavefront per SIMD: 3.0 vs 2.8 ms)
+            Geo gA;
+            float4 SA[NV];
+            stage(0, gA, SA);
+            for (int i0 = 0; i0 < N; i0 += 64) {
+                const Taps tp = put_records(gA, SA);
+                if (i0 + 64 < N) stage(i0 + 64, gA, SA);
+                blend_lists(tp);
+            }
+            continue;
+        } else {
         Geo gA, gB;
         float4 SA[NV], SB[NV];
         stage(0, gA, SA);
@@ -2136,6 +2160,7 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
             if (!moreB) break;
             if (i0 + 128 < N) stage(i0 + 128, gA, SA);
             process(gB, SB);
+        }
         }
     }
     wave_lds_sync();
