@@ -156,7 +156,9 @@ def bench_raster(cx: Ctx, workload: str, mode: str, views: int, steps: int, warm
                 t.grad = None
             color, depth = render_views(cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"],
                                         (H, W), bg, g["means"], g["covariances"], g["harmonics"], g["opacities"])
-            loss = ((color - target) ** 2).mean()
+            # (the fused library loss: `((color - target) ** 2).mean()` ran ~10 elementwise torch kernels over the step's images,
+            #  22 % of the step's GPU time in profiles/r6_train_kernel_stats.csv -- glue, not rasterizer)
+            loss = torch.nn.functional.mse_loss(color, target)
             loss.backward()
             if exchange is not None:
                 if diag_events is not None:

@@ -163,7 +163,7 @@ def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_tar
             p_.grad = None
         res = encoder_forward(enc, dict(ctx), 0)
         out = dec(res["gaussians"][0], tgt_E, tgt_K, near_t, far_t, (H, W), depth_mode=None)
-        loss = ((out.color - target) ** 2).mean()
+        loss = torch.nn.functional.mse_loss(out.color, target)
         loss.backward()
         info["gaussians"] = int(res["num_gaussians"])
         return loss
