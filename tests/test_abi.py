@@ -215,15 +215,15 @@ def test_traffic_lookup_refuses_kernels_the_library_no_longer_contains():
 
 
 def test_committed_bench_line_honours_the_contract():
-    """The tracked copy of the bench output of the final code (profiles/r5_bench.json = the FULL sectioned line,
-    profiles/r5_bench_headline.json = the compact LAST line the driver parses; both written by `python bench.py` on the GPU box):
+    """The tracked copy of the bench output of the final code (profiles/r6_bench.json = the FULL sectioned line,
+    profiles/r6_bench_headline.json = the compact LAST line the driver parses; both written by `python bench.py` on the GPU box):
     every key the bench contract names, the roofline / cpu_baseline objects, BASELINE.json's workload, the sub-objects the
     documentation cites, and the compact line's size."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r5_bench.json")))
-    raw = open(os.path.join(root, "profiles", "r5_bench_headline.json")).read().strip()
+    d = json.load(open(os.path.join(root, "profiles", "r6_bench.json")))
+    raw = open(os.path.join(root, "profiles", "r6_bench_headline.json")).read().strip()
     hl = json.loads(raw)
     assert len(raw) <= 4096 and "\n" not in raw                              # VERDICT r4 item 1: the driver parsed nothing of 28 KB
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -249,7 +249,7 @@ def test_committed_bench_line_honours_the_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "oracle/raster_oracle.c" in c["sample"]
     assert d["parity"]["bit_exact"] is True and d["parity"]["pixels_above_1e-4"] == 0
     # the sub-objects: training step, config 2, fp16 SH, the close-up workload, the three cost-volume shapes, four folds
-    assert d["train"]["value"] > 1000 and d["train"]["roofline"]["kernel"] == "render_bwd_kernel"
+    assert d["train"]["value"] > 1200 and d["value"] > 4200 and d["train"]["roofline"]["kernel"] == "render_bwd_kernel"
     assert d["c2"]["config"]["workload"].startswith("c2") and d["c3_fp16_sh"]["config"]["sh_storage"] == "fp16"
     assert d["c3_fp16_sh"]["parity"]["bit_exact"] is True
     cu = d["c3_closeup"]        # every tile list beyond the LDS sort; bit-exact; per list entry no slower than the headline
@@ -262,8 +262,8 @@ def test_committed_bench_line_honours_the_contract():
         assert v["roofline"]["bound"] == "mfma" and b["bound"] == "mfma" and b["global_float_atomics_on_source_maps"] == 0, name
         assert abs(b["algorithmic_flops_per_launch"] - 2 * v["roofline"]["algorithmic_flops_per_launch"]) < 1, name
         assert "cpu_baseline" in v and "parity" in v and v["roofline"]["traffic"] is not None and b["traffic"] is not None, name
-    assert cv["fvt10_96x128_K8"]["train_fwd_bwd"]["ms"] <= 25 and cv["c3scale_242x324_K2"]["train_fwd_bwd"]["ms"] <= 14
-    assert cv["native_96x128_K1"]["train_fwd_bwd"]["ms"] <= 1.3
+    assert cv["fvt10_96x128_K8"]["train_fwd_bwd"]["ms"] <= 14.5 and cv["c3scale_242x324_K2"]["train_fwd_bwd"]["ms"] <= 13.2   # (round 5: 16.7 / 13.2)
+    assert cv["native_96x128_K1"]["train_fwd_bwd"]["ms"] <= 1.25
     assert set(d["ptf"]) == {"fold_2_views", "fold_10_views", "fold_3_views_968x1296", "fold_30_views"}
     for name, v in d["ptf"].items():
         assert v["parity"]["same_count_and_order"] is True and v["roofline"]["bound"] == "hbm" and v["cpu_baseline"]["cores"] <= 16, name
@@ -297,7 +297,7 @@ def test_compact_headline_fits_the_driver_window():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    full = json.load(open(os.path.join(root, "profiles", "r5_bench.json")))
+    full = json.load(open(os.path.join(root, "profiles", "r6_bench.json")))
     h = bench.headline(full)
     line = json.dumps(h)
     assert len(line) <= bench.HEADLINE_MAX_BYTES <= 8192
