@@ -33,6 +33,10 @@
 
 #include "fs_common.h"
 
+#ifndef FS_REC_PIXEL_MAJOR
+#define FS_REC_PIXEL_MAJOR 1     // records of the 16-pixel backward pass 1: [view, plane][pixel][C/4 float4 chunks] (0, A/B: chunk-planar)
+#endif
+
 namespace fs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1627,11 +1631,17 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const float di = ddot * inv;
             if (live_m) {
                 const size_t pl = (size_t)b * D + d;
+#if FS_REC_PIXEL_MAJOR
+                // pixel-major records ([view, plane][pixel][C/4 chunks]: 4 C contiguous bytes per point): pass 2 reads the pixels of
+                // a ~10-pixel-wide box row by row, and with chunk-planar records a row was 160 useful bytes of every 256 fetched
+                float4* rp = recS + (pl * hw + pix_m) * (C / 4) + g;
+#else
                 float4* rp = recS + (pl * (C / 4) + g) * hw + pix_m;
+#endif
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
                     const float4 cv = cv4[rb];
-                    rp[(size_t)(4 * rb) * hw] = make_float4(fmaf(di, cv.x, dx[rb][0] * inv), fmaf(di, cv.y, dx[rb][1] * inv),
+                    rp[FS_REC_PIXEL_MAJOR ? (size_t)(4 * rb) : (size_t)(4 * rb) * hw] = make_float4(fmaf(di, cv.x, dx[rb][0] * inv), fmaf(di, cv.y, dx[rb][1] * inv),
                                                             fmaf(di, cv.z, dx[rb][2] * inv), fmaf(di, cv.w, dx[rb][3] * inv));
                 }
                 if (g == 0) recM[pl * hw + pix_m] = make_float2(di, __uint_as_float(flags_m));
@@ -2032,9 +2042,10 @@ __global__ __launch_bounds__(64) void cv_src_grad_kernel(
                 const float2 mt = recM[pl * hw + pix];
                 const uint32_t fl = __float_as_uint(mt.y) >> kbit;
                 pend = (fl & 2u) != 0u;                       // (the first pass's own z_k > 0)
-                const float4* sp = recS + pl * NV * hw + pix;
+                const bool pm = NAT && FS_REC_PIXEL_MAJOR;     // (the 16-pixel pass 1's records are pixel-major)
+                const float4* sp = pm ? recS + (pl * hw + pix) * NV : recS + pl * NV * hw + pix;
 #pragma unroll
-                for (int s = 0; s < NV; ++s) S[s] = sp[(size_t)s * hw];
+                for (int s = 0; s < NV; ++s) S[s] = sp[pm ? (size_t)s : (size_t)s * hw];
                 if (pend && !(fl & 1u)) {
                     // in front, not averaged (an exactly zero score): only d dot / cnt * cur reaches this source
                     const float4* c4 = (const float4*)(curT + ((size_t)b * hw + pix) * C);
