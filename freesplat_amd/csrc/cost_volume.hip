@@ -33,6 +33,9 @@
 
 #include "fs_common.h"
 
+#ifndef FS_BWD16_SAVED_PREFETCH
+#define FS_BWD16_SAVED_PREFETCH 1
+#endif
 #ifndef FS_REC_PIXEL_MAJOR
 #define FS_REC_PIXEL_MAJOR 1     // records of the 16-pixel backward pass 1: [view, plane][pixel][C/4 float4 chunks] (0, A/B: chunk-planar)
 #endif
@@ -1341,6 +1344,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const float* const gp = g_out + (size_t)b * D * hw + (live_m ? pix_m : 0);
         float go_next = (d0 < d1 && live_m) ? gp[(size_t)d0 * hw] : 0.0f;
         float depth_next = planes[b * ps_b + min(d0, D - 1) * ps_d];     // (two-pass form: one depth per plane, wave-uniform; one plane ahead)
+        // SAVED: the kept inputs of the NEXT plane are loaded while this plane's matrix part runs (both wavefronts of a SIMD otherwise
+        // wait for them together at the top of every plane)
+        float4 xs_next[RB];
+        float2 xm_next = make_float2(0.0f, 0.0f);
+        auto load_saved = [&](int dd) __attribute__((always_inline)) {
+            const size_t pl = (size_t)b * D + min(dd, D - 1);
+            xm_next = live_m ? xm[pl * hw + pix_m] : make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                xs_next[rb] = live_m ? xs[(pl * (C / 4) + 4 * rb + g) * hw + pix_m] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        };
+        if (SAVED) load_saved(d0);
 
         for (int d = d0; d < d1; ++d) {
             const float depth = depth_next;
@@ -1348,6 +1363,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             FS_CV_T(tq0, depth);
             const float go = go_next;
             go_next = live_m ? gp[(size_t)min(d + 1, d1 - 1) * hw] : 0.0f;
+#if !FS_BWD16_SAVED_PREFETCH
+            if (SAVED && d > d0) load_saved(d);
+#endif
             // ---------------- forward recompute: gather (the forward sweep's code, plus the backward's bits) ----------------
             float favg[NR];
 #pragma unroll
@@ -1487,15 +1505,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             float dot_m;
             if (SAVED) {
                 // from the training forward: lane (n, g)'s operand-order x is chunk 4 rb + g of the point, one float4 per block
-                const size_t pl = (size_t)b * D + d;
-                const float2 mt = live_m ? xm[pl * hw + pix_m] : make_float2(0.0f, 0.0f);
-                dot_m = mt.x;
-                flags_m = __float_as_uint(mt.y);
+                dot_m = xm_next.x;
+                flags_m = __float_as_uint(xm_next.y);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    const float4 v4 = live_m ? xs[(pl * (C / 4) + 4 * rb + g) * hw + pix_m] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const float4 v4 = xs_next[rb];
                     xop[4 * rb] = v4.x; xop[4 * rb + 1] = v4.y; xop[4 * rb + 2] = v4.z; xop[4 * rb + 3] = v4.w;
                 }
+#if FS_BWD16_SAVED_PREFETCH
+                if (d + 1 < d1) load_saved(d + 1);
+#endif
 #pragma unroll
                 for (int t = 0; t < NR; ++t) tX[256 * (t >> 2) + wr_at[t & 3]] = xop[t];
                 xop[NR] = g == 0 ? dot_m : (g == 1 ? 1.0f : 0.0f);
