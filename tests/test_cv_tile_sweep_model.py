@@ -93,3 +93,48 @@ def test_tile_sweep_model_matches_oracle_autograd(V, K, h4, w4, D, behind):
     assert np.abs(d_src - want).max() <= 1e-9 * (np.abs(want).max() + 1e-30) + 1e-12
     # the walk visits little more than the pixels it needs (and, with a source behind the planes, skips its tiles)
     assert visited <= 6 * max(useful, 1) + V * K * D * 64
+
+
+def test_register_form_lists_blend_every_tap_exactly_once():
+    """Model of round 6's pass 2 (cv_src_grad_kernel<C, NAT, 1>): a batch's taps are appended to per-texel lists of 8 entries
+    (slot = the value a ds_add_rtn_u32 returns; a tap whose slot is >= 8 stays pending), every texel blends min(count, 8)
+    entries, the counters are cleared and the pending taps go round again.  Whatever the collisions, the result is the plain
+    scatter-add."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    CAP, TW, TH, C = 8, 8, 8, 6
+    for trial in range(40):
+        crowd = trial % 4 == 3                                   # every 4th trial: all pixels on a few texels (lists overflow)
+        S = rng.normal(size=(64, C)).astype(np.float32)          # the staged records
+        base_x = rng.integers(-1, 2 if crowd else TW, size=64)
+        base_y = rng.integers(-1, 2 if crowd else TH, size=64)
+        w = rng.random(size=(64, 4)).astype(np.float32)
+        taps = []                                                # (lane, tap, texel)
+        for lane in range(64):
+            for tap in range(4):
+                x, y = base_x[lane] + (tap & 1), base_y[lane] + (tap >> 1)
+                if 0 <= x < TW and 0 <= y < TH:
+                    taps.append((lane, tap, y * TW + x))
+        want = np.zeros((TW * TH, C), np.float64)
+        for lane, tap, t in taps:
+            want[t] += np.float64(w[lane, tap]) * S[lane]
+        got = np.zeros((TW * TH, C), np.float64)
+        pending, rounds = list(taps), 0
+        while pending:
+            rounds += 1
+            count = np.zeros(TW * TH, np.int64)
+            lists = [[] for _ in range(TW * TH)]
+            still = []
+            for lane, tap, t in pending:                         # (any order: the adds are atomic)
+                slot = count[t]
+                count[t] += 1
+                if slot < CAP:
+                    lists[t].append((lane, w[lane, tap]))
+                else:
+                    still.append((lane, tap, t))
+            for t in range(TW * TH):
+                for lane, wt in lists[t][:min(count[t], CAP)]:
+                    got[t] += np.float64(wt) * S[lane]
+            pending = still
+        assert np.allclose(got, want, rtol=0, atol=1e-12)
+        assert rounds >= 1 and (crowd or rounds <= 3)
