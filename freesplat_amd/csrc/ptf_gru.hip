@@ -45,33 +45,59 @@ static_assert(kFwdUsed == 696 && kBias == 704, "operand table layout");
 
 // The ring: G = this wavefront's rows of the chunk after the current one.  FS_AOP(pos) = operand row `pos` of the stream
 // (pos a compile-time constant after unrolling; the switch to a new chunk folds away everywhere else).
-#define FS_RING_SETUP(STREAM, NCHUNKS, TOTAL, LA)                                                                        \
-    __shared__ float s_ring[2 * kCh * 64];                                                                               \
+#define FS_RING_SETUP(STREAM, NCHUNKS, TOTAL, LA, QUAD)                                                                  \
+    __shared__ __attribute__((aligned(16))) float s_ring[2 * kCh * 64];                                                  \
     constexpr int kRingTotal = (TOTAL), kRingLA = (LA);                                                                  \
-    float Q[8];   /* LA > 0: operand rows pos .. pos + LA - 1 already read (slot pos % 8) */                            \
+    constexpr bool kRingQuad = (QUAD);                                                                                   \
+    float Q[8];     /* LA > 0: operand rows pos .. pos + LA - 1 already read (slot pos % 8) */                          \
+    float4 Q4[2];   /* QUAD: the quad of rows in use and the next one */                                                 \
     float G[kCh / 4];                                                                                                    \
     auto load_chunk = [&](int c) {                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < kCh / 4; ++j)                                                              \
-            G[j] = (STREAM)[(size_t)(c * kCh + wave * (kCh / 4) + j) * 64 + lane];                                       \
+        if constexpr (kRingQuad) {                                                                                       \
+            _Pragma("unroll") for (int q = 0; q < kCh / 16; ++q) {                                                       \
+                const float4 v = ((const float4*)(STREAM))[((size_t)(c * 4 + wave) * (kCh / 16) + q) * 64 + lane];       \
+                G[4 * q] = v.x; G[4 * q + 1] = v.y; G[4 * q + 2] = v.z; G[4 * q + 3] = v.w;                              \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < kCh / 4; ++j)                                                          \
+                G[j] = (STREAM)[(size_t)(c * kCh + wave * (kCh / 4) + j) * 64 + lane];                                   \
+        }                                                                                                                \
     };                                                                                                                   \
     auto switch_chunk = [&](int c) {   /* before the first operand of chunk c is read; G holds this wavefront's rows of it */ \
-        _Pragma("unroll") for (int j = 0; j < kCh / 4; ++j)                                                              \
-            s_ring[((c & 1) * kCh + wave * (kCh / 4) + j) * 64 + lane] = G[j];                                           \
+        if constexpr (kRingQuad) {                                                                                       \
+            _Pragma("unroll") for (int q = 0; q < kCh / 16; ++q)                                                         \
+                ((float4*)s_ring)[((c & 1) * (kCh / 4) + wave * (kCh / 16) + q) * 64 + lane] =                           \
+                    make_float4(G[4 * q], G[4 * q + 1], G[4 * q + 2], G[4 * q + 3]);                                     \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < kCh / 4; ++j)                                                          \
+                s_ring[((c & 1) * kCh + wave * (kCh / 4) + j) * 64 + lane] = G[j];                                       \
+        }                                                                                                                \
         if (c + 1 < (NCHUNKS)) load_chunk(c + 1);                                                                        \
         __syncthreads();                                                                                                 \
     };                                                                                                                   \
     load_chunk(0);                                                                                                       \
-    _Pragma("unroll") for (int q_ = 0; q_ < kRingLA; ++q_) FS_RING_FETCH(q_);
+    if constexpr (kRingQuad) { FS_RING_FETCH4(0); }                                                                      \
+    else { _Pragma("unroll") for (int q_ = 0; q_ < kRingLA; ++q_) FS_RING_FETCH(q_); }
 // row `pos` of the stream from the ring (switching to its chunk first where a chunk starts)
 #define FS_RING_ROW(pos) (((pos) % kCh == 0 ? switch_chunk((pos) / kCh) : (void)0), \
                           s_ring[((((pos) / kCh) & 1) * kCh + (pos) % kCh) * 64 + lane])
 #define FS_RING_FETCH(pos) ((pos) < kRingTotal ? (void)(Q[(pos) & 7] = FS_RING_ROW(pos)) : (void)0)
+// QUAD: the stream is stored interleaved -- [chunk][owner wavefront][quad of 4 rows][lane][4 rows], i.e. a lane's four consecutive
+// operand rows are ONE float4 in memory and in the ring -- so a chunk's fill is kCh/16 global_load_dwordx4 + kCh/16
+// ds_write_b128 per wavefront (instead of kCh/4 dword loads + kCh/8 ds_write2st64), and the operands of four MFMAs come
+// back with ONE ds_read_b128, issued a whole quad (four MFMAs) ahead of its first use.
+#define FS_RING_ROW4(qp) (((qp) % (kCh / 4) == 0 ? switch_chunk((qp) / (kCh / 4)) : (void)0), \
+                          ((const float4*)s_ring)[((((qp) / (kCh / 4)) & 1) * (kCh / 4) + (qp) % (kCh / 4)) * 64 + lane])
+#define FS_RING_FETCH4(qp) ((qp) * 4 < kRingTotal ? (void)(Q4[(qp) & 1] = FS_RING_ROW4(qp)) : (void)0)
+#define FS_Q4_COMP(v, e) ((e) == 0 ? (v).x : ((e) == 1 ? (v).y : ((e) == 2 ? (v).z : (v).w)))
 // The operand of MFMA `pos`.  LA = 0: read where it is used (the forward: two wavefronts per SIMD hide the LDS round trip).  LA > 0
 // (the backward: ONE wavefront per SIMD): row pos + LA is read HERE, LA MFMAs ahead of its use, and a scheduling barrier keeps
 // the read in front of this MFMA -- left alone the scheduler issues a ds_read at most two MFMAs before its use and the single
 // wavefront waits out the LDS round trip in front of every other MFMA pair.  The stream is consumed strictly in order.
-#define FS_AOP(pos) (kRingLA == 0 ? FS_RING_ROW(pos) \
-                                  : (FS_RING_FETCH((pos) + kRingLA), __builtin_amdgcn_sched_barrier(0), Q[(pos) & 7]))
+#define FS_AOP(pos) (kRingQuad ? ((((pos) & 3) == 0 ? (FS_RING_FETCH4((pos) / 4 + 1), __builtin_amdgcn_sched_barrier(0)) : (void)0), \
+                                  FS_Q4_COMP(Q4[((pos) / 4) & 1], (pos) & 3))                                                          \
+                     : (kRingLA == 0 ? FS_RING_ROW(pos)                                                                                 \
+                                     : (FS_RING_FETCH((pos) + kRingLA), __builtin_amdgcn_sched_barrier(0), Q[(pos) & 7])))
 
 // gates on the hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp each; |error| of a gate ~2e-7, the fold's bar is
 // 1e-4): the libm forms are ~30 VALU instructions each, 96 per lane and 32 pairs, and fp32 VALU work does not overlap
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int t = grp * 32 + p;
     const bool live = t < n;
     FS_BIAS_SETUP(tab)
-    FS_RING_SETUP(tab, kFwdChunks, kFwdUsed, 0)
+    FS_RING_SETUP(tab, kFwdChunks, kFwdUsed, 0, false)
     // sources of this pair: `row` = a materialised row, or (GATHER) the state latent / the view latent
     const float* row = GATHER ? nullptr : cat + (size_t)(live ? t : 0) * 176;
     const long long gm = GATHER ? ga.fuse_idx[live ? t : 0] : 0, gp = GATHER ? ga.fuse_pix[live ? t : 0] : 0;
@@ -299,6 +325,9 @@ __device__ __forceinline__ void store_acc(float* __restrict__ dst, int hf, const
         *(float4*)(dst + 8 * g4 + 4 * hf) = make_float4(a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]);
 }
 
+#ifndef FS_GRU_BWD_QUAD
+#define FS_GRU_BWD_QUAD 1   // the backward's operand stream interleaved by quads of rows (fs_ptf_gru_stream_layout() tells the host)
+#endif
 #ifndef FS_GRU_BWD_LA
 #define FS_GRU_BWD_LA 4    // operand rows read this many MFMAs ahead in the backward (0: A/B, the scheduler's own placement)
 #endif
@@ -318,7 +347,7 @@ __global__ __launch_bounds__(256) FS_GRU_BWD_OCC void ptf_gru_bwd_kernel(int n, 
     const bool live = t < n;             // (a wavefront beyond n stays for the barriers, computes on row 0, stores nothing)
     const size_t tr = (size_t)(live ? t : 0);
     FS_BIAS_SETUP(tab)
-    FS_RING_SETUP(stream, kStreamChunks, kStreamUsed, FS_GRU_BWD_LA)
+    FS_RING_SETUP(stream, kStreamChunks, kStreamUsed, FS_GRU_BWD_LA, FS_GRU_BWD_QUAD != 0)
     const float* row = cat + tr * 176;
     float* sd = side + tr * kSide;       // (dead pairs compute on row 0 and store nothing)
 
@@ -830,6 +859,9 @@ FS_API int32_t fs_ptf_gru_table_t_rows(void) { return kRowsT; }
 FS_API int32_t fs_ptf_gru_side_cols(void) { return kSide; }
 
 FS_API int32_t fs_ptf_gru_stream_rows(void) { return kStreamChunks * kCh; }
+// 0: row r of the operand stream is 64 consecutive floats; 1: interleaved -- [chunk of kCh rows][owner wavefront (4)][quad][lane (64)][4 rows]
+FS_API int32_t fs_ptf_gru_stream_layout(void) { return FS_GRU_BWD_QUAD != 0 ? 1 : 0; }
+FS_API int32_t fs_ptf_gru_stream_chunk_rows(void) { return kCh; }
 
 FS_API int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables, const float* operand_stream,
                                const float* g_fused, float* dcat, float* side, void* stream_)

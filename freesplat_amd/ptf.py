@@ -246,6 +246,12 @@ def gru_operand_stream(gru: "GRU") -> Tensor:
     stream = tab.new_zeros(rows, 64)
     stream[:696] = tab[:696]
     stream[696: 1464] = tab_t[torch.tensor(o, device=tab.device)]
+    if _lib.lib().fs_ptf_gru_stream_layout() == 1:
+        # interleaved by quads of rows (include/freesplat_amd.h): [chunk][owner wavefront][quad][lane][row of the quad] -- a lane's
+        # four consecutive operand rows are one float4 in memory and in the kernel's LDS ring
+        c = _lib.lib().fs_ptf_gru_stream_chunk_rows()
+        assert rows % c == 0 and c % 16 == 0
+        stream = stream.view(rows // c, 4, c // 16, 4, 64).permute(0, 1, 2, 4, 3).contiguous().view(rows, 64)
     _stream_cache[gru] = (tab, tab_t, stream)
     return stream
 

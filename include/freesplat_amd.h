@@ -380,6 +380,12 @@ int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, float* 
  * sums, reduced by a second launch). */
 int32_t fs_ptf_gru_table_t_rows(void);
 int32_t fs_ptf_gru_stream_rows(void);
+/* Memory layout of `operand_stream` (ABI 6): 0 = row r is 64 consecutive floats; 1 = interleaved by quads of rows -- with
+ * c = fs_ptf_gru_stream_chunk_rows() rows per LDS chunk, element [chunk][owner wavefront (4)][quad (c/16)][lane (64)][row of the
+ * quad (4)] holds row chunk*c + wavefront*(c/4) + 4*quad + row, lane `lane`, so that a lane's four consecutive operand rows are one
+ * float4 (one ds_read_b128 per four MFMAs).  freesplat_amd/ptf.py:gru_operand_stream builds what the library reports. */
+int32_t fs_ptf_gru_stream_layout(void);
+int32_t fs_ptf_gru_stream_chunk_rows(void);
 int32_t fs_ptf_gru_side_cols(void);
 int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables, const float* operand_stream,
                         const float* g_fused, float* dcat, float* side, void* stream);
