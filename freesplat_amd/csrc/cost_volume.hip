@@ -2520,10 +2520,12 @@ static int cv_backward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t 
     if (bwd16) {
         if (C == 48) {
             if (saved) sweep16(cost_volume16_bwd_kernel<48, true>); else sweep16(cost_volume16_bwd_kernel<48, false>);
-            if (sg_form) tile_sweep(cv_src_grad_kernel<48, true, 1>); else tile_sweep(cv_src_grad_kernel<48, true, 0>);
+            if constexpr (kSgTW * kSgTH == 64) { if (sg_form) tile_sweep(cv_src_grad_kernel<48, true, 1>); else tile_sweep(cv_src_grad_kernel<48, true, 0>); }
+            else tile_sweep(cv_src_grad_kernel<48, true, 0>);
         } else {
             if (saved) sweep16(cost_volume16_bwd_kernel<16, true>); else sweep16(cost_volume16_bwd_kernel<16, false>);
-            if (sg_form) tile_sweep(cv_src_grad_kernel<16, true, 1>); else tile_sweep(cv_src_grad_kernel<16, true, 0>);
+            if constexpr (kSgTW * kSgTH == 64) { if (sg_form) tile_sweep(cv_src_grad_kernel<16, true, 1>); else tile_sweep(cv_src_grad_kernel<16, true, 0>); }
+            else tile_sweep(cv_src_grad_kernel<16, true, 0>);
         }
     } else if (two_pass) {
         if (C == 48) {
