@@ -661,7 +661,7 @@ def headline(full: dict) -> dict:
                 e["order_ok"] = p["same_count_and_order"]
                 e["views_cmp"] = p.get("views_compared")
             digest[f"{group}.{name}"] = e
-    for name in ("c3_train_step_hotpath", "c4_eval_step_hotpath"):
+    for name in ("c3_train_step_hotpath", "c4_eval_step_hotpath", "c5_eval_step_hotpath"):
         if isinstance(full.get(name), dict):
             o = full[name]
             digest[name] = ({"error": str(o["error"])[:80]} if "error" in o else
@@ -794,6 +794,12 @@ def main():
         # matched against its 8 pose-nearest views (num_views = 9), the 10-view fold, 8 rendered target views; no autograd
         out["c4_eval_step_hotpath"] = section(lambda: bc.bench_c3_step(cx.dev, steps=5, warmup=2, H=384, W=512, V=10, n_targets=8,
                                                                        train=False, num_views=9, workload="c4_eval_step_hotpath"))
+        # BASELINE config 5 ("Replica 10-views eval, 30-view long-sequence fusion, fp16 SH coeffs") on ONE of its GPUs as one composed
+        # evaluation step: 30 context views at 384x512, each matched against its 8 pose-nearest views, the 30-view fold, 8 rendered
+        # target views with the SH coefficients stored in fp16; no autograd
+        out["c5_eval_step_hotpath"] = section(lambda: bc.bench_c3_step(cx.dev, steps=3, warmup=1, H=384, W=512, V=30, n_targets=8,
+                                                                       train=False, num_views=9, workload="c5_eval_step_hotpath",
+                                                                       sh_fp16=True))
     if cx.rank == 0:
         emit(out)
     if cx.dist_on:

@@ -135,7 +135,7 @@ def committed_glue():
 
 
 def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_targets=4, trace_steps=0, train=True,
-                  num_views=None, workload="c3_train_step_hotpath") -> dict:
+                  num_views=None, workload="c3_train_step_hotpath", sh_fp16=False) -> dict:
     import inputs
     from freesplat_amd import _lib
     from freesplat_amd.decoder import DecoderSplattingCUDA
@@ -156,7 +156,11 @@ def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_tar
         if not train:       # evaluation: test_step's encoder + decoder calls (model_wrapper.py:314-324), no autograd
             with torch.no_grad():
                 res = encoder_forward(enc, dict(ctx), 0, is_testing=True)
-                out = dec(res["gaussians"][0], tgt_E, tgt_K, near_t, far_t, (H, W), depth_mode=None)
+                gs = res["gaussians"][0]
+                if sh_fp16:      # BASELINE config 5's storage option: the SH coefficients kept in fp16 (FS_RASTER_SH_FP16)
+                    import dataclasses
+                    gs = dataclasses.replace(gs, harmonics=gs.harmonics.half())
+                out = dec(gs, tgt_E, tgt_K, near_t, far_t, (H, W), depth_mode=None)
             info["gaussians"] = int(res["num_gaussians"])
             return out.color[0, 0, 0, 0, 0]
         for p_ in enc.parameters():
@@ -218,7 +222,7 @@ def bench_c3_step(dev, steps=5, warmup=3, H=968, W=1296, V=3, D=128, C=48, n_tar
             "dtype": "f32", "data": "synthetic (random images, seeded cameras; stand-in modules for the reference's out-of-scope networks)",
             "config": {"workload": workload, "image_hw": [H, W], "context_views": V, "target_views": n_targets,
                        "depth_planes": D, "match_hw": [H // 4, W // 4], "sources_per_view": K_src,
-                       "raw_gaussians": V * H * W, "gaussians_after_fold": n_g},
+                       "raw_gaussians": V * H * W, "gaussians_after_fold": n_g, "sh_storage": "fp16" if sh_fp16 else "fp32"},
             "gaussians": n_g, "target_views": n_targets,
             "library_kernel_ms": lib_ms, "library_kernel_ms_by_stage": stages,
             "non_library_ms": other_ms,
@@ -241,12 +245,15 @@ if __name__ == "__main__":
                     help="run ONLY this many plain steps after the warm-up and print their count (for rocprofv3 --kernel-trace: "
                          "profiles/tools/c3_step_glue.py divides the trace by it)")
     ap.add_argument("--c4", action="store_true", help="config 4's evaluation step instead: 10 views at 384x512, K = 8, 8 targets, no autograd")
+    ap.add_argument("--c5", action="store_true", help="config 5's evaluation step: 30 views at 384x512, K = 8, the 30-view fold, 8 targets, fp16 SH, no autograd")
     ap.add_argument("--small", action="store_true", help="config 1's size (256x256, 2 views, D = 16): a quick functional run")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     kw = dict(H=256, W=256, V=2, D=16, n_targets=2) if a.small else {}
     if a.c4:
         kw = dict(H=384, W=512, V=10, n_targets=8, train=False, num_views=9, workload="c4_eval_step_hotpath")
+    if a.c5:
+        kw = dict(H=384, W=512, V=30, n_targets=8, train=False, num_views=9, workload="c5_eval_step_hotpath", sh_fp16=True)
     if a.trace_steps:
         kw["trace_steps"] = a.trace_steps
     print(json.dumps(bench_c3_step(dev, a.steps, a.warmup, **kw)))

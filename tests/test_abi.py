@@ -284,6 +284,9 @@ def test_committed_bench_line_honours_the_contract():
     c4 = d["c4_eval_step_hotpath"]          # config 4's per-GPU evaluation step: 10 views at the native size, K = 8, no backward stages
     assert c4["config"]["context_views"] == 10 and c4["config"]["sources_per_view"] == 8 and c4["config"]["image_hw"] == [384, 512]
     assert not {"render_bwd", "preprocess_bwd"} & set(c4["library_kernel_ms_by_stage"]) and c4["library_kernel_ms"] < c4["ms_per_step"]
+    c5 = d["c5_eval_step_hotpath"]          # config 5: 30-view long-sequence fusion, fp16 SH storage, evaluation only
+    assert c5["config"]["context_views"] == 30 and c5["config"]["sh_storage"] == "fp16" and c5["config"]["sources_per_view"] == 8
+    assert c5["library_kernel_ms"] < c5["ms_per_step"] and not {"render_bwd", "preprocess_bwd"} & set(c5["library_kernel_ms_by_stage"])
 
 
 def test_compact_headline_fits_the_driver_window():
