@@ -111,11 +111,17 @@ def bench_cost_volume(dev, steps, warmup, V=2, K=1, h4=96, w4=128, D=128, C=48, 
     # training step of the volume: forward + backward w.r.t. both feature maps and the six MLP tensors
     ga = {k: (v.clone().requires_grad_(True) if k in ("cur_feats", "src_feats") else v) for k, v in args.items()}
 
+    cot = torch.ones(V, D, h4, w4, device=dev)      # the volume's cotangent (in training it arrives from the depth network)
+    leaves = [ga["cur_feats"], ga["src_feats"]] + list(mg.parameters())
+
     def train_step():
+        # gradients start from None, as after optimizer.zero_grad(set_to_none=True): rounds 4 - 5 let every backward ACCUMULATE into
+        # the previous step's .grad -- eight torch `add` kernels per step, two of them over the feature maps' 45 + 91 MB at
+        # config-3 scale, plus a 120 MB ones_like fill: ~0.15 ms of harness inside `train_ms`
+        for t in leaves:
+            t.grad = None
         o = mg(**ga)
-        o.backward(torch.ones_like(o))
-    # (two warm-up steps: the SECOND backward is the first to accumulate into existing .grad tensors -- torch loads its `add`
-    #  kernel's code object then, ~60 ms once)
+        o.backward(cot)
     dt_train = timed(train_step, max(2, steps // 4), 2)
     # the backward alone, event-timed through the library's stage hooks (every launch of a training step is in the
     # cost_volume stage: forward sweep + relayouts, then the backward's two passes + relayouts)
