@@ -574,12 +574,272 @@ __global__ __launch_bounds__(256) FS_GRU_BWD_OCC void ptf_gru_bwd_kernel(int n, 
     }
 }
 
+// FS_GRU_BWD16=0: the 32-pair backward kernel of rounds 4 - 5 (A/B; the operand stream's layout follows: fs_ptf_gru_stream_layout())
+static bool gru_bwd16()
+{
+    static const bool on = [] { const char* e = getenv("FS_GRU_BWD16"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward of the GRU on 16-PAIR wavefronts (round 6): the same computation as ptf_gru_bwd_kernel on v_mfma_f32_16x16x4_f32, lane =
+// (pair n = lane & 15, quarter g = lane >> 4).  An activation matrix [64 units x 16 pairs] is 4 blocks x 4 registers per lane
+// (register (blk, r) = unit 16 blk + 4 g + r of pair n) instead of 2 x 16, the input row 44 instead of 88 registers: the kernel
+// fits 256 registers and TWO wavefronts share a SIMD -- with one, 45 % of the 32-pair kernel's time was gate math, LDS / memory
+// issue, waits and layer-boundary dependencies that nothing overlapped (profiles/r6_gru_bwd_waves_ab.txt).  As everywhere in this
+// layout an accumulator IS the next layer's B operand (k-step s of a 64-unit input = register (s >> 2, s & 3): units
+// 16 (s >> 2) + 4 kk + (s & 3) over the quarters kk), forward and transposed.  Operand rows: 696 (forward re-run) + 704
+// (transposed layers; the 176 features of dcat are 11 blocks of 16) = 1 400, consumed strictly in order from the quad-interleaved
+// stream freesplat_amd/ptf.py:gru_operand_stream builds for fs_ptf_gru_stream_layout() = 2; the six bias vectors follow it.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kS16Used = 696 + 704, kS16Chunks = (kS16Used + kCh - 1) / kCh;
+#define FS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#ifndef FS_GRU_BWD16_WAVES
+#define FS_GRU_BWD16_WAVES 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD16_WAVES, FS_GRU_BWD16_WAVES))) void ptf_gru_bwd16_kernel(
+    int n, const float* __restrict__ cat, const float* __restrict__ stream, const float* __restrict__ g_fused,
+    float* __restrict__ dcat, float* __restrict__ side)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = blockIdx.x * 4 + wave;
+    const int pn = lane & 15, g = lane >> 4;
+    const int t = grp * 16 + pn;
+    const bool live = t < n;             // (a wavefront beyond n stays for the barriers, computes on row 0, stores nothing)
+    const size_t tr = (size_t)(live ? t : 0);
+    FS_RING_SETUP(stream, kS16Chunks, kS16Used, 0, true)
+    const float* const bias = stream + (size_t)kS16Chunks * kCh * 64;     // [6][64]: br1, bz1, br2, bz2, bn1, bn2
+    const float* row = cat + tr * 176;
+    float* sd = side + tr * kSide;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    auto ld4 = [&](const float* p) __attribute__((always_inline)) { const float4 v = *(const float4*)p; return f32x4{v.x, v.y, v.z, v.w}; };
+    auto st4 = [&](float* p, const f32x4 v) __attribute__((always_inline)) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); };
+    const int ao = 4 * g;                                  // accumulator block blk, registers 0..3 = units / features 16 blk + ao + 0..3
+    int pos = 0;                                           // (compile-time after unrolling: every loop below is fully unrolled)
+
+    f32x4 hid[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) hid[blk] = ld4(row + 16 * blk + ao);
+    // ================= forward, keeping what the backward needs =================
+    uint32_t mr = 0, mz = 0, mn = 0;     // ReLU masks of the three first layers, bit 4 blk + r
+    f32x4 rr[4], zz[4], n1[4];
+    {
+        f32x4 r1[4], z1[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) { r1[blk] = ld4(bias + 0 * 64 + 16 * blk + ao); z1[blk] = ld4(bias + 1 * 64 + 16 * blk + ao); }
+        {
+            float xh[44];       // this quarter's 44 features of the input row: k-step s, quarter g <-> feature 44 g + s
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float4 v = ((const float4*)(row + 44 * g))[k];
+                xh[4 * k] = v.x; xh[4 * k + 1] = v.y; xh[4 * k + 2] = v.z; xh[4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 44; ++s) {
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) r1[ob] = FS_MFMA16(FS_AOP(s * 8 + ob), xh[s], r1[ob]);
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) z1[ob] = FS_MFMA16(FS_AOP(s * 8 + 4 + ob), xh[s], z1[ob]);
+            }
+        }
+        constexpr int p1 = 44 * 8;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mr |= (r1[blk][r] > 0.0f ? 1u : 0u) << (4 * blk + r);
+                mz |= (z1[blk][r] > 0.0f ? 1u : 0u) << (4 * blk + r);
+                r1[blk][r] = fmaxf(r1[blk][r], 0.0f); z1[blk][r] = fmaxf(z1[blk][r], 0.0f);
+            }
+        if (live) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) { st4(sd + 6 * 64 + 16 * blk + ao, r1[blk]); st4(sd + 7 * 64 + 16 * blk + ao, z1[blk]); }
+        }
+        f32x4 R[4], Z[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) { R[blk] = ld4(bias + 2 * 64 + 16 * blk + ao); Z[blk] = ld4(bias + 3 * 64 + 16 * blk + ao); }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float br = r1[s >> 2][s & 3], bz = z1[s >> 2][s & 3];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) R[ob] = FS_MFMA16(FS_AOP(p1 + s * 8 + ob), br, R[ob]);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) Z[ob] = FS_MFMA16(FS_AOP(p1 + s * 8 + 4 + ob), bz, Z[ob]);
+        }
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { rr[blk][r] = sigmoidf_(R[blk][r]); zz[blk][r] = sigmoidf_(Z[blk][r]); }
+    }
+    constexpr int p2 = 44 * 8 + 16 * 8;
+    {   // mlp_n layer 1: [r * hid (64) | x (64) | xe (24)]
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) n1[blk] = ld4(bias + 4 * 64 + 16 * blk + ao);
+        f32x4 h0[4];   // r * hid, stored for the weight gradient of mlp_n layer 1
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h0[blk][r] = rr[blk][r] * hid[blk][r];
+        if (live) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) st4(sd + 9 * 64 + 16 * blk + ao, h0[blk]);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) n1[ob] = FS_MFMA16(FS_AOP(p2 + s * 4 + ob), h0[s >> 2][s & 3], n1[ob]);
+        float xt[22];   // k-step s, quarter g <-> feature 88 + 22 g + s of the row (x | xe)
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float2 v = ((const float2*)(row + 88 + 22 * g))[k];
+            xt[2 * k] = v.x; xt[2 * k + 1] = v.y;
+        }
+#pragma unroll
+        for (int s = 0; s < 22; ++s)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) n1[ob] = FS_MFMA16(FS_AOP(p2 + 64 + s * 4 + ob), xt[s], n1[ob]);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mn |= (n1[blk][r] > 0.0f ? 1u : 0u) << (4 * blk + r);
+                n1[blk][r] = fmaxf(n1[blk][r], 0.0f);
+            }
+        if (live) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) st4(sd + 8 * 64 + 16 * blk + ao, n1[blk]);
+        }
+    }
+    constexpr int p3 = p2 + 64 + 88;
+    f32x4 dN[4], dZ[4], dh[4];   // pre-activation gradients of the two output layers; gradient of hid through (1 - z) * hid
+    {
+        f32x4 N[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) N[blk] = ld4(bias + 5 * 64 + 16 * blk + ao);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) N[ob] = FS_MFMA16(FS_AOP(p3 + s * 4 + ob), n1[s >> 2][s & 3], N[ob]);
+        const float* go = g_fused + tr * 64;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const f32x4 gv = ld4(go + 16 * blk + ao);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gq = live ? gv[r] : 0.0f;
+                const float z = zz[blk][r], h = hid[blk][r];
+                const float qq = tanhf_(N[blk][r]);
+                dN[blk][r] = gq * z * (1.0f - qq * qq);
+                dZ[blk][r] = gq * (qq - h) * z * (1.0f - z);
+                dh[blk][r] = gq * (1.0f - z);
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) { st4(sd + 5 * 64 + 16 * blk + ao, dN[blk]); st4(sd + 3 * 64 + 16 * blk + ao, dZ[blk]); }
+    }
+    static_assert(p3 + 64 == 696, "forward operand rows");
+    // ================= transposed layers =================
+    constexpr int q0 = 696;
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 C[11];                 // dcat: feature block ob = features 16 ob + 4 g + r
+    f32x4 dR[4];
+    {
+        f32x4 a[4] = {zero4, zero4, zero4, zero4};      // mlp_n layer 2: d relu(n1) = Wn2^T dN, masked -> dn1
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) a[ob] = FS_MFMA16(FS_AOP(q0 + s * 4 + ob), dN[s >> 2][s & 3], a[ob]);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[blk][r] = (mn >> (4 * blk + r)) & 1u ? a[blk][r] : 0.0f;
+        if (live) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) st4(sd + 4 * 64 + 16 * blk + ao, a[blk]);
+        }
+        // mlp_n layer 1: d(r * hid) (4 blocks) and the x | xe part straight into dcat's blocks 5 .. 10
+        f32x4 H[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+        for (int ob = 5; ob < 11; ++ob) C[ob] = zero4;
+        constexpr int q1 = q0 + 64;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float b = a[s >> 2][s & 3];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) H[ob] = FS_MFMA16(FS_AOP(q1 + s * 10 + ob), b, H[ob]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) C[5 + j] = FS_MFMA16(FS_AOP(q1 + s * 10 + 4 + j), b, C[5 + j]);
+        }
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float r_ = rr[blk][r];
+                dR[blk][r] = H[blk][r] * hid[blk][r] * r_ * (1.0f - r_);
+                dh[blk][r] += H[blk][r] * r_;
+            }
+    }
+    if (live) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) st4(sd + 2 * 64 + 16 * blk + ao, dR[blk]);
+    }
+    constexpr int q2 = q0 + 64 + 160;
+    f32x4 e[4] = {zero4, zero4, zero4, zero4}, f[4] = {zero4, zero4, zero4, zero4};   // dr1, dz1
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float br = dR[s >> 2][s & 3], bz = dZ[s >> 2][s & 3];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) e[ob] = FS_MFMA16(FS_AOP(q2 + s * 8 + ob), br, e[ob]);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) f[ob] = FS_MFMA16(FS_AOP(q2 + s * 8 + 4 + ob), bz, f[ob]);
+    }
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e[blk][r] = (mr >> (4 * blk + r)) & 1u ? e[blk][r] : 0.0f;
+            f[blk][r] = (mz >> (4 * blk + r)) & 1u ? f[blk][r] : 0.0f;
+        }
+    if (live) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) { st4(sd + 0 * 64 + 16 * blk + ao, e[blk]); st4(sd + 1 * 64 + 16 * blk + ao, f[blk]); }
+    }
+    // first layers of r and z: all eleven feature blocks of dcat (blocks 0..3 start from the gate's d hid, 5..10 hold mlp_n's part)
+    constexpr int q3 = q2 + 128;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) C[blk] = dh[blk];
+    C[4] = zero4;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float br = e[s >> 2][s & 3], bz = f[s >> 2][s & 3];
+#pragma unroll
+        for (int ob = 0; ob < 11; ++ob) C[ob] = FS_MFMA16(FS_AOP(q3 + s * 22 + ob), br, C[ob]);
+#pragma unroll
+        for (int ob = 0; ob < 11; ++ob) C[ob] = FS_MFMA16(FS_AOP(q3 + s * 22 + 11 + ob), bz, C[ob]);
+    }
+    static_assert(q3 + 16 * 22 == kS16Used, "operand rows");
+    (void)pos;
+    if (live) {
+        float* dc = dcat + tr * 176;
+#pragma unroll
+        for (int ob = 0; ob < 11; ++ob) st4(dc + 16 * ob + ao, C[ob]);
+    }
+}
+
 int launch_ptf_gru_bwd(int n, const float* cat, const float* tables, const float* stream, const float* g_fused,
                        float* dcat, float* side, hipStream_t st)
 {
     if (n <= 0) return FS_OK;
-    const int groups = (n + 31) / 32;
-    hipLaunchKernelGGL(ptf_gru_bwd_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, tables, stream, g_fused, dcat, side);
+    if (gru_bwd16()) {      // 16 pairs per wavefront, 64 per workgroup
+        const int groups = (n + 15) / 16;
+        hipLaunchKernelGGL(ptf_gru_bwd16_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, stream, g_fused, dcat, side);
+    } else {
+        const int groups = (n + 31) / 32;
+        hipLaunchKernelGGL(ptf_gru_bwd_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, tables, stream, g_fused, dcat, side);
+    }
     FS_CHECK_LAUNCH("ptf_gru_backward");
     return FS_OK;
 }
@@ -858,9 +1118,11 @@ FS_API int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, 
 FS_API int32_t fs_ptf_gru_table_t_rows(void) { return kRowsT; }
 FS_API int32_t fs_ptf_gru_side_cols(void) { return kSide; }
 
-FS_API int32_t fs_ptf_gru_stream_rows(void) { return kStreamChunks * kCh; }
+FS_API int32_t fs_ptf_gru_stream_rows(void) { return gru_bwd16() ? kS16Chunks * kCh + 6 : kStreamChunks * kCh; }
 // 0: row r of the operand stream is 64 consecutive floats; 1: interleaved -- [chunk of kCh rows][owner wavefront (4)][quad][lane (64)][4 rows]
-FS_API int32_t fs_ptf_gru_stream_layout(void) { return FS_GRU_BWD_QUAD != 0 ? 1 : 0; }
+// 2: the 16-pair backward's stream -- its 1 400 operand rows (padded to whole chunks) interleaved as in layout 1, then six rows = the
+// bias vectors br1, bz1, br2, bz2, bn1, bn2 (64 floats each)
+FS_API int32_t fs_ptf_gru_stream_layout(void) { return gru_bwd16() ? 2 : (FS_GRU_BWD_QUAD != 0 ? 1 : 0); }
 FS_API int32_t fs_ptf_gru_stream_chunk_rows(void) { return kCh; }
 
 FS_API int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables, const float* operand_stream,

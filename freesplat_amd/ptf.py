@@ -223,6 +223,69 @@ _KTN2, _KTN1H, _KTN1C, _KTR2, _KTZ2, _KTR1, _KTZ1 = 0, 64, 128, 256, 320, 384, 5
 _stream_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
+def _gru_operand_stream16(gru: "GRU") -> Tensor:
+    """Operand stream of csrc/ptf_gru.hip:ptf_gru_bwd16_kernel (fs_ptf_gru_stream_layout() = 2): one row of 64 lanes per
+    v_mfma_f32_16x16x4_f32 in consumption order, lane l = (i = l & 15, kk = l >> 4) holding A[i][kk] --
+      forward layer, output block ob:     W[16 ob + i][input of k-step s for quarter kk]
+      transposed layer, feature block ob: W[unit of k-step s for quarter kk][feature 16 ob + i]      (0 where there is none)
+    where a 64-unit activation is consumed register by register of the accumulator layout: k-step s <-> units
+    16 (s >> 2) + 4 kk + (s & 3).  696 forward + 704 transposed rows, padded to whole ring chunks and interleaved by quads of rows
+    as layout 1; then the six bias vectors (64 floats each)."""
+    params = _gru_params(gru)
+    dev = params[0].device
+    with torch.no_grad():
+        Wr1, br1, Wr2, br2, Wz1, bz1, Wz2, bz2, Wn1, bn1, Wn2, bn2 = [q.detach().float() for q in params]
+        lane = torch.arange(64, device=dev)
+        i, kk = lane & 15, lane >> 4
+        rows = []
+
+        def pad(W):
+            return torch.cat([W, torch.zeros(W.shape[0], 1, device=dev)], dim=1)
+
+        def fwd(W, ob, col):                      # col [64]: input index per lane (outside the matrix -> 0)
+            c = torch.where((col >= 0) & (col < W.shape[1]), col, torch.full_like(col, W.shape[1]))
+            return pad(W)[16 * ob + i, c]
+
+        def acc(s):                               # units of k-step s, per lane
+            return 16 * (s >> 2) + 4 * kk + (s & 3)
+
+        def tr(W, ob, s, col_of_feature=None):    # out row = feature 16 ob + i, k = unit acc(s)
+            f = 16 * ob + i
+            col = f if col_of_feature is None else col_of_feature(f)
+            c = torch.where((col >= 0) & (col < W.shape[1]), col, torch.full_like(col, W.shape[1]))
+            return pad(W)[acc(s), c]
+
+        for s in range(44):                       # layer 1 of r and z: feature 44 kk + s
+            col = 44 * kk + s
+            rows += [fwd(Wr1, ob, col) for ob in range(4)] + [fwd(Wz1, ob, col) for ob in range(4)]
+        for s in range(16):                       # layer 2 of r and z
+            rows += [fwd(Wr2, ob, acc(s)) for ob in range(4)] + [fwd(Wz2, ob, acc(s)) for ob in range(4)]
+        for s in range(16):                       # mlp_n layer 1: r * hid ...
+            rows += [fwd(Wn1, ob, acc(s)) for ob in range(4)]
+        for s in range(22):                       # ... then x | xe: row feature 88 + 22 kk + s = mlp_n input 64 + 22 kk + s
+            rows += [fwd(Wn1, ob, 64 + 22 * kk + s) for ob in range(4)]
+        for s in range(16):                       # mlp_n layer 2
+            rows += [fwd(Wn2, ob, acc(s)) for ob in range(4)]
+        assert len(rows) == 696
+        n1_from_cat = lambda f: torch.where(f >= 88, f - 24, torch.full_like(f, -1))
+        for s in range(16):
+            rows += [tr(Wn2, ob, s) for ob in range(4)]
+        for s in range(16):
+            rows += [tr(Wn1, ob, s) for ob in range(4)] + [tr(Wn1, ob, s, n1_from_cat) for ob in range(5, 11)]
+        for s in range(16):
+            rows += [tr(Wr2, ob, s) for ob in range(4)] + [tr(Wz2, ob, s) for ob in range(4)]
+        for s in range(16):
+            rows += [tr(Wr1, ob, s) for ob in range(11)] + [tr(Wz1, ob, s) for ob in range(11)]
+        assert len(rows) == 1400
+        c = _lib.lib().fs_ptf_gru_stream_chunk_rows()
+        n_rows = _lib.lib().fs_ptf_gru_stream_rows() - 6
+        assert n_rows % c == 0 and n_rows >= 1400 and c % 16 == 0
+        ops = torch.zeros(n_rows, 64, device=dev)
+        ops[:1400] = torch.stack(rows)
+        ops = ops.view(n_rows // c, 4, c // 16, 4, 64).permute(0, 1, 2, 4, 3).contiguous().view(n_rows, 64)
+        return torch.cat([ops, torch.stack([br1, bz1, br2, bz2, bn1, bn2])]).contiguous()
+
+
 def gru_operand_stream(gru: "GRU") -> Tensor:
     """The operand rows of ptf_gru_bwd_kernel in the order in which it consumes them: the 696 rows of the forward
     (gru_tables, already in consumption order), then the transposed layers' rows (gru_tables_t) -- mlp_n second layer,
@@ -231,6 +294,10 @@ def gru_operand_stream(gru: "GRU") -> Tensor:
     hit = _stream_cache.get(gru)
     if hit is not None and hit[0] is tab and hit[1] is tab_t:
         return hit[2]
+    if _lib.lib().fs_ptf_gru_stream_layout() == 2:          # the 16-pair backward kernel's stream (built from the parameters)
+        stream = _gru_operand_stream16(gru)
+        _stream_cache[gru] = (tab, tab_t, stream)
+        return stream
     o = []
     for s in range(32):
         o += [_KTN2 + s, _KTN2 + 32 + s]

@@ -383,7 +383,10 @@ int32_t fs_ptf_gru_stream_rows(void);
 /* Memory layout of `operand_stream` (ABI 6): 0 = row r is 64 consecutive floats; 1 = interleaved by quads of rows -- with
  * c = fs_ptf_gru_stream_chunk_rows() rows per LDS chunk, element [chunk][owner wavefront (4)][quad (c/16)][lane (64)][row of the
  * quad (4)] holds row chunk*c + wavefront*(c/4) + 4*quad + row, lane `lane`, so that a lane's four consecutive operand rows are one
- * float4 (one ds_read_b128 per four MFMAs).  freesplat_amd/ptf.py:gru_operand_stream builds what the library reports. */
+ * float4 (one ds_read_b128 per four MFMAs); 2 = the stream of the 16-pair backward kernel (the default; FS_GRU_BWD16=0 in the
+ * environment selects the 32-pair kernel and layout 1): 1 400 operand rows of v_mfma_f32_16x16x4_f32 in consumption order, padded to whole
+ * chunks and interleaved as in layout 1, followed by six rows = the bias vectors br1, bz1, br2, bz2, bn1, bn2.
+ * freesplat_amd/ptf.py:gru_operand_stream builds what the library reports. */
 int32_t fs_ptf_gru_stream_layout(void);
 int32_t fs_ptf_gru_stream_chunk_rows(void);
 int32_t fs_ptf_gru_side_cols(void);
