@@ -83,6 +83,7 @@ SIGNATURES = {
     "fs_ptf_gru_table_t_rows": (C.c_int32, []),
     "fs_ptf_gru_stream_rows": (C.c_int32, []),
     "fs_ptf_gru_stream_layout": (C.c_int32, []),
+    "fs_ptf_gru_table_layout": (C.c_int32, []),
     "fs_ptf_gru_stream_chunk_rows": (C.c_int32, []),
     "fs_ptf_gru_side_cols": (C.c_int32, []),
     "fs_ptf_gru_backward": (C.c_int, [C.c_int32] + [_VP] * 7),

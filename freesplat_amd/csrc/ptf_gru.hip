@@ -269,31 +269,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// n pairs, or (counts != NULL) at most n_max with the actual number in counts[1] on the device
-int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const float* tables, float* fused, hipStream_t st)
-{
-    if (n_max <= 0) return FS_OK;
-    const int groups = (n_max + 31) / 32;
-    hipLaunchKernelGGL(ptf_gru_kernel<false>, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, cat, GruGather{}, tables,
-                       fused, 0);
-    FS_CHECK_LAUNCH("ptf_gru_forward");
-    return FS_OK;
-}
-
-int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fuse_idx, const long long* fuse_pix,
-                          const float* G, const float* R, const float* O, const float* g_i, const float* rho_i,
-                          const float* om_i, const float* tables, float* fused, bool out_after_keep, hipStream_t st)
-{
-    if (n_max <= 0) return FS_OK;
-    const int groups = (n_max + 31) / 32;
-    const GruGather ga{fuse_idx, fuse_pix, G, R, O, g_i, rho_i, om_i};
-    hipLaunchKernelGGL(ptf_gru_kernel<true>, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, (const float*)nullptr, ga,
-                       tables, fused, out_after_keep ? 1 : 0);
-    FS_CHECK_LAUNCH("ptf_gru_gather");
-    return FS_OK;
-}
-
-
 // ------------------------------------------------------------------------------------------------------------
 // Backward of the GRU, same organisation: one wavefront owns 32 pairs, lane = (pair, half), every value of a pair
 // stays in its own lanes.  The forward is re-run from the materialised input rows (keeping r, z, q, the ReLU masks as
@@ -829,6 +804,191 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Forward of the GRU on 16-pair wavefronts (round 6; the layout of ptf_gru_bwd16_kernel): 696 v_mfma_f32_16x16x4_f32 per 16 pairs,
+// ~120 registers -- FS_GRU_FWD16_WAVES wavefronts per SIMD instead of the 32-pair kernel's two.  `tab` = the forward part of the
+// 16-pair operand stream (696 rows padded to whole chunks, quad-interleaved) followed by the six bias vectors
+// (fs_ptf_gru_table_layout() = 1; freesplat_amd/ptf.py:gru_tables builds it).
+// GATHER: k-step s of layer 1, quarter g <-> feature 44 g + s of the virtual row [hid (64) | he (24) | x (64) | xe (24)]: quarter 0 = hid[0:44],
+// 1 = hid[44:64] | he, 2 = x[0:44], 3 = x[44:64] | xe; every lane computes ONE positional encoding -- he for quarters 0 - 1,
+// xe for 2 - 3 (a wavefront executes both anyway) -- and mlp_n's x | xe steps (feature 88 + 22 g + s) take x from memory and xe from it.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kF16Chunks = (696 + kCh - 1) / kCh;
+#ifndef FS_GRU_FWD16_WAVES
+#define FS_GRU_FWD16_WAVES 3
+#endif
+template <bool GATHER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_FWD16_WAVES, FS_GRU_FWD16_WAVES))) void ptf_gru16_kernel(
+    int n, const int32_t* __restrict__ counts, const float* __restrict__ cat, GruGather ga, const float* __restrict__ tab,
+    float* __restrict__ fused, int out_after_keep)
+{
+    const size_t out_row0 = (out_after_keep && counts) ? (size_t)counts[0] : 0;
+    if (counts) n = counts[1];  // (device-resident pair count: fs_ptf_fold_step)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = blockIdx.x * 4 + wave;
+    if (blockIdx.x * 64 >= n) return;   // whole workgroup beyond n (a single wavefront beyond n stays for the barriers)
+    const int pn = lane & 15, g = lane >> 4;
+    const int t = grp * 16 + pn;
+    const bool live = t < n;
+    FS_RING_SETUP(tab, kF16Chunks, 696, 0, true)
+    const float* const bias = tab + (size_t)kF16Chunks * kCh * 64;     // [6][64]: br1, bz1, br2, bz2, bn1, bn2
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    auto ld4 = [&](const float* p) __attribute__((always_inline)) { const float4 v = *(const float4*)p; return f32x4{v.x, v.y, v.z, v.w}; };
+    const int ao = 4 * g;
+    const float* row = GATHER ? nullptr : cat + (size_t)(live ? t : 0) * 176;
+    const long long gm = GATHER ? ga.fuse_idx[live ? t : 0] : 0, gp = GATHER ? ga.fuse_pix[live ? t : 0] : 0;
+    const float* hrow = GATHER ? ga.G + gm * 64 : row;          // hid: 64 floats
+    const float* xrow = GATHER ? ga.g_i + gp * 64 : row + 88;   // x: 64 floats (xe follows only in a materialised row)
+
+    float xh[44];      // layer-1 inputs of this quarter: feature 44 g + s of the (virtual) row
+    float pe[24];      // GATHER: he (quarters 0, 1) or xe (quarters 2, 3)
+    if (GATHER) {
+        pos_enc2(g < 2 ? ga.rho_i[gp] : ga.R[gm], g < 2 ? ga.O[gm] : ga.om_i[gp], pe);
+        const float* src = (g < 2 ? hrow : xrow) + 44 * (g & 1);       // even quarters: 44 floats; odd: 20 floats, then the encoding
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float4 v = *(const float4*)((k < 5 || !(g & 1)) ? src + 4 * k : src);     // (no read past the 64-float row)
+            xh[4 * k] = v.x; xh[4 * k + 1] = v.y; xh[4 * k + 2] = v.z; xh[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) xh[20 + k] = (g & 1) ? pe[k] : xh[20 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float4 v = ((const float4*)(row + 44 * g))[k];
+            xh[4 * k] = v.x; xh[4 * k + 1] = v.y; xh[4 * k + 2] = v.z; xh[4 * k + 3] = v.w;
+        }
+    }
+    f32x4 hid[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) hid[blk] = ld4(hrow + 16 * blk + ao);
+
+    f32x4 r1[4], z1[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) { r1[blk] = ld4(bias + 0 * 64 + 16 * blk + ao); z1[blk] = ld4(bias + 1 * 64 + 16 * blk + ao); }
+#pragma unroll
+    for (int s = 0; s < 44; ++s) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) r1[ob] = FS_MFMA16(FS_AOP(s * 8 + ob), xh[s], r1[ob]);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) z1[ob] = FS_MFMA16(FS_AOP(s * 8 + 4 + ob), xh[s], z1[ob]);
+    }
+    constexpr int p1 = 44 * 8;
+    f32x4 R[4], Z[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) { R[blk] = ld4(bias + 2 * 64 + 16 * blk + ao); Z[blk] = ld4(bias + 3 * 64 + 16 * blk + ao); }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float br = fmaxf(r1[s >> 2][s & 3], 0.0f), bz = fmaxf(z1[s >> 2][s & 3], 0.0f);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) R[ob] = FS_MFMA16(FS_AOP(p1 + s * 8 + ob), br, R[ob]);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) Z[ob] = FS_MFMA16(FS_AOP(p1 + s * 8 + 4 + ob), bz, Z[ob]);
+    }
+    constexpr int p2 = p1 + 16 * 8;
+    f32x4 n1[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) n1[blk] = ld4(bias + 4 * 64 + 16 * blk + ao);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float b = sigmoidf_(R[s >> 2][s & 3]) * hid[s >> 2][s & 3];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) n1[ob] = FS_MFMA16(FS_AOP(p2 + s * 4 + ob), b, n1[ob]);
+    }
+    {
+        float xt[22];   // k-step s, quarter g <-> feature 88 + 22 g + s = entry 22 g + s of x | xe
+        if (GATHER) {
+            // quarters 0, 1: x[22 g : 22 g + 22]; quarter 2: x[44:64] | xe[0:2]; quarter 3: xe[2:24] (its own encoding IS xe)
+            const float* src = xrow + 22 * (g < 3 ? g : 0);
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float2 v = *(const float2*)((g < 2 || (g == 2 && k < 10)) ? src + 2 * k : xrow);
+                xt[2 * k] = v.x; xt[2 * k + 1] = v.y;
+            }
+#pragma unroll
+            for (int s = 0; s < 22; ++s) xt[s] = g == 3 ? pe[2 + s] : ((g == 2 && s >= 20) ? pe[s - 20] : xt[s]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float2 v = ((const float2*)(row + 88 + 22 * g))[k];
+                xt[2 * k] = v.x; xt[2 * k + 1] = v.y;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 22; ++s)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) n1[ob] = FS_MFMA16(FS_AOP(p2 + 64 + s * 4 + ob), xt[s], n1[ob]);
+    }
+    constexpr int p3 = p2 + 64 + 88;
+    f32x4 N[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) N[blk] = ld4(bias + 5 * 64 + 16 * blk + ao);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float b = fmaxf(n1[s >> 2][s & 3], 0.0f);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) N[ob] = FS_MFMA16(FS_AOP(p3 + s * 4 + ob), b, N[ob]);
+    }
+    static_assert(p3 + 64 == 696, "forward operand rows");
+    // ---- gates: out = (1 - z) * hid + z * tanh(q), lane holds 16 units of its pair ----
+    if (live) {
+        float* o = fused + (out_row0 + (size_t)t) * 64;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float zz = sigmoidf_(Z[blk][r]);
+                const float qq = tanhf_(N[blk][r]);
+                v[r] = (1.0f - zz) * hid[blk][r] + zz * qq;
+            }
+            *(float4*)(o + 16 * blk + ao) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// FS_GRU_FWD16=0 (or FS_GRU_BWD16=0): the 32-pair forward kernel and its tables
+static bool gru_fwd16()
+{
+    static const bool on = [] { const char* e = getenv("FS_GRU_FWD16"); return !(e && atoi(e) == 0); }() && gru_bwd16();
+    return on;
+}
+
+// n pairs, or (counts != NULL) at most n_max with the actual number in counts[1] on the device
+int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const float* tables, float* fused, hipStream_t st)
+{
+    if (n_max <= 0) return FS_OK;
+    if (gru_fwd16()) {
+        hipLaunchKernelGGL(ptf_gru16_kernel<false>, dim3((n_max + 63) / 64), dim3(256), 0, st, n_max, counts, cat, GruGather{}, tables,
+                           fused, 0);
+    } else {
+        const int groups = (n_max + 31) / 32;
+        hipLaunchKernelGGL(ptf_gru_kernel<false>, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, cat, GruGather{}, tables,
+                           fused, 0);
+    }
+    FS_CHECK_LAUNCH("ptf_gru_forward");
+    return FS_OK;
+}
+
+int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fuse_idx, const long long* fuse_pix,
+                          const float* G, const float* R, const float* O, const float* g_i, const float* rho_i,
+                          const float* om_i, const float* tables, float* fused, bool out_after_keep, hipStream_t st)
+{
+    if (n_max <= 0) return FS_OK;
+    const GruGather ga{fuse_idx, fuse_pix, G, R, O, g_i, rho_i, om_i};
+    if (gru_fwd16()) {
+        hipLaunchKernelGGL(ptf_gru16_kernel<true>, dim3((n_max + 63) / 64), dim3(256), 0, st, n_max, counts, (const float*)nullptr, ga,
+                           tables, fused, out_after_keep ? 1 : 0);
+    } else {
+        const int groups = (n_max + 31) / 32;
+        hipLaunchKernelGGL(ptf_gru_kernel<true>, dim3((groups + 3) / 4), dim3(256), 0, st, n_max, counts, (const float*)nullptr, ga,
+                           tables, fused, out_after_keep ? 1 : 0);
+    }
+    FS_CHECK_LAUNCH("ptf_gru_gather");
+    return FS_OK;
+}
+
+
 int launch_ptf_gru_bwd(int n, const float* cat, const float* tables, const float* stream, const float* g_fused,
                        float* dcat, float* side, hipStream_t st)
 {
@@ -1103,7 +1263,10 @@ int launch_ptf_gru_dw(int n, const float* cat, const float* side, float* grads, 
 
 using namespace fs;
 
-FS_API int32_t fs_ptf_gru_table_rows(void) { return kRows; }
+FS_API int32_t fs_ptf_gru_table_rows(void) { return gru_fwd16() ? kF16Chunks * kCh + 6 : kRows; }
+// 0: the 32-pair kernels' tables (operand rows of ptf_gru_kernel, then 192 bias rows); 1: the 16-pair forward's -- its 696 operand rows
+// padded to whole chunks and interleaved by quads (as operand-stream layout 2), then six rows = the bias vectors
+FS_API int32_t fs_ptf_gru_table_layout(void) { return gru_fwd16() ? 1 : 0; }
 
 FS_API int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, float* fused, void* stream_)
 {

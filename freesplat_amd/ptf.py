@@ -137,6 +137,11 @@ def gru_tables(gru: "GRU") -> Tensor:
     if hit is not None and hit[0] == key:
         return hit[1]
     dev = params[0].device
+    if _lib.lib().fs_ptf_gru_table_layout() == 1:          # the 16-pair forward kernel's tables
+        tab = _gru_operand_stream16(gru, forward_only=True)
+        assert tab.shape[0] == _lib.lib().fs_ptf_gru_table_rows()
+        _table_cache[gru] = (key, tab)
+        return tab
     with torch.no_grad():
         Wr1, br1, Wr2, br2, Wz1, bz1, Wz2, bz2, Wn1, bn1, Wn2, bn2 = [q.detach().float() for q in params]
         lane = torch.arange(64, device=dev)
@@ -223,14 +228,15 @@ _KTN2, _KTN1H, _KTN1C, _KTR2, _KTZ2, _KTR1, _KTZ1 = 0, 64, 128, 256, 320, 384, 5
 _stream_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
-def _gru_operand_stream16(gru: "GRU") -> Tensor:
+def _gru_operand_stream16(gru: "GRU", forward_only: bool = False) -> Tensor:
     """Operand stream of csrc/ptf_gru.hip:ptf_gru_bwd16_kernel (fs_ptf_gru_stream_layout() = 2): one row of 64 lanes per
     v_mfma_f32_16x16x4_f32 in consumption order, lane l = (i = l & 15, kk = l >> 4) holding A[i][kk] --
       forward layer, output block ob:     W[16 ob + i][input of k-step s for quarter kk]
       transposed layer, feature block ob: W[unit of k-step s for quarter kk][feature 16 ob + i]      (0 where there is none)
     where a 64-unit activation is consumed register by register of the accumulator layout: k-step s <-> units
     16 (s >> 2) + 4 kk + (s & 3).  696 forward + 704 transposed rows, padded to whole ring chunks and interleaved by quads of rows
-    as layout 1; then the six bias vectors (64 floats each)."""
+    as layout 1; then the six bias vectors (64 floats each).  forward_only: the 16-pair FORWARD kernel's tables
+    (fs_ptf_gru_table_layout() = 1) -- the first 696 rows, packaged the same way."""
     params = _gru_params(gru)
     dev = params[0].device
     with torch.no_grad():
@@ -277,11 +283,12 @@ def _gru_operand_stream16(gru: "GRU") -> Tensor:
         for s in range(16):
             rows += [tr(Wr1, ob, s) for ob in range(11)] + [tr(Wz1, ob, s) for ob in range(11)]
         assert len(rows) == 1400
+        rows = torch.stack(rows if not forward_only else rows[:696])
         c = _lib.lib().fs_ptf_gru_stream_chunk_rows()
-        n_rows = _lib.lib().fs_ptf_gru_stream_rows() - 6
-        assert n_rows % c == 0 and n_rows >= 1400 and c % 16 == 0
+        n_rows = (_lib.lib().fs_ptf_gru_table_rows() if forward_only else _lib.lib().fs_ptf_gru_stream_rows()) - 6
+        assert n_rows % c == 0 and n_rows >= rows.shape[0] and c % 16 == 0
         ops = torch.zeros(n_rows, 64, device=dev)
-        ops[:1400] = torch.stack(rows)
+        ops[:rows.shape[0]] = rows
         ops = ops.view(n_rows // c, 4, c // 16, 4, 64).permute(0, 1, 2, 4, 3).contiguous().view(n_rows, 64)
         return torch.cat([ops, torch.stack([br1, bz1, br2, bz2, bn1, bn2])]).contiguous()
 
@@ -290,14 +297,18 @@ def gru_operand_stream(gru: "GRU") -> Tensor:
     """The operand rows of ptf_gru_bwd_kernel in the order in which it consumes them: the 696 rows of the forward
     (gru_tables, already in consumption order), then the transposed layers' rows (gru_tables_t) -- mlp_n second layer,
     mlp_n first layer, r/z second layers, r/z first layers --, padded to whole LDS chunks."""
+    if _lib.lib().fs_ptf_gru_stream_layout() == 2:          # the 16-pair backward kernel's stream (built from the parameters)
+        tab = gru_tables(gru)                               # (cached per parameter version: a new table = new parameters)
+        hit = _stream_cache.get(gru)
+        if hit is not None and hit[0] is tab:
+            return hit[2]
+        stream = _gru_operand_stream16(gru)
+        _stream_cache[gru] = (tab, None, stream)
+        return stream
     tab, tab_t = gru_tables(gru), gru_tables_t(gru)
     hit = _stream_cache.get(gru)
     if hit is not None and hit[0] is tab and hit[1] is tab_t:
         return hit[2]
-    if _lib.lib().fs_ptf_gru_stream_layout() == 2:          # the 16-pair backward kernel's stream (built from the parameters)
-        stream = _gru_operand_stream16(gru)
-        _stream_cache[gru] = (tab, tab_t, stream)
-        return stream
     o = []
     for s in range(32):
         o += [_KTN2 + s, _KTN2 + 32 + s]

@@ -360,6 +360,10 @@ int fs_ptf_fold(int32_t V, int32_t h, int32_t w, const float* lat, const float* 
  * operand order, fs_ptf_gru_table_rows() rows of 64 floats (layout: csrc/ptf_gru.hip; builder:
  * freesplat_amd/ptf.py:gru_tables). */
 int32_t fs_ptf_gru_table_rows(void);
+/* Layout of `tables` (ABI 6): 0 = the 32-pair kernels' (operand rows of the forward in consumption order, then 192 bias rows); 1 = the
+ * 16-pair forward kernel's (the default; FS_GRU_FWD16=0 or FS_GRU_BWD16=0 selects 0): its 696 operand rows of v_mfma_f32_16x16x4_f32
+ * padded to whole chunks and interleaved by quads as operand-stream layout 2, then six rows = the bias vectors. */
+int32_t fs_ptf_gru_table_layout(void);
 int fs_ptf_gru_forward(int32_t n, const float* cat, const float* tables, float* fused, void* stream);
 
 /* Backward of the GRU on the fp32 matrix cores (autograd of networks.py:201-214 w.r.t. its input rows): the forward
