@@ -228,69 +228,88 @@ _KTN2, _KTN1H, _KTN1C, _KTR2, _KTZ2, _KTR1, _KTZ1 = 0, 64, 128, 256, 320, 384, 5
 _stream_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
-def _gru_operand_stream16(gru: "GRU", forward_only: bool = False) -> Tensor:
-    """Operand stream of csrc/ptf_gru.hip:ptf_gru_bwd16_kernel (fs_ptf_gru_stream_layout() = 2): one row of 64 lanes per
-    v_mfma_f32_16x16x4_f32 in consumption order, lane l = (i = l & 15, kk = l >> 4) holding A[i][kk] --
+_stream16_index_cache: dict = {}
+
+
+def _gru_stream16_index(forward_only: bool) -> "np.ndarray":
+    """For every float of the 16-pair kernels' operand stream, its position in the concatenation of the GRU's 12 parameter
+    tensors (flattened, in _gru_params order) followed by one zero -- the stream is ONE gather of that vector.  Rows of 64 lanes
+    per v_mfma_f32_16x16x4_f32 in consumption order, lane l = (i = l & 15, kk = l >> 4) holding A[i][kk] --
       forward layer, output block ob:     W[16 ob + i][input of k-step s for quarter kk]
-      transposed layer, feature block ob: W[unit of k-step s for quarter kk][feature 16 ob + i]      (0 where there is none)
+      transposed layer, feature block ob: W[unit of k-step s for quarter kk][feature 16 ob + i]      (the zero where there is none)
     where a 64-unit activation is consumed register by register of the accumulator layout: k-step s <-> units
-    16 (s >> 2) + 4 kk + (s & 3).  696 forward + 704 transposed rows, padded to whole ring chunks and interleaved by quads of rows
-    as layout 1; then the six bias vectors (64 floats each).  forward_only: the 16-pair FORWARD kernel's tables
-    (fs_ptf_gru_table_layout() = 1) -- the first 696 rows, packaged the same way."""
+    16 (s >> 2) + 4 kk + (s & 3).  696 forward + 704 transposed rows, padded to whole ring chunks and interleaved by quads of rows;
+    then the six bias vectors (64 floats each).  forward_only: the first 696 rows, packaged the same way."""
+    import numpy as np
+    sizes = [int(np.prod(sh)) for sh in GRU_PARAM_SHAPES]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    zero = int(off[-1])
+    R1, BR1, R2, BR2, Z1, BZ1, Z2, BZ2, N1, BN1, N2, BN2 = range(12)
+    ncols = {m: GRU_PARAM_SHAPES[m][1] for m in (R1, R2, Z1, Z2, N1, N2)}
+    lane = np.arange(64)
+    i, kk = lane & 15, lane >> 4
+    rows = []
+
+    def at(m, r, col):
+        ok = (col >= 0) & (col < ncols[m])
+        return np.where(ok, off[m] + r * ncols[m] + np.where(ok, col, 0), zero)
+
+    def fwd(m, ob, col):                      # col [64]: input index per lane (outside the matrix -> the zero)
+        return at(m, 16 * ob + i, col)
+
+    def acc(s):                               # units of k-step s, per lane
+        return 16 * (s >> 2) + 4 * kk + (s & 3)
+
+    def tr(m, ob, s, col_of_feature=None):    # out row = feature 16 ob + i, k = unit acc(s)
+        f = 16 * ob + i
+        return at(m, acc(s), f if col_of_feature is None else col_of_feature(f))
+
+    for s in range(44):                       # layer 1 of r and z: feature 44 kk + s
+        col = 44 * kk + s
+        rows += [fwd(R1, ob, col) for ob in range(4)] + [fwd(Z1, ob, col) for ob in range(4)]
+    for s in range(16):                       # layer 2 of r and z
+        rows += [fwd(R2, ob, acc(s)) for ob in range(4)] + [fwd(Z2, ob, acc(s)) for ob in range(4)]
+    for s in range(16):                       # mlp_n layer 1: r * hid ...
+        rows += [fwd(N1, ob, acc(s)) for ob in range(4)]
+    for s in range(22):                       # ... then x | xe: row feature 88 + 22 kk + s = mlp_n input 64 + 22 kk + s
+        rows += [fwd(N1, ob, 64 + 22 * kk + s) for ob in range(4)]
+    for s in range(16):                       # mlp_n layer 2
+        rows += [fwd(N2, ob, acc(s)) for ob in range(4)]
+    assert len(rows) == 696
+    if not forward_only:
+        n1_from_cat = lambda f: np.where(f >= 88, f - 24, -1)
+        for s in range(16):
+            rows += [tr(N2, ob, s) for ob in range(4)]
+        for s in range(16):
+            rows += [tr(N1, ob, s) for ob in range(4)] + [tr(N1, ob, s, n1_from_cat) for ob in range(5, 11)]
+        for s in range(16):
+            rows += [tr(R2, ob, s) for ob in range(4)] + [tr(Z2, ob, s) for ob in range(4)]
+        for s in range(16):
+            rows += [tr(R1, ob, s) for ob in range(11)] + [tr(Z1, ob, s) for ob in range(11)]
+        assert len(rows) == 1400
+    c = _lib.lib().fs_ptf_gru_stream_chunk_rows()
+    n_rows = (_lib.lib().fs_ptf_gru_table_rows() if forward_only else _lib.lib().fs_ptf_gru_stream_rows()) - 6
+    assert n_rows % c == 0 and n_rows >= len(rows) and c % 16 == 0
+    ops = np.full((n_rows, 64), zero, dtype=np.int64)
+    ops[:len(rows)] = np.stack(rows)
+    ops = ops.reshape(n_rows // c, 4, c // 16, 4, 64).transpose(0, 1, 2, 4, 3).reshape(n_rows, 64)
+    bias = np.stack([off[m] + lane for m in (BR1, BZ1, BR2, BZ2, BN1, BN2)])
+    return np.concatenate([ops, bias]).astype(np.int64)
+
+
+def _gru_operand_stream16(gru: "GRU", forward_only: bool = False) -> Tensor:
+    """Operand stream of csrc/ptf_gru.hip:ptf_gru_bwd16_kernel (fs_ptf_gru_stream_layout() = 2) or, forward_only, the tables of
+    ptf_gru16_kernel (fs_ptf_gru_table_layout() = 1): one concatenation + one gather of the parameters through the index
+    _gru_stream16_index describes (built once per device: a training loop rebuilds the stream after every optimizer step)."""
     params = _gru_params(gru)
     dev = params[0].device
+    key = (str(dev), bool(forward_only))
+    idx = _stream16_index_cache.get(key)
+    if idx is None:
+        idx = _stream16_index_cache[key] = torch.from_numpy(_gru_stream16_index(forward_only)).to(dev)
     with torch.no_grad():
-        Wr1, br1, Wr2, br2, Wz1, bz1, Wz2, bz2, Wn1, bn1, Wn2, bn2 = [q.detach().float() for q in params]
-        lane = torch.arange(64, device=dev)
-        i, kk = lane & 15, lane >> 4
-        rows = []
-
-        def pad(W):
-            return torch.cat([W, torch.zeros(W.shape[0], 1, device=dev)], dim=1)
-
-        def fwd(W, ob, col):                      # col [64]: input index per lane (outside the matrix -> 0)
-            c = torch.where((col >= 0) & (col < W.shape[1]), col, torch.full_like(col, W.shape[1]))
-            return pad(W)[16 * ob + i, c]
-
-        def acc(s):                               # units of k-step s, per lane
-            return 16 * (s >> 2) + 4 * kk + (s & 3)
-
-        def tr(W, ob, s, col_of_feature=None):    # out row = feature 16 ob + i, k = unit acc(s)
-            f = 16 * ob + i
-            col = f if col_of_feature is None else col_of_feature(f)
-            c = torch.where((col >= 0) & (col < W.shape[1]), col, torch.full_like(col, W.shape[1]))
-            return pad(W)[acc(s), c]
-
-        for s in range(44):                       # layer 1 of r and z: feature 44 kk + s
-            col = 44 * kk + s
-            rows += [fwd(Wr1, ob, col) for ob in range(4)] + [fwd(Wz1, ob, col) for ob in range(4)]
-        for s in range(16):                       # layer 2 of r and z
-            rows += [fwd(Wr2, ob, acc(s)) for ob in range(4)] + [fwd(Wz2, ob, acc(s)) for ob in range(4)]
-        for s in range(16):                       # mlp_n layer 1: r * hid ...
-            rows += [fwd(Wn1, ob, acc(s)) for ob in range(4)]
-        for s in range(22):                       # ... then x | xe: row feature 88 + 22 kk + s = mlp_n input 64 + 22 kk + s
-            rows += [fwd(Wn1, ob, 64 + 22 * kk + s) for ob in range(4)]
-        for s in range(16):                       # mlp_n layer 2
-            rows += [fwd(Wn2, ob, acc(s)) for ob in range(4)]
-        assert len(rows) == 696
-        n1_from_cat = lambda f: torch.where(f >= 88, f - 24, torch.full_like(f, -1))
-        for s in range(16):
-            rows += [tr(Wn2, ob, s) for ob in range(4)]
-        for s in range(16):
-            rows += [tr(Wn1, ob, s) for ob in range(4)] + [tr(Wn1, ob, s, n1_from_cat) for ob in range(5, 11)]
-        for s in range(16):
-            rows += [tr(Wr2, ob, s) for ob in range(4)] + [tr(Wz2, ob, s) for ob in range(4)]
-        for s in range(16):
-            rows += [tr(Wr1, ob, s) for ob in range(11)] + [tr(Wz1, ob, s) for ob in range(11)]
-        assert len(rows) == 1400
-        rows = torch.stack(rows if not forward_only else rows[:696])
-        c = _lib.lib().fs_ptf_gru_stream_chunk_rows()
-        n_rows = (_lib.lib().fs_ptf_gru_table_rows() if forward_only else _lib.lib().fs_ptf_gru_stream_rows()) - 6
-        assert n_rows % c == 0 and n_rows >= rows.shape[0] and c % 16 == 0
-        ops = torch.zeros(n_rows, 64, device=dev)
-        ops[:rows.shape[0]] = rows
-        ops = ops.view(n_rows // c, 4, c // 16, 4, 64).permute(0, 1, 2, 4, 3).contiguous().view(n_rows, 64)
-        return torch.cat([ops, torch.stack([br1, bz1, br2, bz2, bn1, bn2])]).contiguous()
+        flat = torch.cat([q.detach().float().reshape(-1) for q in params] + [torch.zeros(1, device=dev)])
+        return flat[idx]
 
 
 def gru_operand_stream(gru: "GRU") -> Tensor:
