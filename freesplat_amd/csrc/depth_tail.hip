@@ -31,13 +31,7 @@ __global__ __launch_bounds__(256) void depth_expect_kernel(int B, int D, int hw,
     const int b = (int)(ee / hw), p = (int)(ee % hw);
     const float* l = logits + (size_t)b * D * hw + p;
     float m = -3.0e38f, s = 0.0f, acc = 0.0f;
-    for (int d0 = w; d0 < D; d0 += 32) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int d = d0 + 4 * i;
-            v[i] = d < D ? l[(size_t)d * hw] : -3.0e38f;
-        }
+    auto batch = [&](const float (&v)[8], int d0) __attribute__((always_inline)) {
         float mb = v[0];
 #pragma unroll
         for (int i = 1; i < 8; ++i) mb = fmaxf(mb, v[i]);
@@ -52,6 +46,33 @@ __global__ __launch_bounds__(256) void depth_expect_kernel(int B, int D, int hw,
                 s += ex;
                 acc += cand[d] * ex;
             }
+        }
+    };
+    if (D <= 128) {
+        // the wavefront's 32 planes of its 64 pixels: 32 independent loads in flight, then four rescaling batches (round 6; before:
+        // each batch of 8 waited for its own loads -- four exposed memory latencies per workgroup)
+        float v[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int d = w + 32 * k + 4 * i;                  // (past D: the last plane's address, the value replaced)
+                const float x = l[(size_t)min(d, D - 1) * hw];
+                v[k][i] = d < D ? x : -3.0e38f;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (w + 32 * k < D) batch(v[k], w + 32 * k);
+    } else {
+        for (int d0 = w; d0 < D; d0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int d = d0 + 4 * i;
+                v[i] = d < D ? l[(size_t)d * hw] : -3.0e38f;
+            }
+            batch(v, d0);
         }
     }
     s_m[w][lane] = m; s_s[w][lane] = s; s_a[w][lane] = acc;
@@ -143,21 +164,38 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
     const float* l = logits + (size_t)b * D * hw + pci;
     float best = -1.0f;
     int bi = 0;
+    // the fill thread's 16 logits of the NEXT chunk are loaded while the workgroup blends the taps of this one (round 6; before: loads
+    // issued after the barrier and waited for before the next -- one exposed memory latency per 32 planes and workgroup)
+    float nv[kUpPlanes / 2];
+    auto issue = [&](int d0) __attribute__((always_inline)) {
+        // (guarded loads, measured: unconditional loads -- threads without a patch pixel reading pixel 0 of the image -- made one L2
+        // channel the bottleneck, 31 -> 42 us at the native size; one branch around the batch with clamped planes: 35 us)
+#pragma unroll
+        for (int k = 0; k < kUpPlanes / 8; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = d0 + 4 * (2 * k + par) + e;
+                nv[4 * k + e] = (fill && d < D) ? l[(size_t)d * hw] : -3.0e38f;     // (exp2(-huge) = 0: never a new maximum)
+            }
+    };
+    issue(0);
     for (int d0 = 0; d0 < D; d0 += kUpPlanes) {
         __syncthreads();  // (the previous chunk's taps are read)
-        const int nd = min(kUpPlanes, D - d0);
         if (fill) {
 #pragma unroll
             for (int k = 0; k < kUpPlanes / 8; ++k) {
                 const int dd = 4 * (2 * k + par);          // planes dd .. dd + 3 of the chunk
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = dd + e < nd ? __builtin_amdgcn_exp2f((l[(size_t)(d0 + dd + e) * hw] - pm) * kLog2e) * prs : 0.0f;
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_exp2f((nv[4 * k + e] - pm) * kLog2e) * prs;
                 *(float4*)(s_p + pc * kUpRow + dd) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (d0 + kUpPlanes < D) issue(d0 + kUpPlanes);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        const int nd = min(kUpPlanes, D - d0);
         for (int dd = 0; dd < nd; dd += 4) {           // (planes past nd hold zeros: never a new maximum)
             const float4 a = *(const float4*)(t00 + dd), bq = *(const float4*)(t01 + dd);
             const float4 c = *(const float4*)(t10 + dd), e = *(const float4*)(t11 + dd);
@@ -194,7 +232,8 @@ __global__ __launch_bounds__(256) void depth_upsample_kernel(int B, int D, int h
 // (Rounds 2 - 3: memset of a dense g_prob, a scatter kernel with 8 global atomics per fine pixel, then one thread per
 // coarse pixel reading logits and g_prob twice: 12 + 89 + 103 us for 2 x 128 x 192 x 256.)
 constexpr int kBwdPlanes = 128;
-__global__ __launch_bounds__(256) void depth_tail_bwd_kernel(int B, int D, int h2, int w2, const float* __restrict__ logits,
+template <bool ONE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void depth_tail_bwd_kernel(int B, int D, int h2, int w2, const float* __restrict__ logits,
                                                              const float* __restrict__ cand, int log_planes,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ coarse,
@@ -206,7 +245,7 @@ __global__ __launch_bounds__(256) void depth_tail_bwd_kernel(int B, int D, int h
                                                              const float* __restrict__ g_map,
                                                              const float* __restrict__ g_w, float* __restrict__ g_logits)
 {
-    __shared__ float s_gp[kBwdPlanes * 64];
+    __shared__ __attribute__((aligned(16))) float s_gp[kBwdPlanes * 64];
     __shared__ float s_gE[64], s_dot[4][64];
     const int hw = h2 * w2, H = 2 * h2, W = 2 * w2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -219,26 +258,42 @@ __global__ __launch_bounds__(256) void depth_tail_bwd_kernel(int B, int D, int h
 
     // the fine pixels that tap this coarse pixel: wavefront w looks at 9 of the 36 candidates
     auto gather = [&](int c0, bool with_map) {
-        for (int k = threadIdx.x; k < kBwdPlanes * 64; k += 256) s_gp[k] = 0.0f;
+        for (int k = threadIdx.x; k < kBwdPlanes * 16; k += 256) ((float4*)s_gp)[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         __syncthreads();
         if (live) {
-            float gEacc = 0.0f;
+            // (round 6: the weights first, then every load of the nine candidates in flight together -- the loop used to take them one
+            // dependent load at a time behind its `continue`s)
+            float wt[9], gw[9], gm[9], dm[9];
+            int am[9];
+            int f[9];                              // (inside image b: H W < 2^31)
+            const size_t fb = (size_t)b * H * W;
+#pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const int idx = 9 * w + i;
                 const int fy = 2 * Y + idx / 6 - 2, fx = 2 * X + idx % 6 - 2;
-                if (fy < 0 || fy >= H || fx < 0 || fx >= W) continue;
-                const Bilin q = bilin_x2(fy, fx, h2, w2);
-                const float wt = (q.i00 == p ? q.w00 : 0.0f) + (q.i01 == p ? q.w01 : 0.0f) + (q.i10 == p ? q.w10 : 0.0f) +
-                                 (q.i11 == p ? q.w11 : 0.0f);
-                if (wt == 0.0f) continue;
-                const size_t f = ((size_t)b * H + fy) * W + fx;
-                if (with_map && g_map) {
-                    const float dm = depth_map[f];
-                    gEacc += wt * (log_planes ? g_map[f] * dm : -g_map[f] * dm * dm);   // d exp(f) = exp(f); d(1/f) = -1/f^2
-                }
+                const bool inside = fy >= 0 && fy < H && fx >= 0 && fx < W;
+                const int cy = min(max(fy, 0), H - 1), cx = min(max(fx, 0), W - 1);
+                const Bilin q = bilin_x2(cy, cx, h2, w2);
+                wt[i] = inside ? (q.i00 == p ? q.w00 : 0.0f) + (q.i01 == p ? q.w01 : 0.0f) + (q.i10 == p ? q.w10 : 0.0f) +
+                                     (q.i11 == p ? q.w11 : 0.0f)
+                               : 0.0f;
+                f[i] = cy * W + cx;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                am[i] = g_w ? argmax[fb + f[i]] : 0;
+                gw[i] = g_w ? g_w[fb + f[i]] : 0.0f;
+                dm[i] = (with_map && g_map) ? depth_map[fb + f[i]] : 0.0f;
+                gm[i] = (with_map && g_map) ? g_map[fb + f[i]] : 0.0f;
+            }
+            float gEacc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (wt[i] == 0.0f) continue;
+                if (with_map && g_map) gEacc += wt[i] * (log_planes ? gm[i] * dm[i] : -gm[i] * dm[i] * dm[i]);   // d exp(f) = exp(f); d(1/f) = -1/f^2
                 if (g_w) {
-                    const int d = argmax[f] - c0;
-                    if (d >= 0 && d < kBwdPlanes) atomicAdd(&s_gp[d * 64 + lane], wt * g_w[f]);
+                    const int d = am[i] - c0;
+                    if (d >= 0 && d < kBwdPlanes) atomicAdd(&s_gp[d * 64 + lane], wt[i] * gw[i]);
                 }
             }
             if (with_map && g_map) atomicAdd(&s_gE[lane], gEacc);
@@ -251,6 +306,44 @@ __global__ __launch_bounds__(256) void depth_tail_bwd_kernel(int B, int D, int h
     const float* l = logits + (size_t)b * D * hw + p;
     const int nchunks = (D + kBwdPlanes - 1) / kBwdPlanes;
     float dot = 0.0f;
+    if constexpr (ONE) {
+        // D <= 128: this wavefront's 32 planes of the pixel are loaded ONCE, all 32 loads in flight while the workgroup clears
+        // and gathers g_prob, and the probabilities stay in registers between the dot product and the output (round 6; before:
+        // two passes over the logits with an expf each, the first load issued only after the gather's barrier)
+        float pd[kBwdPlanes / 4];
+#pragma unroll
+        for (int j = 0; j < kBwdPlanes / 4; ++j) {
+            const int d = w + 4 * j;
+            const float x = l[(size_t)min(d, D - 1) * hw];         // (unconditional: planes past D re-read the last one)
+            pd[j] = d < D ? x : -3.0e38f;                          // (exp(-huge) = 0)
+        }
+        if (up) gather(0, true); else __syncthreads();             // (else: s_gE's zeros)
+#pragma unroll
+        for (int j = 0; j < kBwdPlanes / 4; ++j) pd[j] = expf(pd[j] - m) * rs;
+        if (g_w) {
+#pragma unroll
+            for (int j = 0; j < kBwdPlanes / 4; ++j) dot += pd[j] * s_gp[(w + 4 * j) * 64 + lane];
+            s_dot[w][lane] = dot;
+            __syncthreads();
+            dot = (s_dot[0][lane] + s_dot[1][lane]) + (s_dot[2][lane] + s_dot[3][lane]);
+        }
+        const float E = coarse[ee];
+        float gE = s_gE[lane];
+        if (g_coarse) gE += g_coarse[ee];
+        if (g_depth) gE += log_planes ? g_depth[ee] * depth[ee] : -g_depth[ee] * depth[ee] * depth[ee];
+        float* go = g_logits + (size_t)b * D * hw + p;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < kBwdPlanes / 4; ++j) {
+                const int d = w + 4 * j;
+                if (d < D) {
+                    const float gpd = g_w ? s_gp[d * 64 + lane] : 0.0f;
+                    go[(size_t)d * hw] = pd[j] * ((cand[d] - E) * gE + gpd - dot);
+                }
+            }
+        }
+        return;
+    }
     if (up) {
         for (int c = 0; c < nchunks; ++c) {
             gather(c * kBwdPlanes, c == 0);
@@ -259,6 +352,7 @@ __global__ __launch_bounds__(256) void depth_tail_bwd_kernel(int B, int D, int h
 #pragma unroll 8
                 for (int d = c * kBwdPlanes + w; d < dend; d += 4)
                     dot += expf(l[(size_t)d * hw] - m) * rs * s_gp[(d - c * kBwdPlanes) * 64 + lane];
+                if (c + 1 < nchunks) __syncthreads();              // (the next gather clears s_gp: every wavefront must have read it)
             }
         }
         if (g_w) {
@@ -331,9 +425,11 @@ FS_API int fs_depth_tail_backward(int32_t B, int32_t D, int32_t h2, int32_t w2, 
     hipStream_t st = (hipStream_t)stream_;
     const long long n = (long long)B * h2 * w2;
     ScopedStage prof_(kStEncoderTail, st);
-    hipLaunchKernelGGL(depth_tail_bwd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, B, D, h2, w2, logits,
-                       candidates, log_planes, stats, coarse, depth, depth_map, argmax, g_coarse, g_depth, g_map, g_weights,
-                       g_logits);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, B, D, h2, w2, logits, candidates, log_planes,
+                           stats, coarse, depth, depth_map, argmax, g_coarse, g_depth, g_map, g_weights, g_logits);
+    };
+    if (D <= kBwdPlanes) go(depth_tail_bwd_kernel<true>); else go(depth_tail_bwd_kernel<false>);
     FS_CHECK_LAUNCH("depth_tail_backward");
     return FS_OK;
 }
