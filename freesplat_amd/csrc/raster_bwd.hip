@@ -346,8 +346,11 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float 
 // registers before the single write (per view only the 48-byte record, the tile rect and the 48-byte screen-space
 // gradient row are read).  view / proj [V,16], campos [V,3], tanfov [V,2] | NULL, scale [V] | NULL; geom and grad
 // hold V buffers geom_stride / grad_stride bytes apart.  `accumulate` adds to what the outputs already hold.
-// (two wavefronts per SIMD: 256 registers + 59 spilled dwords beat one wavefront at 310 registers by 13 %)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void preprocess_bwd_kernel(
+// (two wavefronts per SIMD beat one wavefront at 310 registers by 13 %)
+#ifndef FS_PBWD_WAVES
+#define FS_PBWD_WAVES 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_PBWD_WAVES, FS_PBWD_WAVES))) void preprocess_bwd_kernel(
     fs_raster_dims d, int V, const float* __restrict__ means3D, const float* __restrict__ cov3D,
     const float* __restrict__ shs, const float* __restrict__ opacities, const float* __restrict__ view_all, const float* __restrict__ proj_all,
     const float* __restrict__ campos_all, const float* __restrict__ tanfov_dev,
@@ -382,18 +385,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int k = 0; k < 6; ++k) c0[k] = cov_full ? cov3D[9 * (size_t)i + kTriu[k]] : cov3D[6 * (size_t)i + k];
         // (the blend summed the moments of dL/dalpha * G: the Gaussian's opacity completes w = dL/dG * G -- see render_bwd)
         const float opac = opacities[i];
-        float shbuf[48];
+        // the Gaussian's SH coefficients wait in the thread's own slots of the LDS staging area (idle until the gradients are staged
+        // there after the view loop; row stride M*3 floats is odd for every degree: conflict-free) instead of 48 registers -- with the
+        // 48 gradient sums they spilled 59 dwords at two wavefronts per SIMD (round 6)
+        float* const shl = lds + t * per_sh;
         if (have_sh) {
             if (d.flags & FS_RASTER_SH_FP16) {
                 const _Float16* hsrc = (const _Float16*)shs + (size_t)i * per_sh;
 #pragma unroll
-                for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? (float)hsrc[sh_cm ? (k % 3) * d.M + k / 3 : k] : 0.0f;
+                for (int k = 0; k < 48; ++k) if (k < per_sh) shl[k] = (float)hsrc[sh_cm ? (k % 3) * d.M + k / 3 : k];
             } else {
                 const float* fsrc = shs + (size_t)i * per_sh;
 #pragma unroll
-                for (int k = 0; k < 48; ++k) shbuf[k] = k < per_sh ? fsrc[sh_cm ? (k % 3) * d.M + k / 3 : k] : 0.0f;
+                for (int k = 0; k < 48; ++k) if (k < per_sh) shl[k] = fsrc[sh_cm ? (k % 3) * d.M + k / 3 : k];
             }
         }
+        // the NEXT view's rect, gradient row and clamp bits are loaded while this view's gradients are formed (round 6: with two
+        // wavefronts per SIMD every view's dependent loads were an exposed round trip -- V of them per thread)
+        auto view_rows = [&](int vi, ushort4& rc, float4& ga0, float4& ga1, float4& ga2, uint8_t& cb) __attribute__((always_inline)) {
+            const GeomView g = geom_view((void*)(geom_base + geom_stride * vi), d.N > 0 ? d.N : 1);
+            const float4* gp = (const float4*)((const float*)(grad_base + grad_stride * vi) + (size_t)i * kGradStride);
+            rc = g.rect[i];
+            ga0 = gp[0]; ga1 = gp[1]; ga2 = gp[2];
+            cb = have_sh ? g.clamp[i] : (uint8_t)0;
+        };
+        ushort4 rc_n; float4 gn0, gn1, gn2; uint8_t cb_n;
+        view_rows(0, rc_n, gn0, gn1, gn2, cb_n);
       for (int vi = 0; vi < V; ++vi) {
         const float* view = view_all + 16 * vi;
         const float* proj = proj_all + 16 * vi;
@@ -401,12 +418,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float tanfovx = tanfov_dev ? tanfov_dev[2 * vi] : d.tanfovx;
         const float tanfovy = tanfov_dev ? tanfov_dev[2 * vi + 1] : d.tanfovy;
         const float wscale = scale_dev ? scale_dev[vi] : 1.0f;
-        const GeomView g = geom_view((void*)(geom_base + geom_stride * vi), d.N > 0 ? d.N : 1);
-        const float* grad = (const float*)(grad_base + grad_stride * vi);
         float gm[3] = {0, 0, 0}, gcov[6] = {0, 0, 0, 0, 0, 0};
-        const ushort4 rc = g.rect[i];
+        const ushort4 rc = rc_n;
+        const float ga[12] = {gn0.x, gn0.y, gn0.z, gn0.w, gn1.x, gn1.y, gn1.z, gn1.w, gn2.x, gn2.y, gn2.z, gn2.w};
+        const uint8_t cb = cb_n;
+        if (vi + 1 < V) view_rows(vi + 1, rc_n, gn0, gn1, gn2, cb_n);
         if (rc.z > rc.x && rc.w > rc.y) {
-            const float* ga = grad + (size_t)i * kGradStride;
             // the five moment sums of the blend (S_x, S_y, S_xx, S_xy, S_yy)
             const float S0 = ga[0] * opac, S1 = ga[1] * opac, S2 = ga[2] * opac, S3 = ga[3] * opac, S4 = ga[4] * opac;
             float3 p = p0;
@@ -486,14 +503,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (!have_sh) {
                 acol[0] += ga[6]; acol[1] += ga[7]; acol[2] += ga[8];
             } else {
-                const uint8_t cb = g.clamp[i];
                 float gr[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) gr[ch] = ((cb >> ch) & 1) ? 0.0f : ga[6 + ch];
                 const float dox = p.x - campos[0], doy = p.y - campos[1], doz = p.z - campos[2];
                 const float len = sqrtf(dox * dox + doy * doy + doz * doz);
                 const float x = dox / len, y = doy / len, z = doz / len;
-                const float* sh = shbuf;
+                const float* sh = shl;
                 float gdv[3];
                 switch (d.sh_degree) {
                     case 0: sh_backward<0>(sh, x, y, z, gr, gsh, gdv); break;
