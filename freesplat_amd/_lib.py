@@ -87,6 +87,9 @@ SIGNATURES = {
     "fs_ptf_gru_stream_chunk_rows": (C.c_int32, []),
     "fs_ptf_gru_side_cols": (C.c_int32, []),
     "fs_ptf_gru_backward": (C.c_int, [C.c_int32] + [_VP] * 7),
+    "fs_ptf_gru_backward_saved": (C.c_int, [C.c_int32] + [_VP] * 7),
+    "fs_ptf_gru_act_cols": (C.c_int32, []),
+    "fs_ptf_gru_stream_t_rows": (C.c_int32, []),
     "fs_ptf_gru_grad_floats": (C.c_int32, []),
     "fs_ptf_gru_weight_grads_bytes": (C.c_size_t, [C.c_int32]),
     "fs_ptf_gru_weight_grads": (C.c_int, [C.c_int32] + [_VP] * 5),
@@ -98,6 +101,7 @@ SIGNATURES = {
                                       + [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _VP, C.c_int32, C.c_int32, C.c_int32]),
     "fs_ptf_fold_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
     "fs_ptf_fold_step": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 14 + [C.c_float] + [_VP] * 10),
+    "fs_ptf_fold_step_save": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 14 + [C.c_float] + [_VP] * 12),
     "fs_ptf_fold_bytes": (C.c_size_t, [C.c_int32] * 3),
     "fs_ptf_fold": (C.c_int, [C.c_int32] * 3 + [_VP] * 8 + [C.c_float] + [_VP] * 2 + [C.POINTER(C.c_void_p)] * 2 + [_VP] * 2),
     "fs_ptf_cameras": (C.c_int, [C.c_int32] * 3 + [_VP] * 5),

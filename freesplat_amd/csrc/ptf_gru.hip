@@ -120,7 +120,9 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 struct GruGather {
     const long long *fuse_idx, *fuse_pix;
     const float *G, *R, *O, *g_i, *rho_i, *om_i;
+    float *side = nullptr, *act = nullptr;      // ptf_gru16_kernel<true, true>: where the training forward leaves what the backward needs
 };
+constexpr int kAct = 192;   // floats per pair the saving forward keeps beside the `side` columns: r, z (gates), q = tanh(.)
 // (two workgroups per CU: at one -- 407 registers if the compiler is left alone -- the fold is 7 % slower)
 template <bool GATHER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ptf_gru_kernel(int n, const int32_t* __restrict__ counts,
@@ -567,15 +569,18 @@ static bool gru_bwd16()
 // (transposed layers; the 176 features of dcat are 11 blocks of 16) = 1 400, consumed strictly in order from the quad-interleaved
 // stream freesplat_amd/ptf.py:gru_operand_stream builds for fs_ptf_gru_stream_layout() = 2; the six bias vectors follow it.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kS16Used = 696 + 704, kS16Chunks = (kS16Used + kCh - 1) / kCh;
+constexpr int kS16Used = 696 + 704, kS16Chunks = (kS16Used + kCh - 1) / kCh, kT16Chunks = (704 + kCh - 1) / kCh;
 #define FS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #ifndef FS_GRU_BWD16_WAVES
 #define FS_GRU_BWD16_WAVES 2
 #endif
+// SAVED: the training forward (ptf_gru16_kernel<true, true>) left relu(r1), relu(z1), relu(n1), r * hid in `side` (columns 6 .. 9) and the
+// gates r, z, q in `act`: no re-run of the forward, `stream` = the 704 transposed rows alone (kT16Chunks chunks).
+template <bool SAVED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD16_WAVES, FS_GRU_BWD16_WAVES))) void ptf_gru_bwd16_kernel(
     int n, const float* __restrict__ cat, const float* __restrict__ stream, const float* __restrict__ g_fused,
-    float* __restrict__ dcat, float* __restrict__ side)
+    float* __restrict__ dcat, float* __restrict__ side, const float* __restrict__ act)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = blockIdx.x * 4 + wave;
@@ -583,8 +588,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
     const int t = grp * 16 + pn;
     const bool live = t < n;             // (a wavefront beyond n stays for the barriers, computes on row 0, stores nothing)
     const size_t tr = (size_t)(live ? t : 0);
-    FS_RING_SETUP(stream, kS16Chunks, kS16Used, 0, true)
-    const float* const bias = stream + (size_t)kS16Chunks * kCh * 64;     // [6][64]: br1, bz1, br2, bz2, bn1, bn2
+    FS_RING_SETUP(stream, (SAVED ? kT16Chunks : kS16Chunks), (SAVED ? kS16Used - 696 : kS16Used), 0, true)
+    const float* const bias = stream + (size_t)kS16Chunks * kCh * 64;     // [6][64]: br1, bz1, br2, bz2, bn1, bn2 (!SAVED)
+    // (the forward's lane-native layout; a wavefront beyond n reads group 0, the last group's dead lanes rows the caller padded to 16)
+    const float* const ac = SAVED ? act + (size_t)(grp * 16 < n ? grp : 0) * (16 * kAct) + 4 * lane : nullptr;
     const float* row = cat + tr * 176;
     float* sd = side + tr * kSide;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -599,6 +606,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
     // ================= forward, keeping what the backward needs =================
     uint32_t mr = 0, mz = 0, mn = 0;     // ReLU masks of the three first layers, bit 4 blk + r
     f32x4 rr[4], zz[4], n1[4];
+    constexpr int p2 = 44 * 8 + 16 * 8;
+    if constexpr (SAVED) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) { rr[blk] = ld4(ac + (0 * 4 + blk) * 256); zz[blk] = ld4(ac + (1 * 4 + blk) * 256); }
+    } else {
     {
         f32x4 r1[4], z1[4];
 #pragma unroll
@@ -647,7 +659,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
 #pragma unroll
             for (int r = 0; r < 4; ++r) { rr[blk][r] = sigmoidf_(R[blk][r]); zz[blk][r] = sigmoidf_(Z[blk][r]); }
     }
-    constexpr int p2 = 44 * 8 + 16 * 8;
     {   // mlp_n layer 1: [r * hid (64) | x (64) | xe (24)]
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) n1[blk] = ld4(bias + 4 * 64 + 16 * blk + ao);
@@ -686,16 +697,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
             for (int blk = 0; blk < 4; ++blk) st4(sd + 8 * 64 + 16 * blk + ao, n1[blk]);
         }
     }
+    }
     constexpr int p3 = p2 + 64 + 88;
     f32x4 dN[4], dZ[4], dh[4];   // pre-activation gradients of the two output layers; gradient of hid through (1 - z) * hid
     {
         f32x4 N[4];
+        if constexpr (SAVED) {
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) N[blk] = ld4(bias + 5 * 64 + 16 * blk + ao);
+            for (int blk = 0; blk < 4; ++blk) N[blk] = ld4(ac + (2 * 4 + blk) * 256);       // q = tanh(.) itself
+        } else {
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+            for (int blk = 0; blk < 4; ++blk) N[blk] = ld4(bias + 5 * 64 + 16 * blk + ao);
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) N[ob] = FS_MFMA16(FS_AOP(p3 + s * 4 + ob), n1[s >> 2][s & 3], N[ob]);
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) N[ob] = FS_MFMA16(FS_AOP(p3 + s * 4 + ob), n1[s >> 2][s & 3], N[ob]);
+        }
         const float* go = g_fused + tr * 64;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
@@ -704,7 +721,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
             for (int r = 0; r < 4; ++r) {
                 const float gq = live ? gv[r] : 0.0f;
                 const float z = zz[blk][r], h = hid[blk][r];
-                const float qq = tanhf_(N[blk][r]);
+                const float qq = SAVED ? N[blk][r] : tanhf_(N[blk][r]);
                 dN[blk][r] = gq * z * (1.0f - qq * qq);
                 dZ[blk][r] = gq * (qq - h) * z * (1.0f - z);
                 dh[blk][r] = gq * (1.0f - z);
@@ -717,7 +734,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
     }
     static_assert(p3 + 64 == 696, "forward operand rows");
     // ================= transposed layers =================
-    constexpr int q0 = 696;
+    constexpr int q0 = SAVED ? 0 : 696;
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 C[11];                 // dcat: feature block ob = features 16 ob + 4 g + r
     f32x4 dR[4];
@@ -730,7 +747,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[blk][r] = (mn >> (4 * blk + r)) & 1u ? a[blk][r] : 0.0f;
+            for (int r = 0; r < 4; ++r) a[blk][r] = (SAVED || ((mn >> (4 * blk + r)) & 1u)) ? a[blk][r] : 0.0f;
+        if constexpr (SAVED) {      // (the masks from the kept post-ReLU activations: relu(x) > 0 <=> x > 0)
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const f32x4 kept = ld4(sd + 8 * 64 + 16 * blk + ao);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[blk][r] = kept[r] > 0.0f ? a[blk][r] : 0.0f;
+            }
+        }
         if (live) {
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) st4(sd + 4 * 64 + 16 * blk + ao, a[blk]);
@@ -775,9 +800,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
     for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            e[blk][r] = (mr >> (4 * blk + r)) & 1u ? e[blk][r] : 0.0f;
-            f[blk][r] = (mz >> (4 * blk + r)) & 1u ? f[blk][r] : 0.0f;
+            e[blk][r] = (SAVED || ((mr >> (4 * blk + r)) & 1u)) ? e[blk][r] : 0.0f;
+            f[blk][r] = (SAVED || ((mz >> (4 * blk + r)) & 1u)) ? f[blk][r] : 0.0f;
         }
+    if constexpr (SAVED) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const f32x4 kr = ld4(sd + 6 * 64 + 16 * blk + ao), kz = ld4(sd + 7 * 64 + 16 * blk + ao);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { e[blk][r] = kr[r] > 0.0f ? e[blk][r] : 0.0f; f[blk][r] = kz[r] > 0.0f ? f[blk][r] : 0.0f; }
+        }
+    }
     if (live) {
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) { st4(sd + 0 * 64 + 16 * blk + ao, e[blk]); st4(sd + 1 * 64 + 16 * blk + ao, f[blk]); }
@@ -795,7 +828,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_BWD1
 #pragma unroll
         for (int ob = 0; ob < 11; ++ob) C[ob] = FS_MFMA16(FS_AOP(q3 + s * 22 + 11 + ob), bz, C[ob]);
     }
-    static_assert(q3 + 16 * 22 == kS16Used, "operand rows");
+    static_assert(q3 + 16 * 22 == (SAVED ? kS16Used - 696 : kS16Used), "operand rows");
     (void)pos;
     if (live) {
         float* dc = dcat + tr * 176;
@@ -817,7 +850,7 @@ constexpr int kF16Chunks = (696 + kCh - 1) / kCh;
 #ifndef FS_GRU_FWD16_WAVES
 #define FS_GRU_FWD16_WAVES 3
 #endif
-template <bool GATHER>
+template <bool GATHER, bool SAVE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_FWD16_WAVES, FS_GRU_FWD16_WAVES))) void ptf_gru16_kernel(
     int n, const int32_t* __restrict__ counts, const float* __restrict__ cat, GruGather ga, const float* __restrict__ tab,
     float* __restrict__ fused, int out_after_keep)
@@ -839,6 +872,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_FWD1
     const long long gm = GATHER ? ga.fuse_idx[live ? t : 0] : 0, gp = GATHER ? ga.fuse_pix[live ? t : 0] : 0;
     const float* hrow = GATHER ? ga.G + gm * 64 : row;          // hid: 64 floats
     const float* xrow = GATHER ? ga.g_i + gp * 64 : row + 88;   // x: 64 floats (xe follows only in a materialised row)
+    // SAVE (the training fold): the hidden activations the weight gradients pair with go straight into the backward's `side` rows
+    // (columns 6 .. 9: relu(r1), relu(z1), relu(n1), r * hid) and the gates r, z, q into `act` -- ptf_gru_bwd16_kernel<true> then
+    // runs the transposed layers only (704 instead of 1 400 MFMAs per 16 pairs)
+    float* const sd = SAVE ? ga.side + (size_t)(live ? t : 0) * kSide : nullptr;
+    // act is private to the two 16-pair kernels, which share their lane map: [group of 16 pairs][r, z, q][blk][lane] float4 -- every
+    // store / load instruction moves 1 KB of consecutive bytes (a pair-major row would be 64-byte pieces 768 bytes apart)
+    float* const ac = SAVE ? ga.act + (size_t)grp * (16 * kAct) + 4 * lane : nullptr;
+    auto st4 = [&](float* p, const f32x4 v) __attribute__((always_inline)) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); };
 
     float xh[44];      // layer-1 inputs of this quarter: feature 44 g + s of the (virtual) row
     float pe[24];      // GATHER: he (quarters 0, 1) or xe (quarters 2, 3)
@@ -874,6 +915,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_FWD1
         for (int ob = 0; ob < 4; ++ob) z1[ob] = FS_MFMA16(FS_AOP(s * 8 + 4 + ob), xh[s], z1[ob]);
     }
     constexpr int p1 = 44 * 8;
+    if constexpr (SAVE) {
+        if (live) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                f32x4 a, b;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = fmaxf(r1[blk][r], 0.0f); b[r] = fmaxf(z1[blk][r], 0.0f); }
+                st4(sd + 6 * 64 + 16 * blk + ao, a); st4(sd + 7 * 64 + 16 * blk + ao, b);
+            }
+        }
+    }
     f32x4 R[4], Z[4];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) { R[blk] = ld4(bias + 2 * 64 + 16 * blk + ao); Z[blk] = ld4(bias + 3 * 64 + 16 * blk + ao); }
@@ -889,9 +941,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_FWD1
     f32x4 n1[4];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) n1[blk] = ld4(bias + 4 * 64 + 16 * blk + ao);
+    if constexpr (SAVE) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x4 h0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { R[blk][r] = sigmoidf_(R[blk][r]); h0[r] = R[blk][r] * hid[blk][r]; }
+            if (live) {
+                st4(ac + (0 * 4 + blk) * 256, R[blk]);
+                st4(sd + 9 * 64 + 16 * blk + ao, h0);
+            }
+        }
+    }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const float b = sigmoidf_(R[s >> 2][s & 3]) * hid[s >> 2][s & 3];
+        const float b = (SAVE ? R[s >> 2][s & 3] : sigmoidf_(R[s >> 2][s & 3])) * hid[s >> 2][s & 3];
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) n1[ob] = FS_MFMA16(FS_AOP(p2 + s * 4 + ob), b, n1[ob]);
     }
@@ -920,6 +984,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_FWD1
             for (int ob = 0; ob < 4; ++ob) n1[ob] = FS_MFMA16(FS_AOP(p2 + 64 + s * 4 + ob), xt[s], n1[ob]);
     }
     constexpr int p3 = p2 + 64 + 88;
+    if constexpr (SAVE) {
+        if (live) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                f32x4 a;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = fmaxf(n1[blk][r], 0.0f);
+                st4(sd + 8 * 64 + 16 * blk + ao, a);
+            }
+        }
+    }
     f32x4 N[4];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) N[blk] = ld4(bias + 5 * 64 + 16 * blk + ao);
@@ -936,13 +1011,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_FWD1
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
             float v[4];
+            f32x4 zs, qs;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float zz = sigmoidf_(Z[blk][r]);
                 const float qq = tanhf_(N[blk][r]);
                 v[r] = (1.0f - zz) * hid[blk][r] + zz * qq;
+                zs[r] = zz; qs[r] = qq;
             }
             *(float4*)(o + 16 * blk + ao) = make_float4(v[0], v[1], v[2], v[3]);
+            if constexpr (SAVE) { st4(ac + (1 * 4 + blk) * 256, zs); st4(ac + (2 * 4 + blk) * 256, qs); }
         }
     }
 }
@@ -972,11 +1050,16 @@ int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const flo
 
 int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fuse_idx, const long long* fuse_pix,
                           const float* G, const float* R, const float* O, const float* g_i, const float* rho_i,
-                          const float* om_i, const float* tables, float* fused, bool out_after_keep, hipStream_t st)
+                          const float* om_i, const float* tables, float* fused, bool out_after_keep, hipStream_t st,
+                          float* save_side, float* save_act)
 {
     if (n_max <= 0) return FS_OK;
-    const GruGather ga{fuse_idx, fuse_pix, G, R, O, g_i, rho_i, om_i};
-    if (gru_fwd16()) {
+    if ((save_side != nullptr) != (save_act != nullptr) || (save_side && !gru_fwd16())) return FS_ERR_INVALID_ARG;
+    const GruGather ga{fuse_idx, fuse_pix, G, R, O, g_i, rho_i, om_i, save_side, save_act};
+    if (gru_fwd16() && save_side) {
+        hipLaunchKernelGGL((ptf_gru16_kernel<true, true>), dim3((n_max + 63) / 64), dim3(256), 0, st, n_max, counts, (const float*)nullptr,
+                           ga, tables, fused, out_after_keep ? 1 : 0);
+    } else if (gru_fwd16()) {
         hipLaunchKernelGGL(ptf_gru16_kernel<true>, dim3((n_max + 63) / 64), dim3(256), 0, st, n_max, counts, (const float*)nullptr, ga,
                            tables, fused, out_after_keep ? 1 : 0);
     } else {
@@ -990,12 +1073,17 @@ int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fus
 
 
 int launch_ptf_gru_bwd(int n, const float* cat, const float* tables, const float* stream, const float* g_fused,
-                       float* dcat, float* side, hipStream_t st)
+                       float* dcat, float* side, hipStream_t st, const float* act = nullptr)
 {
     if (n <= 0) return FS_OK;
+    if (act && !gru_fwd16()) return FS_ERR_INVALID_ARG;
     if (gru_bwd16()) {      // 16 pairs per wavefront, 64 per workgroup
         const int groups = (n + 15) / 16;
-        hipLaunchKernelGGL(ptf_gru_bwd16_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, stream, g_fused, dcat, side);
+        if (act)
+            hipLaunchKernelGGL(ptf_gru_bwd16_kernel<true>, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, stream, g_fused, dcat, side, act);
+        else
+            hipLaunchKernelGGL(ptf_gru_bwd16_kernel<false>, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, stream, g_fused, dcat, side,
+                               (const float*)nullptr);
     } else {
         const int groups = (n + 31) / 32;
         hipLaunchKernelGGL(ptf_gru_bwd_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, n, cat, tables, stream, g_fused, dcat, side);
@@ -1297,6 +1385,23 @@ FS_API int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables,
     hipStream_t st = (hipStream_t)stream_;
     ScopedStage prof_(kStPtf, st);
     return launch_ptf_gru_bwd(n, cat, tables, operand_stream, g_fused, dcat, side, st);
+}
+
+// The saving training forward + the backward that re-runs nothing (round 6): fs_ptf_fold_step_save leaves, per fused pair, the `side`
+// columns 6 .. 9 and fs_ptf_gru_act_cols() floats of gates; fs_ptf_gru_backward_saved then takes `stream_t` = the
+// fs_ptf_gru_stream_t_rows() transposed operand rows (quad-interleaved like layout 2, no bias rows) and fills side's columns 0 .. 5.
+// 0 rows = not available in this build / mode (FS_GRU_FWD16=0 or FS_GRU_BWD16=0): use fs_ptf_gru_backward.
+FS_API int32_t fs_ptf_gru_act_cols(void) { return kAct; }
+FS_API int32_t fs_ptf_gru_stream_t_rows(void) { return gru_fwd16() ? kT16Chunks * kCh : 0; }
+FS_API int fs_ptf_gru_backward_saved(int32_t n, const float* cat, const float* stream_t, const float* act, const float* g_fused,
+                                     float* dcat, float* side, void* stream_)
+{
+    if (n < 0 || !gru_fwd16()) return FS_ERR_INVALID_ARG;
+    if (n == 0) return FS_OK;
+    if (!cat || !stream_t || !act || !g_fused || !dcat || !side) return FS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    ScopedStage prof_(kStPtf, st);
+    return launch_ptf_gru_bwd(n, cat, nullptr, stream_t, g_fused, dcat, side, st, act);
 }
 
 FS_API int32_t fs_ptf_gru_grad_floats(void) { return kGradFloats; }

@@ -231,7 +231,7 @@ _stream_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _stream16_index_cache: dict = {}
 
 
-def _gru_stream16_index(forward_only: bool) -> "np.ndarray":
+def _gru_stream16_index(forward_only: bool, transposed_only: bool = False) -> "np.ndarray":
     """For every float of the 16-pair kernels' operand stream, its position in the concatenation of the GRU's 12 parameter
     tensors (flattened, in _gru_params order) followed by one zero -- the stream is ONE gather of that vector.  Rows of 64 lanes
     per v_mfma_f32_16x16x4_f32 in consumption order, lane l = (i = l & 15, kk = l >> 4) holding A[i][kk] --
@@ -239,7 +239,8 @@ def _gru_stream16_index(forward_only: bool) -> "np.ndarray":
       transposed layer, feature block ob: W[unit of k-step s for quarter kk][feature 16 ob + i]      (the zero where there is none)
     where a 64-unit activation is consumed register by register of the accumulator layout: k-step s <-> units
     16 (s >> 2) + 4 kk + (s & 3).  696 forward + 704 transposed rows, padded to whole ring chunks and interleaved by quads of rows;
-    then the six bias vectors (64 floats each).  forward_only: the first 696 rows, packaged the same way."""
+    then the six bias vectors (64 floats each).  forward_only: the first 696 rows, packaged the same way; transposed_only: the
+    last 704 rows alone (exactly 11 chunks, no bias rows) -- the stream of fs_ptf_gru_backward_saved."""
     import numpy as np
     sizes = [int(np.prod(sh)) for sh in GRU_PARAM_SHAPES]
     off = np.concatenate([[0], np.cumsum(sizes)])
@@ -289,24 +290,28 @@ def _gru_stream16_index(forward_only: bool) -> "np.ndarray":
         assert len(rows) == 1400
     c = _lib.lib().fs_ptf_gru_stream_chunk_rows()
     n_rows = (_lib.lib().fs_ptf_gru_table_rows() if forward_only else _lib.lib().fs_ptf_gru_stream_rows()) - 6
+    if transposed_only:
+        rows, n_rows = rows[696:], _lib.lib().fs_ptf_gru_stream_t_rows()
     assert n_rows % c == 0 and n_rows >= len(rows) and c % 16 == 0
     ops = np.full((n_rows, 64), zero, dtype=np.int64)
     ops[:len(rows)] = np.stack(rows)
     ops = ops.reshape(n_rows // c, 4, c // 16, 4, 64).transpose(0, 1, 2, 4, 3).reshape(n_rows, 64)
+    if transposed_only:
+        return ops.astype(np.int64)
     bias = np.stack([off[m] + lane for m in (BR1, BZ1, BR2, BZ2, BN1, BN2)])
     return np.concatenate([ops, bias]).astype(np.int64)
 
 
-def _gru_operand_stream16(gru: "GRU", forward_only: bool = False) -> Tensor:
+def _gru_operand_stream16(gru: "GRU", forward_only: bool = False, transposed_only: bool = False) -> Tensor:
     """Operand stream of csrc/ptf_gru.hip:ptf_gru_bwd16_kernel (fs_ptf_gru_stream_layout() = 2) or, forward_only, the tables of
     ptf_gru16_kernel (fs_ptf_gru_table_layout() = 1): one concatenation + one gather of the parameters through the index
     _gru_stream16_index describes (built once per device: a training loop rebuilds the stream after every optimizer step)."""
     params = _gru_params(gru)
     dev = params[0].device
-    key = (str(dev), bool(forward_only))
+    key = (str(dev), bool(forward_only), bool(transposed_only))
     idx = _stream16_index_cache.get(key)
     if idx is None:
-        idx = _stream16_index_cache[key] = torch.from_numpy(_gru_stream16_index(forward_only)).to(dev)
+        idx = _stream16_index_cache[key] = torch.from_numpy(_gru_stream16_index(forward_only, transposed_only)).to(dev)
     with torch.no_grad():
         flat = torch.cat([q.detach().float().reshape(-1) for q in params] + [torch.zeros(1, device=dev)])
         return flat[idx]
@@ -353,6 +358,28 @@ def gru_operand_stream(gru: "GRU") -> Tensor:
     return stream
 
 
+_stream_t_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def save_gru_activations() -> bool:
+    """Training folds keep the GRU's hidden activations and gates (fs_ptf_fold_step_save) so that the backward runs the
+    transposed layers only (fs_ptf_gru_backward_saved: 704 instead of 1 400 MFMAs per 16 pairs; +3.3 KB per fused pair held
+    until the backward).  FREESPLAT_GRU_SAVE=0 switches it off (A/B); unavailable with the 32-pair kernels."""
+    return os.environ.get("FREESPLAT_GRU_SAVE", "1") != "0" and _lib.lib().fs_ptf_gru_stream_t_rows() > 0
+
+
+def gru_operand_stream_t(gru: "GRU") -> Tensor:
+    """The transposed layers' operand rows alone (fs_ptf_gru_stream_t_rows() rows): the stream of fs_ptf_gru_backward_saved."""
+    tab = gru_tables(gru)                                   # (cached per parameter version: a new table = new parameters)
+    hit = _stream_t_cache.get(gru)
+    if hit is not None and hit[0] is tab:
+        return hit[1]
+    stream = _gru_operand_stream16(gru, transposed_only=True)
+    assert stream.shape[0] == _lib.lib().fs_ptf_gru_stream_t_rows()
+    _stream_t_cache[gru] = (tab, stream)
+    return stream
+
+
 GRU_PARAM_SHAPES = [(64, 176), (64,), (64, 64), (64,), (64, 176), (64,), (64, 64), (64,), (64, 152), (64,), (64, 64), (64,)]
 
 
@@ -367,11 +394,14 @@ def gru_grad_views(flat: Tensor) -> list:
     return out
 
 
-def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tensor, g_fused: Tensor, grads: Tensor = None):
+def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tensor, g_fused: Tensor, grads: Tensor = None,
+                 saved: tuple = None):
     """Backward of the GRU over n materialised input rows: fs_ptf_gru_backward (forward re-run + the six transposed
     layers on the matrix cores) gives dcat [n,176] and the per-pair factors of the weight gradients (`side`);
     fs_ptf_gru_weight_grads contracts those over the n pairs -- dW = dY^T X and the bias sums, two launches -- ADDING to
     the flat buffer `grads` (fs_ptf_gru_grad_floats() floats; a zeroed one is made if not given).
+    saved = (side, act, stream_t) of a fold step run by fs_ptf_fold_step_save: the forward is not re-run (fs_ptf_gru_backward_saved
+    fills the remaining columns of THAT side buffer).
     Returns (dcat, [12 parameter gradients in the order of _gru_params], views of `grads`)."""
     L = _lib.lib()
     p = _lib.ptr
@@ -380,11 +410,16 @@ def gru_backward(params: list, tables: Tensor, operand_stream: Tensor, cat: Tens
     if grads is None:
         grads = torch.zeros(L.fs_ptf_gru_grad_floats(), dtype=torch.float32, device=dev)
     dcat = torch.empty(n, 176, dtype=torch.float32, device=dev)
-    side = torch.empty(n, L.fs_ptf_gru_side_cols(), dtype=torch.float32, device=dev)
     g_fused = g_fused.contiguous()
     st = _lib.current_stream()
-    _lib.check(L.fs_ptf_gru_backward(n, p(cat), p(tables), p(operand_stream), p(g_fused), p(dcat), p(side), st),
-               "fs_ptf_gru_backward")
+    if saved is not None:
+        side, act, stream_t = saved
+        _lib.check(L.fs_ptf_gru_backward_saved(n, p(cat), p(stream_t), p(act), p(g_fused), p(dcat), p(side), st),
+                   "fs_ptf_gru_backward_saved")
+    else:
+        side = torch.empty(n, L.fs_ptf_gru_side_cols(), dtype=torch.float32, device=dev)
+        _lib.check(L.fs_ptf_gru_backward(n, p(cat), p(tables), p(operand_stream), p(g_fused), p(dcat), p(side), st),
+                   "fs_ptf_gru_backward")
     ws = torch.empty(L.fs_ptf_gru_weight_grads_bytes(n), dtype=torch.uint8, device=dev)
     _lib.check(L.fs_ptf_gru_weight_grads(n, p(cat), p(side), p(grads), p(ws), st), "fs_ptf_gru_weight_grads")
     return dcat, gru_grad_views(grads)
@@ -510,7 +545,7 @@ class _PtfFold(torch.autograd.Function):
     D [n]."""
 
     @staticmethod
-    def forward(ctx, lat, xs, rho, om, dep, Es, Kn, h, w, depth_thres, tables, operand_stream, *params):
+    def forward(ctx, lat, xs, rho, om, dep, Es, Kn, h, w, depth_thres, tables, operand_stream, stream_t, *params):
         L = _lib.lib()
         p = _lib.ptr
         V, P = lat.shape[0], lat.shape[1]
@@ -521,18 +556,27 @@ class _PtfFold(torch.autograd.Function):
         _lib.check(L.fs_ptf_cameras(V, h, w, p(Es), p(Kn), p(kpix), p(E0), _lib.current_stream()), "fs_ptf_cameras")
         counts = torch.empty(V, 4, dtype=torch.int32, device=dev)
         state = (lat[0], xs[0], rho[0], om[0], E0, dep[0])         # G, X, R, O, E, D of the state after view 0
-        states, scratches = [state], [None]
+        states, scratches, saves = [state], [None], [None]
         for i in range(1, V):
             M_max = i * P
             rows = M_max + P
             out = tuple(torch.empty(rows, n, device=dev) for n in (64, 3, 1, 1, 16, 1))
             scratch = torch.empty(L.fs_ptf_fold_scratch_bytes(M_max, h, w), dtype=torch.uint8, device=dev)
             G, X, R, O, E, D = state
-            _lib.check(L.fs_ptf_fold_step(
-                M_max, None if i == 1 else p(counts[i - 1, 3:]), h, w, p(G), p(X), p(R), p(O), p(E), p(D),
-                p(lat[i]), p(xs[i]), p(rho[i]), p(om[i]), p(dep[i]), p(Es[i]), p(w2c[i]), p(kpix[i]),
-                C.c_float(depth_thres), p(tables), p(scratch), *[p(t) for t in out], p(counts[i]),
-                _lib.current_stream()), "fs_ptf_fold_step")
+            args = (M_max, None if i == 1 else p(counts[i - 1, 3:]), h, w, p(G), p(X), p(R), p(O), p(E), p(D),
+                    p(lat[i]), p(xs[i]), p(rho[i]), p(om[i]), p(dep[i]), p(Es[i]), p(w2c[i]), p(kpix[i]),
+                    C.c_float(depth_thres), p(tables), p(scratch), *[p(t) for t in out], p(counts[i]))
+            if stream_t is not None:
+                # the GRU leaves its hidden activations (side columns 6 .. 9) and gates for the backward: one row per fused pair,
+                # at most min(M_max, P) of them (the step's fuse list has that many slots)
+                nf_max = min(M_max, P)
+                side = torch.empty(nf_max, L.fs_ptf_gru_side_cols(), dtype=torch.float32, device=dev)
+                act = torch.empty(-(-nf_max // 16) * 16, L.fs_ptf_gru_act_cols(), dtype=torch.float32, device=dev)   # (whole 16-pair groups)
+                _lib.check(L.fs_ptf_fold_step_save(*args, p(side), p(act), _lib.current_stream()), "fs_ptf_fold_step_save")
+                saves.append((side, act))
+            else:
+                _lib.check(L.fs_ptf_fold_step(*args, _lib.current_stream()), "fs_ptf_fold_step")
+                saves.append(None)
             state = out
             states.append(out)
             scratches.append(scratch)
@@ -558,7 +602,7 @@ class _PtfFold(torch.autograd.Function):
             G, X, E, D = (t[:n].clone() for t in (G, X, E, D))
         states[V - 1] = None
         ctx.cnt, ctx.hw, ctx.states, ctx.scratches = cnt, (h, w), states, scratches
-        ctx.tables, ctx.operand_stream = tables, operand_stream
+        ctx.tables, ctx.operand_stream, ctx.stream_t, ctx.saves = tables, operand_stream, stream_t, saves
         ctx.save_for_backward(lat, xs, rho, om, dep, Es, *params)
         return G[:n], X[:n], E[:n], D[:n, 0]
 
@@ -609,7 +653,10 @@ class _PtfFold(torch.autograd.Function):
                 g_fused = g_out[0][nk: nk + nf] if g_out[0] is not None else z(nf, 64)
                 if g_flat is None:
                     g_flat = z(L.fs_ptf_gru_grad_floats())
-                dcat, g_params = gru_backward(params, ctx.tables, ctx.operand_stream, cat, g_fused, g_flat)
+                sv = ctx.saves[i]
+                dcat, g_params = gru_backward(params, ctx.tables, ctx.operand_stream, cat, g_fused, g_flat,
+                                              saved=None if sv is None else (sv[0], sv[1], ctx.stream_t))
+                ctx.saves[i] = None
                 _lib.check(L.fs_ptf_gru_inputs_backward(nf, fuse, fpix, p(R), p(O), p(rho[i]), p(om[i]), p(dcat),
                                                         p(g_in[0]), p(g_in[2]), p(g_in[3]), p(g_lat[i]), p(g_rho[i]),
                                                         p(g_om[i]), _lib.current_stream()), "fs_ptf_gru_inputs_backward")
@@ -617,7 +664,7 @@ class _PtfFold(torch.autograd.Function):
         need = ctx.needs_input_grad
         pick = lambda k, t: t if need[k] else None
         return (pick(0, g_lat), pick(1, g_xs), pick(2, g_rho), pick(3, g_om), pick(4, g_dep), None, None, None, None,
-                None, None, None) + tuple(g if need[12 + k] else None for k, g in enumerate(g_params))
+                None, None, None, None) + tuple(g if need[13 + k] else None for k, g in enumerate(g_params))
 
 
 def _fuse_gaussians_train(gru, gaussians, coords, densities, weight_emb, depths, extrinsics, intrinsics, image_shape,
@@ -632,7 +679,8 @@ def _fuse_gaussians_train(gru, gaussians, coords, densities, weight_emb, depths,
         return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
     Kn = f32(intrinsics[0].detach()).reshape(V, 9)
     G, X, E, D = _PtfFold.apply(lat, xs, rho, om, dep, Es, Kn, h, w, float(depth_thres), gru_tables(gru),
-                                gru_operand_stream(gru), *_gru_params(gru))
+                                gru_operand_stream(gru), gru_operand_stream_t(gru) if save_gru_activations() else None,
+                                *_gru_params(gru))
     n = G.shape[0]
     return G[None], X[None], E.view(1, n, 4, 4), D[None]
 

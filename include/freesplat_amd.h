@@ -342,6 +342,17 @@ int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, 
                      const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
                      void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
                      int32_t* counts, void* stream);
+/* The same step for a TRAINING fold (ABI 6, round 6): the GRU additionally leaves, for fused pair t (the order of the step's fuse
+ * list), row t of `side` [min(M_max, h w), fs_ptf_gru_side_cols()] -- columns 6 .. 9 only: relu(r1), relu(z1), relu(n1), r * hid, the
+ * activations the weight gradients pair with -- and `act` [min(M_max, h w) rounded up to 16, fs_ptf_gru_act_cols()] = the gates r, z, q in the kernels' own lane order
+ * (opaque: [group of 16 pairs][r, z, q][4 blocks][64 lanes] float4), so that
+ * fs_ptf_gru_backward_saved runs the transposed layers only.  Requires fs_ptf_gru_stream_t_rows() > 0 (the 16-pair kernels). */
+int fs_ptf_fold_step_save(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, const float* G, const float* X,
+                          const float* R, const float* O, const float* E, const float* D, const float* g_i,
+                          const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
+                          const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
+                          void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
+                          int32_t* counts, float* side, float* act, void* stream);
 
 /* All fold steps of one scene in one host call (no host sync, no allocation): views 1 .. V-1 are folded into the state
  * that starts as view 0.  lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es [V,16] (camera-to-world), w2c [V,16]
@@ -396,6 +407,15 @@ int32_t fs_ptf_gru_stream_chunk_rows(void);
 int32_t fs_ptf_gru_side_cols(void);
 int fs_ptf_gru_backward(int32_t n, const float* cat, const float* tables, const float* operand_stream,
                         const float* g_fused, float* dcat, float* side, void* stream);
+/* Backward of the GRU over the n fused pairs of a step that fs_ptf_fold_step_save ran (replaces the re-run of the forward inside
+ * fs_ptf_gru_backward: 704 instead of 1 400 matrix instructions per 16 pairs; reference: autograd through networks.py:188-214).
+ * stream_t: the fs_ptf_gru_stream_t_rows() transposed operand rows of stream layout 2 alone (rows 696 .. 1399, interleaved by quads
+ * inside chunks exactly like layout 2, no bias rows; freesplat_amd/ptf.py:gru_operand_stream_t); 0 rows = unavailable in this mode.
+ * side: the step's buffer (columns 6 .. 9 filled by the forward; columns 0 .. 5 are written here), act: the step's gates. */
+int32_t fs_ptf_gru_act_cols(void);
+int32_t fs_ptf_gru_stream_t_rows(void);
+int fs_ptf_gru_backward_saved(int32_t n, const float* cat, const float* stream_t, const float* act, const float* g_fused,
+                              float* dcat, float* side, void* stream);
 int32_t fs_ptf_gru_grad_floats(void);
 size_t fs_ptf_gru_weight_grads_bytes(int32_t n);
 int fs_ptf_gru_weight_grads(int32_t n, const float* cat, const float* side, float* grads, void* workspace, void* stream);

@@ -119,7 +119,7 @@ def test_every_entry_point_validates_its_arguments_before_touching_a_device():
     import ctypes as C
     from freesplat_amd import _lib
     L = _lib.lib()
-    getters = {"fs_abi_version", "fs_ptf_gru_table_rows", "fs_ptf_gru_table_t_rows", "fs_ptf_gru_stream_rows", "fs_ptf_gru_stream_layout", "fs_ptf_gru_table_layout", "fs_ptf_gru_stream_chunk_rows", "fs_ptf_gru_side_cols",
+    getters = {"fs_abi_version", "fs_ptf_gru_table_rows", "fs_ptf_gru_table_t_rows", "fs_ptf_gru_stream_rows", "fs_ptf_gru_stream_layout", "fs_ptf_gru_table_layout", "fs_ptf_gru_stream_chunk_rows", "fs_ptf_gru_side_cols", "fs_ptf_gru_act_cols", "fs_ptf_gru_stream_t_rows",
                "fs_ptf_gru_grad_floats", "fs_raster_scratch_slots",
                "fs_profile_enable", "fs_profile_collect"}
 

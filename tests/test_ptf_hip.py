@@ -414,3 +414,38 @@ def test_training_fold_with_and_without_state_trims(hip_device, monkeypatch):
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), k
     for a, b in zip(g_keep[5:], g_trim[5:]):                          # (GRU weights: fixed-order partial sums -> same bits)
         assert torch.equal(a, b)
+
+
+def test_training_fold_with_kept_and_with_recomputed_gru_activations(hip_device, monkeypatch):
+    """Round 6: a training fold keeps the GRU's hidden activations and gates (fs_ptf_fold_step_save) and its backward runs the transposed
+    layers only (fs_ptf_gru_backward_saved); FREESPLAT_GRU_SAVE=0 re-runs the forward inside the backward kernel as before.  Same
+    outputs (the same forward kernel arithmetic) and the same gradients -- the kept values ARE the values the re-run produces, up to
+    the order in which the two kernels round sigmoid / tanh inputs (identical operand rows, identical MFMA order: in practice bits)."""
+    from freesplat_amd import _lib, ptf as P
+    if _lib.lib().fs_ptf_gru_stream_t_rows() == 0:
+        pytest.skip("32-pair GRU kernels selected (FS_GRU_FWD16=0 / FS_GRU_BWD16=0): no saved-activation backward")
+    V, h, w = 4, 48, 64
+    E, Kn, depths, lat, dens, wts, coords = _scene(V, h, w, seed=78)
+    torch.manual_seed(4)
+    m = P.PixelwiseTripletFusion().to(hip_device)
+    d = lambda t: t.to(hip_device)
+
+    def run():
+        ins = [d(t).requires_grad_(True) for t in (lat, coords, dens, wts, depths)]
+        out = m.fuse_gaussians([ins[0]], [ins[1]], ins[2], ins[3], ins[4], d(E)[None], d(Kn)[None], (h, w))
+        cot = [torch.randn(o.shape, generator=torch.Generator().manual_seed(21 + k)).to(hip_device) for k, o in enumerate(out)]
+        grads = torch.autograd.grad(out, ins + list(m.gru.parameters()), cot, allow_unused=True)
+        return [o.detach() for o in out], grads
+    monkeypatch.setenv("FREESPLAT_GRU_SAVE", "1")
+    assert P.save_gru_activations()
+    out_s, g_s = run()
+    monkeypatch.setenv("FREESPLAT_GRU_SAVE", "0")
+    assert not P.save_gru_activations()
+    out_r, g_r = run()
+    for a, b in zip(out_s, out_r):
+        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(g_s, g_r)):
+        assert (a is None) == (b is None), k
+        if a is not None:
+            scale = b.abs().max().item() + 1e-30
+            assert (a - b).abs().max().item() <= 1e-5 * scale, (k, (a - b).abs().max().item(), scale)

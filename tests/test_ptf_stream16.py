@@ -41,6 +41,10 @@ def test_stream16_rows_are_the_layers_in_consumption_order():
     assert np.array_equal(rows[:696], trow[:696]) and np.array_equal(bias, tbias)
     assert np.array_equal(bias, np.stack([br1, bz1, br2, bz2, bn1, bn2]))
     assert not rows[1400:].any() and not trow[696:].any()
+    # the transposed rows alone (fs_ptf_gru_backward_saved: the training forward kept its activations): exactly 11 chunks, no bias rows
+    tt = P._gru_operand_stream16(gru, transposed_only=True).double().numpy()
+    assert tt.shape == (lib.fs_ptf_gru_stream_t_rows(), 64) == (704, 64)
+    assert np.array_equal(_rows(tt, 704)[0], rows[696:1400])
 
     rng = np.random.default_rng(0)
     kk = np.arange(4)
