@@ -101,7 +101,7 @@ SIGNATURES = {
                                       + [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _VP, C.c_int32, C.c_int32, C.c_int32]),
     "fs_ptf_fold_scratch_bytes": (C.c_size_t, [C.c_int32] * 3),
     "fs_ptf_fold_step": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 14 + [C.c_float] + [_VP] * 10),
-    "fs_ptf_fold_step_save": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 14 + [C.c_float] + [_VP] * 12),
+    "fs_ptf_fold_step_save": (C.c_int, [C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 14 + [C.c_float] + [_VP] * 13),
     "fs_ptf_fold_bytes": (C.c_size_t, [C.c_int32] * 3),
     "fs_ptf_fold": (C.c_int, [C.c_int32] * 3 + [_VP] * 8 + [C.c_float] + [_VP] * 2 + [C.POINTER(C.c_void_p)] * 2 + [_VP] * 2),
     "fs_ptf_cameras": (C.c_int, [C.c_int32] * 3 + [_VP] * 5),

@@ -108,7 +108,7 @@ int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const flo
 int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fuse_idx, const long long* fuse_pix,
                           const float* G, const float* R, const float* O, const float* g_i, const float* rho_i,
                           const float* om_i, const float* tables, float* fused, bool out_after_keep, hipStream_t st,
-                          float* save_side = nullptr, float* save_act = nullptr);
+                          float* save_side = nullptr, float* save_act = nullptr, float* save_cat = nullptr);
 // (save_side / save_act: the training fold keeps the hidden activations and gates for fs_ptf_gru_backward_saved)
 // (out_after_keep: `fused` is the out state's G array and pair t is written to its row counts[0] + t)
 

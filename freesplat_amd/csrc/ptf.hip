@@ -652,7 +652,8 @@ static int fold_step_impl(int32_t M_max, const int32_t* M_dev, int32_t h, int32_
                           const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
                           const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
                           void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
-                          int32_t* counts, void* stream_, bool zbuf_clean, float* save_side = nullptr, float* save_act = nullptr)
+                          int32_t* counts, void* stream_, bool zbuf_clean, float* save_side = nullptr, float* save_act = nullptr,
+                          float* save_cat = nullptr)
 {
     if (M_max <= 0 || h <= 0 || w <= 0 || !G || !X || !R || !O || !E || !D || !g_i || !x_i || !rho_i || !om_i || !d_i ||
         !E_i || !w2c || !kpix || !gru_tables || !scratch || !oG || !oX || !oR || !oO || !oE || !oD || !counts)
@@ -671,7 +672,7 @@ static int fold_step_impl(int32_t M_max, const int32_t* M_dev, int32_t h, int32_
     ScopedStage prof_(kStPtf, st);
     (void)cat; (void)fused;  // (the GRU gathers and encodes its input rows itself and writes its rows into the out state)
     rc = launch_ptf_gru_gather(nf_max, counts, (const long long*)fuse, (const long long*)fpix, G, R, O, g_i, rho_i, om_i,
-                               gru_tables, oG, true, st, save_side, save_act);
+                               gru_tables, oG, true, st, save_side, save_act, save_cat);
     if (rc != FS_OK) return rc;
     PtfState si{const_cast<float*>(G), const_cast<float*>(X), const_cast<float*>(R), const_cast<float*>(O),
                 const_cast<float*>(E), const_cast<float*>(D)};
@@ -696,18 +697,19 @@ FS_API int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int3
 }
 
 // fs_ptf_fold_step for a TRAINING fold (round 6): the GRU additionally leaves, for fused pair t (the order of the step's fuse list),
-// row t of `side` [min(M_max, h w), fs_ptf_gru_side_cols()] (columns 6 .. 9 only) and `act` [.. rounded up to 16, fs_ptf_gru_act_cols()] (gates, lane order), which
-// fs_ptf_gru_backward_saved consumes instead of re-running the forward.  Requires fs_ptf_gru_stream_t_rows() > 0.
+// row t of `side` [min(M_max, h w), fs_ptf_gru_side_cols()] (columns 6 .. 9 only), `act` [.. rounded up to 16, fs_ptf_gru_act_cols()] (gates, lane
+// order) and `cat` [.., 176] (the pair's gathered + encoded input row: what fs_ptf_gru_inputs would re-gather), which
+// fs_ptf_gru_backward_saved / fs_ptf_gru_weight_grads consume instead of re-running the forward.  Requires fs_ptf_gru_stream_t_rows() > 0.
 FS_API int fs_ptf_fold_step_save(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, const float* G, const float* X,
                                  const float* R, const float* O, const float* E, const float* D, const float* g_i,
                                  const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
                                  const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
                                  void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
-                                 int32_t* counts, float* side, float* act, void* stream_)
+                                 int32_t* counts, float* side, float* act, float* cat, void* stream_)
 {
-    if (!side || !act) return FS_ERR_INVALID_ARG;
+    if (!side || !act || !cat) return FS_ERR_INVALID_ARG;
     return fold_step_impl(M_max, M_dev, h, w, G, X, R, O, E, D, g_i, x_i, rho_i, om_i, d_i, E_i, w2c, kpix, depth_thres,
-                          gru_tables, scratch, oG, oX, oR, oO, oE, oD, counts, stream_, false, side, act);
+                          gru_tables, scratch, oG, oX, oR, oO, oE, oD, counts, stream_, false, side, act, cat);
 }
 
 // Camera constants of the fold in one launch: thread i scales the normalised intrinsics of view i to pixels

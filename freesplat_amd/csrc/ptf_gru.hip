@@ -120,7 +120,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 struct GruGather {
     const long long *fuse_idx, *fuse_pix;
     const float *G, *R, *O, *g_i, *rho_i, *om_i;
-    float *side = nullptr, *act = nullptr;      // ptf_gru16_kernel<true, true>: where the training forward leaves what the backward needs
+    float *side = nullptr, *act = nullptr, *cat_out = nullptr;   // ptf_gru16_kernel<true, true>: where the training forward leaves what the backward needs
 };
 constexpr int kAct = 192;   // floats per pair the saving forward keeps beside the `side` columns: r, z (gates), q = tanh(.)
 // (two workgroups per CU: at one -- 407 registers if the compiler is left alone -- the fold is 7 % slower)
@@ -903,6 +903,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FS_GRU_FWD1
     f32x4 hid[4];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) hid[blk] = ld4(hrow + 16 * blk + ao);
+    if constexpr (SAVE && GATHER) {
+        // the pair's gathered + encoded input row [hid | he | x | xe] -- this quarter's 44 features ARE xh -- for the backward and the
+        // weight gradients (saves the backward its re-gather, fs_ptf_gru_inputs: 0.21 ms per step at 968x1296)
+        if (live) {
+            float* cr = ga.cat_out + (size_t)t * 176 + 44 * g;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) *(float4*)(cr + 4 * k) = make_float4(xh[4 * k], xh[4 * k + 1], xh[4 * k + 2], xh[4 * k + 3]);
+        }
+    }
 
     f32x4 r1[4], z1[4];
 #pragma unroll
@@ -1051,11 +1060,12 @@ int launch_ptf_gru(int n_max, const int32_t* counts, const float* cat, const flo
 int launch_ptf_gru_gather(int n_max, const int32_t* counts, const long long* fuse_idx, const long long* fuse_pix,
                           const float* G, const float* R, const float* O, const float* g_i, const float* rho_i,
                           const float* om_i, const float* tables, float* fused, bool out_after_keep, hipStream_t st,
-                          float* save_side, float* save_act)
+                          float* save_side, float* save_act, float* save_cat)
 {
     if (n_max <= 0) return FS_OK;
-    if ((save_side != nullptr) != (save_act != nullptr) || (save_side && !gru_fwd16())) return FS_ERR_INVALID_ARG;
-    const GruGather ga{fuse_idx, fuse_pix, G, R, O, g_i, rho_i, om_i, save_side, save_act};
+    if ((save_side != nullptr) != (save_act != nullptr) || (save_side != nullptr) != (save_cat != nullptr) || (save_side && !gru_fwd16()))
+        return FS_ERR_INVALID_ARG;
+    const GruGather ga{fuse_idx, fuse_pix, G, R, O, g_i, rho_i, om_i, save_side, save_act, save_cat};
     if (gru_fwd16() && save_side) {
         hipLaunchKernelGGL((ptf_gru16_kernel<true, true>), dim3((n_max + 63) / 64), dim3(256), 0, st, n_max, counts, (const float*)nullptr,
                            ga, tables, fused, out_after_keep ? 1 : 0);

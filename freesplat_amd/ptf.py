@@ -572,8 +572,9 @@ class _PtfFold(torch.autograd.Function):
                 nf_max = min(M_max, P)
                 side = torch.empty(nf_max, L.fs_ptf_gru_side_cols(), dtype=torch.float32, device=dev)
                 act = torch.empty(-(-nf_max // 16) * 16, L.fs_ptf_gru_act_cols(), dtype=torch.float32, device=dev)   # (whole 16-pair groups)
-                _lib.check(L.fs_ptf_fold_step_save(*args, p(side), p(act), _lib.current_stream()), "fs_ptf_fold_step_save")
-                saves.append((side, act))
+                cat = torch.empty(nf_max, 176, dtype=torch.float32, device=dev)
+                _lib.check(L.fs_ptf_fold_step_save(*args, p(side), p(act), p(cat), _lib.current_stream()), "fs_ptf_fold_step_save")
+                saves.append((side, act, cat))
             else:
                 _lib.check(L.fs_ptf_fold_step(*args, _lib.current_stream()), "fs_ptf_fold_step")
                 saves.append(None)
@@ -647,13 +648,16 @@ class _PtfFold(torch.autograd.Function):
                 _lib.current_stream()), "fs_ptf_write_state_backward")
             if nf > 0:
                 # the GRU rows: re-gather their inputs (HIP), GRU backward on the matrix cores (+ the weight-gradient GEMMs)
-                cat = torch.empty(nf, 176, dtype=torch.float32, device=dev)
-                _lib.check(L.fs_ptf_gru_inputs(nf, fuse, fpix, p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]), p(cat),
-                                               _lib.current_stream()), "fs_ptf_gru_inputs")
+                sv = ctx.saves[i]
+                if sv is not None:
+                    cat = sv[2][:nf]                       # (the forward kept the gathered + encoded rows)
+                else:
+                    cat = torch.empty(nf, 176, dtype=torch.float32, device=dev)
+                    _lib.check(L.fs_ptf_gru_inputs(nf, fuse, fpix, p(G), p(R), p(O), p(lat[i]), p(rho[i]), p(om[i]), p(cat),
+                                                   _lib.current_stream()), "fs_ptf_gru_inputs")
                 g_fused = g_out[0][nk: nk + nf] if g_out[0] is not None else z(nf, 64)
                 if g_flat is None:
                     g_flat = z(L.fs_ptf_gru_grad_floats())
-                sv = ctx.saves[i]
                 dcat, g_params = gru_backward(params, ctx.tables, ctx.operand_stream, cat, g_fused, g_flat,
                                               saved=None if sv is None else (sv[0], sv[1], ctx.stream_t))
                 ctx.saves[i] = None

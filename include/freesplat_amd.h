@@ -345,14 +345,15 @@ int fs_ptf_fold_step(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, 
 /* The same step for a TRAINING fold (ABI 6, round 6): the GRU additionally leaves, for fused pair t (the order of the step's fuse
  * list), row t of `side` [min(M_max, h w), fs_ptf_gru_side_cols()] -- columns 6 .. 9 only: relu(r1), relu(z1), relu(n1), r * hid, the
  * activations the weight gradients pair with -- and `act` [min(M_max, h w) rounded up to 16, fs_ptf_gru_act_cols()] = the gates r, z, q in the kernels' own lane order
- * (opaque: [group of 16 pairs][r, z, q][4 blocks][64 lanes] float4), so that
+ * (opaque: [group of 16 pairs][r, z, q][4 blocks][64 lanes] float4), and row t of `cat` [min(M_max, h w), 176] = the pair's gathered and
+ * encoded input row (exactly what fs_ptf_gru_inputs would re-gather for the backward), so that
  * fs_ptf_gru_backward_saved runs the transposed layers only.  Requires fs_ptf_gru_stream_t_rows() > 0 (the 16-pair kernels). */
 int fs_ptf_fold_step_save(int32_t M_max, const int32_t* M_dev, int32_t h, int32_t w, const float* G, const float* X,
                           const float* R, const float* O, const float* E, const float* D, const float* g_i,
                           const float* x_i, const float* rho_i, const float* om_i, const float* d_i, const float* E_i,
                           const float* w2c, const float* kpix, float depth_thres, const float* gru_tables,
                           void* scratch, float* oG, float* oX, float* oR, float* oO, float* oE, float* oD,
-                          int32_t* counts, float* side, float* act, void* stream);
+                          int32_t* counts, float* side, float* act, float* cat, void* stream);
 
 /* All fold steps of one scene in one host call (no host sync, no allocation): views 1 .. V-1 are folded into the state
  * that starts as view 0.  lat [V,P,64], xs [V,P,3], rho / om / dep [V,P], Es [V,16] (camera-to-world), w2c [V,16]
