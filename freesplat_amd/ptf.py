@@ -361,11 +361,26 @@ def gru_operand_stream(gru: "GRU") -> Tensor:
 _stream_t_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
-def save_gru_activations() -> bool:
-    """Training folds keep the GRU's hidden activations and gates (fs_ptf_fold_step_save) so that the backward runs the
-    transposed layers only (fs_ptf_gru_backward_saved: 704 instead of 1 400 MFMAs per 16 pairs; +3.3 KB per fused pair held
-    until the backward).  FREESPLAT_GRU_SAVE=0 switches it off (A/B); unavailable with the 32-pair kernels."""
-    return os.environ.get("FREESPLAT_GRU_SAVE", "1") != "0" and _lib.lib().fs_ptf_gru_stream_t_rows() > 0
+def save_gru_activations(V: int = 2, P: int = 0, device=None) -> bool:
+    """Training folds keep the GRU's hidden activations, gates and gathered input rows (fs_ptf_fold_step_save) so that the
+    backward runs the transposed layers only (fs_ptf_gru_backward_saved: 704 instead of 1 400 MFMAs per 16 pairs) -- 4 KB per
+    possible fused pair and step held until the backward: (V - 1) * P * 4 KB, 10 GB for config 3's three views at 968x1296.
+    FREESPLAT_GRU_SAVE=1 / 0 forces it on / off (A/B); otherwise it is on when that fits a quarter of the memory currently free
+    on the device (a 288 GB MI355X: always; a small card falls back to the re-running backward instead of running out of memory).
+    Unavailable with the 32-pair kernels."""
+    if _lib.lib().fs_ptf_gru_stream_t_rows() <= 0:
+        return False
+    e = os.environ.get("FREESPLAT_GRU_SAVE")
+    if e is not None:
+        return e != "0"
+    if P <= 0 or device is None:
+        return True
+    need = (V - 1) * P * 4 * (_lib.lib().fs_ptf_gru_side_cols() + _lib.lib().fs_ptf_gru_act_cols() + 176)
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+    except Exception:
+        return False
+    return need <= free // 4
 
 
 def gru_operand_stream_t(gru: "GRU") -> Tensor:
@@ -683,7 +698,7 @@ def _fuse_gaussians_train(gru, gaussians, coords, densities, weight_emb, depths,
         return lat[:1], xs[:1], Es[0].reshape(1, 1, 4, 4).repeat(1, P, 1, 1), dep[:1]
     Kn = f32(intrinsics[0].detach()).reshape(V, 9)
     G, X, E, D = _PtfFold.apply(lat, xs, rho, om, dep, Es, Kn, h, w, float(depth_thres), gru_tables(gru),
-                                gru_operand_stream(gru), gru_operand_stream_t(gru) if save_gru_activations() else None,
+                                gru_operand_stream(gru), gru_operand_stream_t(gru) if save_gru_activations(V, P, lat.device) else None,
                                 *_gru_params(gru))
     n = G.shape[0]
     return G[None], X[None], E.view(1, n, 4, 4), D[None]
