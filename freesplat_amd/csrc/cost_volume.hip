@@ -247,8 +247,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // SAVE (training forward): the MLP's input of every (pixel, plane) point -- the averaged warped features x = favg / cnt,
 // the averaged score and the sources' (valid, in-front) bits -- is kept for the backward, which then starts from it
 // instead of gathering K x 4 taps again (chunk-planar, natural channel order: cost_volume16_bwd_kernel<C, true>).
-template <int C, bool SAVE>
-__global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
+// Two shapes of the sweep (round 6, profiles/r6_cv_fwd_taps_ab.txt).  Both read the W1 / W2 operands from per-lane LDS images where
+// their MFMA is (42 registers freed).  TAPS = 1: a source's four bilinear taps one after the other (each behind its branch), 124
+// registers, FOUR wavefronts per SIMD -- best at K <= 2, where a wavefront's chain of 8 dependent tap round trips per plane is what
+// the other wavefronts hide.  TAPS = 4: all four taps' loads in flight before the first is blended, 152 registers, three wavefronts --
+// best from K = 3 up, where the L1 / texture path is the bound and a deeper queue per wavefront feeds it better.
+#ifndef FS_FWD16_W_LDS
+#define FS_FWD16_W_LDS 2       // 0: W1 / W2 operands in registers (42); 1: W2's 16 from an LDS image; 2: both from LDS images
+#endif
+template <int C, bool SAVE, int TAPS, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void cost_volume16_kernel(
     int B, int K, int h, int w, int D, int slices, const float* __restrict__ curN, const float* __restrict__ srcN,
     const float* __restrict__ Pmat,
     const float* __restrict__ cur_invK, const float* __restrict__ planes, long long ps_b,
@@ -277,19 +285,31 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
     const int pull = (4 * n + g) * 4;   // ds_bpermute address: operand lane (n, g) takes gather lane 4 n + g
 
     // ---- MLP weights in registers, in MFMA A-operand order (lane = (row n of the block, k = g)) ----
-    float a1[2][NT], a2[2][8], w3v[2][4], b2v[2][4];
+    // (round 6: FS_FWD16_W_LDS >= 1 keeps W2's -- 2: also W1's -- operands as per-lane LDS images shared by the four wavefronts, one
+    //  ds_read_b32 where the MFMA is: the registers go to tap loads in flight, profiles/r6_cv_fwd_taps_ab.txt)
+    constexpr bool kW2Lds = FS_FWD16_W_LDS >= 1, kW1Lds = FS_FWD16_W_LDS >= 2;
+    __shared__ float s_w[(kW2Lds ? 16 : 0) * 64 + (kW1Lds ? 2 * NT : 0) * 64 + 64];
+    float* const sA2 = s_w + lane;                          // [(blk * 8 + t) * 64]
+    float* const sA1 = s_w + (kW2Lds ? 16 * 64 : 0) + lane; // [(blk * NT + t) * 64]
+    float a1[kW1Lds ? 1 : 2][kW1Lds ? 1 : NT], a2[kW2Lds ? 1 : 2][kW2Lds ? 1 : 8], w3v[2][4], b2v[2][4];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
         const int u = 16 * blk + n;
 #pragma unroll
-        for (int t = 0; t < NR; ++t) a1[blk][t] = w1[u * (C + 1) + 16 * (t >> 2) + 4 * g + (t & 3)];
-        a1[blk][NR] = g == 0 ? w1[u * (C + 1) + C] : (g == 1 ? b1[u] : 0.0f);
+        for (int t = 0; t < NT; ++t) {
+            const float v = t < NR ? w1[u * (C + 1) + 16 * (t >> 2) + 4 * g + (t & 3)] : (g == 0 ? w1[u * (C + 1) + C] : (g == 1 ? b1[u] : 0.0f));
+            if constexpr (kW1Lds) { if (wave == 0) sA1[(blk * NT + t) * 64] = v; } else a1[blk][t] = v;
+        }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) a2[blk][t] = w2[u * 32 + 16 * (t >> 2) + 4 * g + (t & 3)];
+        for (int t = 0; t < 8; ++t) {
+            const float v = w2[u * 32 + 16 * (t >> 2) + 4 * g + (t & 3)];
+            if constexpr (kW2Lds) { if (wave == 0) sA2[(blk * 8 + t) * 64] = v; } else a2[blk][t] = v;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { w3v[blk][r] = w3[16 * blk + 4 * g + r]; b2v[blk][r] = b2[16 * blk + 4 * g + r]; }
     }
     const float b3v = b3[0];
+    if constexpr (kW2Lds) __syncthreads();
 
     // ---- current-view feature: this lane's quarter of its pixel's channels ----
     float cur[NR];
@@ -329,6 +349,9 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
         FS_CV_T(t_top, rx);
         const float depth = depth_next;
         depth_next = pl[min(d + 1, d1 - 1) * ps_d];
+        // (one LDS store per plane into the image array's padding, through an index the compiler cannot relate to the operand reads:
+        //  without it the loop-invariant ds_reads are hoisted out of the plane loop -- back into the registers they were to free)
+        if constexpr (kW2Lds) s_w[(kW2Lds ? 16 : 0) * 64 + (kW1Lds ? 2 * NT : 0) * 64 + (lane ^ 1)] = depth;
         float favg[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) favg[r] = 0.0f;
@@ -375,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
             const uint32_t off0 = pr.off + 16u * (uint32_t)c;
             // (tap by tap behind a branch each: with three wavefronts per SIMD that beats having a source's taps in flight together --
             //  the backward's form, 2 wavefronts per SIMD -- which costs the third wavefront: profiles/r6_cv_fwd_taps_ab.txt)
+            if constexpr (TAPS == 1) {
 #pragma unroll
             for (int tap = 0; tap < 4; ++tap) {
                 const int ox = tap & 1, oy = tap >> 1;
@@ -389,6 +413,35 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
                         wv[4 * s + 2] += wt * v.z; wv[4 * s + 3] += wt * v.w;
                     }
                 }
+            }
+            } else {
+            // TAPS taps' loads are issued before the first of them is blended (a tap outside the image loads nothing: its
+            // registers are zero and so is its weight's contribution) -- 4 / TAPS dependent round trips per source instead of 4
+#pragma unroll
+            for (int t0 = 0; t0 < 4; t0 += TAPS) {
+                float4 v[TAPS][NS];
+                float wt[TAPS];
+#pragma unroll
+                for (int e = 0; e < TAPS; ++e) {
+                    const int tap = t0 + e, ox = tap & 1, oy = tap >> 1;
+                    const bool ok = live && (ox ? xin1 : xin0) && (oy ? yin1 : yin0);
+                    wt[e] = (ox ? tx : 1.0f - tx) * (oy ? ty : 1.0f - ty);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) v[e][s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (ok) {
+                        const float4* q = (const float4*)(base + (off0 + (uint32_t)((oy * w + ox) * C) * 4u));
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) v[e][s] = q[4 * s];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < TAPS; ++e)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        wv[4 * s] += wt[e] * v[e][s].x; wv[4 * s + 1] += wt[e] * v[e][s].y;
+                        wv[4 * s + 2] += wt[e] * v[e][s].z; wv[4 * s + 3] += wt[e] * v[e][s].w;
+                    }
+            }
             }
             float part = 0.0f;
 #pragma unroll
@@ -458,7 +511,8 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
         for (int blk = 0; blk < 2; ++blk) {
             h1[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int t = 0; t < NT; ++t) h1[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[blk][t], xop[t], h1[blk], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                h1[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(kW1Lds ? sA1[(blk * NT + t) * 64] : a1[kW1Lds ? 0 : blk][kW1Lds ? 0 : t], xop[t], h1[blk], 0, 0, 0);
         }
         // ---- layer 2 ----
         f32x4 h2[2];
@@ -467,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void cost_volume16_kernel(
             h2[blk] = f32x4{b2v[blk][0], b2v[blk][1], b2v[blk][2], b2v[blk][3]};
 #pragma unroll
             for (int t = 0; t < 8; ++t)
-                h2[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[blk][t], lrelu(h1[t >> 2][t & 3]), h2[blk], 0, 0, 0);
+                h2[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(kW2Lds ? sA2[(blk * 8 + t) * 64] : a2[kW2Lds ? 0 : blk][kW2Lds ? 0 : t], lrelu(h1[t >> 2][t & 3]), h2[blk], 0, 0, 0);
         }
         // ---- layer 3 ----
         float o = 0.0f;
@@ -2353,8 +2407,16 @@ static int cv_forward_impl(int32_t B, int32_t K, int32_t C, int32_t h, int32_t w
                                    cur_invK, planes, (long long)plane_stride_b, (long long)plane_stride_d,
                                    (long long)plane_stride_pix, w1, b1, w2, b2, w3, b3, out, xs, xm, xhdr);
             };
-            if (C == 48) { if (saved) sweep16(cost_volume16_kernel<48, true>); else sweep16(cost_volume16_kernel<48, false>); }
-            else { if (saved) sweep16(cost_volume16_kernel<16, true>); else sweep16(cost_volume16_kernel<16, false>); }
+            // (K <= 2: tap by tap at four wavefronts per SIMD; K >= 3: a source's four taps in flight at three -- FS_CV_FWD_SHAPE=1 / 4 forces one)
+            static const int force_shape = [] { const char* e = getenv("FS_CV_FWD_SHAPE"); return e ? atoi(e) : 0; }();
+            const bool deep = force_shape == 4 || (force_shape != 1 && K >= 3);
+            if (C == 48) {
+                if (deep) { if (saved) sweep16(cost_volume16_kernel<48, true, 4, 3>); else sweep16(cost_volume16_kernel<48, false, 4, 3>); }
+                else { if (saved) sweep16(cost_volume16_kernel<48, true, 1, 4>); else sweep16(cost_volume16_kernel<48, false, 1, 4>); }
+            } else {
+                if (deep) { if (saved) sweep16(cost_volume16_kernel<16, true, 4, 3>); else sweep16(cost_volume16_kernel<16, false, 4, 3>); }
+                else { if (saved) sweep16(cost_volume16_kernel<16, true, 1, 4>); else sweep16(cost_volume16_kernel<16, false, 1, 4>); }
+            }
         }
     }
     FS_CHECK_LAUNCH("cost_volume");
