@@ -306,6 +306,9 @@ __global__ __launch_bounds__(256) void ptf_gru_inputs_kernel(int n_fuse, const i
 
 struct PtfState { float *G, *X, *R, *O, *E, *D; };
 
+// SPLIT: the fused rows whose latent row the GRU wrote itself (`fused` == NULL: the fold) are handled by ptf_write_state_fused_kernel,
+// four lanes per row -- they move ~300 bytes, not a 256-byte latent row; this launch then walks the kept and the appended rows only.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void ptf_write_state_kernel(
     int n_keep, int n_fuse, int n_app, const int32_t* __restrict__ counts, const long long* __restrict__ keep_idx,
     const long long* __restrict__ fuse_idx,
@@ -314,9 +317,14 @@ __global__ __launch_bounds__(256) void ptf_write_state_kernel(
     const float* __restrict__ d_i, const float* __restrict__ E_i, const float* __restrict__ fused, PtfState o)
 {
     if (counts) { n_keep = counts[0]; n_fuse = counts[1]; n_app = counts[2]; }
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
+    const int c = threadIdx.x & 15;
     const int n_out = n_keep + n_fuse + n_app;
-    if (row >= n_out) return;
+    // (grid-stride: with the counts on the device the fold sizes its grid for the worst case -- 235 k workgroups at 968x1296 of
+    //  which 34 k have rows -- so the grid is capped and the workgroups walk)
+    for (long long r0 = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);; r0 += (long long)gridDim.x * 16) {
+    int row = (int)r0;
+    if (SPLIT && row >= n_keep) row += n_fuse;          // (this launch: kept + appended rows)
+    if (r0 >= n_out || row >= n_out) return;
     float4* oG = (float4*)(o.G + (size_t)row * 64);
     if (row < n_keep) {                                                     // global[~mask]          :492
         const long long m = keep_idx[row];
@@ -346,6 +354,33 @@ __global__ __launch_bounds__(256) void ptf_write_state_kernel(
         if (c == 4) { o.X[3 * (size_t)row] = x_i[3 * p]; o.X[3 * (size_t)row + 1] = x_i[3 * p + 1]; o.X[3 * (size_t)row + 2] = x_i[3 * p + 2]; }
         if (c == 5) { o.R[row] = rho_i[p]; o.O[row] = om_i[p]; o.D[row] = d_i[p]; }
     }
+    }
+}
+
+// The fused rows of ptf_write_state_kernel when the GRU has already written their latent rows (the fold): four lanes per row, lane q =
+// float4 q of the blended extrinsics; q = 0 also the position, q = 1 the scalars.  Same expressions as the 16-lane form.
+__global__ __launch_bounds__(256) void ptf_write_state_fused_kernel(
+    int n_keep, int n_fuse, const int32_t* __restrict__ counts, const long long* __restrict__ fuse_idx,
+    const long long* __restrict__ fuse_pix, PtfState s, const float* __restrict__ x_i, const float* __restrict__ rho_i,
+    const float* __restrict__ om_i, const float* __restrict__ d_i, const float* __restrict__ E_i, PtfState o)
+{
+    if (counts) { n_keep = counts[0]; n_fuse = counts[1]; }
+    const int c = threadIdx.x & 3;
+    for (int t = blockIdx.x * 64 + (threadIdx.x >> 2); t < n_fuse; t += gridDim.x * 64) {       // (grid-stride: capped grid)
+        const size_t row = (size_t)n_keep + t;
+        const long long m = fuse_idx[t], p = fuse_pix[t];
+        const float w0 = s.R[m], w1 = rho_i[p], ws = w0 + w1;
+        {
+            const float4 a = ((const float4*)(s.E + m * 16))[c], b = ((const float4*)E_i)[c];
+            ((float4*)(o.E + row * 16))[c] = make_float4((a.x * w0 + b.x * w1) / ws, (a.y * w0 + b.y * w1) / ws,
+                                                          (a.z * w0 + b.z * w1) / ws, (a.w * w0 + b.w * w1) / ws);
+        }
+        if (c == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.X[3 * row + k] = (s.X[3 * m + k] * w0 + x_i[3 * p + k] * w1) / ws;
+        }
+        if (c == 1) { o.R[row] = ws; o.O[row] = s.O[m] + om_i[p]; o.D[row] = (s.D[m] * w0 + d_i[p] * w1) / ws; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -361,6 +396,9 @@ __global__ __launch_bounds__(256) void ptf_write_state_kernel(
 // ------------------------------------------------------------------------------------------
 struct PtfGrad { float *G, *X, *R, *O, *E, *D; };   // any member may be NULL (no gradient for that field)
 
+// SPLIT: the fused rows are handled by ptf_write_state_bwd_fused_kernel (4 lanes per row instead of 16: a fused row moves ~300 bytes,
+// not a 256-byte latent row, and 10 of its 16 lanes had nothing to do) -- this launch then walks the kept and the appended rows only.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void ptf_write_state_bwd_kernel(
     int n_keep, int n_fuse, int n_app, const long long* __restrict__ keep_idx, const long long* __restrict__ fuse_idx,
     const long long* __restrict__ fuse_pix, const long long* __restrict__ app_pix, PtfState s,
@@ -368,8 +406,10 @@ __global__ __launch_bounds__(256) void ptf_write_state_bwd_kernel(
     const float* __restrict__ E_i, PtfGrad go, PtfGrad gs, float* __restrict__ g_lat_i, float* __restrict__ g_x_i,
     float* __restrict__ g_rho_i, float* __restrict__ g_om_i, float* __restrict__ g_d_i)
 {
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
+    int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = threadIdx.x & 15;
     const int n_out = n_keep + n_fuse + n_app;
+    if (SPLIT && row >= n_keep) row += n_fuse;          // (the grid covers n_keep + n_app rows)
     if (row >= n_out) return;
     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const float4 dG = go.G ? ((const float4*)(go.G + (size_t)row * 64))[c] : z4;
@@ -448,6 +488,64 @@ __global__ __launch_bounds__(256) void ptf_write_state_bwd_kernel(
             if (go.O) g_om_i[p] += go.O[row];
             if (go.D) g_d_i[p] += go.D[row];
         }
+    }
+}
+
+// The fused rows of ptf_write_state_bwd_kernel, four lanes per row (lane q: float4 q of the 16 extrinsics floats; q = 0 also the
+// position, q = 1 the depth / density / weight scalars; dw0 / dw1 summed over the four lanes) -- same arithmetic, same order per term.
+__global__ __launch_bounds__(256) void ptf_write_state_bwd_fused_kernel(
+    int n_keep, int n_fuse, const long long* __restrict__ fuse_idx, const long long* __restrict__ fuse_pix, PtfState s,
+    const float* __restrict__ x_i, const float* __restrict__ rho_i, const float* __restrict__ d_i,
+    const float* __restrict__ E_i, PtfGrad go, PtfGrad gs, float* __restrict__ g_x_i,
+    float* __restrict__ g_rho_i, float* __restrict__ g_om_i, float* __restrict__ g_d_i)
+{
+    const int t = blockIdx.x * 64 + (threadIdx.x >> 2), c = threadIdx.x & 3;
+    if (t >= n_fuse) return;                  // (whole quads leave together: the shuffles below stay inside a quad)
+    const int row = n_keep + t;
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const long long m = fuse_idx[t], p = fuse_pix[t];
+    const float w0 = s.R[m], w1 = rho_i[p], ws = w0 + w1, inv = 1.0f / ws;
+    float dw0 = 0.0f, dw1 = 0.0f;
+    {
+        const float4 a = ((const float4*)(s.E + m * 16))[c], b = ((const float4*)E_i)[c];
+        const float4 g = go.E ? ((const float4*)(go.E + (size_t)row * 16))[c] : z4;
+        const float ox = (a.x * w0 + b.x * w1) * inv, oy = (a.y * w0 + b.y * w1) * inv;
+        const float oz = (a.z * w0 + b.z * w1) * inv, ow = (a.w * w0 + b.w * w1) * inv;
+        ((float4*)(gs.E + m * 16))[c] = make_float4(g.x * w0 * inv, g.y * w0 * inv, g.z * w0 * inv, g.w * w0 * inv);
+        dw0 += (g.x * (a.x - ox) + g.y * (a.y - oy) + g.z * (a.z - oz) + g.w * (a.w - ow)) * inv;
+        dw1 += (g.x * (b.x - ox) + g.y * (b.y - oy) + g.z * (b.z - oz) + g.w * (b.w - ow)) * inv;
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = s.X[3 * m + k], b = x_i[3 * p + k], g = go.X ? go.X[3 * (size_t)row + k] : 0.0f;
+            const float o = (a * w0 + b * w1) * inv;
+            gs.X[3 * m + k] = g * w0 * inv;
+            atomicAdd(&g_x_i[3 * p + k], g * w1 * inv);
+            dw0 += g * (a - o) * inv;
+            dw1 += g * (b - o) * inv;
+        }
+    }
+    if (c == 1) {
+        const float a = s.D[m], b = d_i[p], g = go.D ? go.D[row] : 0.0f;
+        const float o = (a * w0 + b * w1) * inv;
+        gs.D[m] = g * w0 * inv;
+        atomicAdd(&g_d_i[p], g * w1 * inv);
+        dw0 += g * (a - o) * inv;
+        dw1 += g * (b - o) * inv;
+        const float gR = go.R ? go.R[row] : 0.0f, gO = go.O ? go.O[row] : 0.0f;
+        dw0 += gR; dw1 += gR;          // R_out = w0 + w1
+        gs.O[m] = gO;                  // O_out = O[m] + om_i[p]
+        atomicAdd(&g_om_i[p], gO);
+    }
+#pragma unroll
+    for (int d = 2; d >= 1; d >>= 1) {
+        dw0 += __shfl_xor(dw0, d, 64);
+        dw1 += __shfl_xor(dw1, d, 64);
+    }
+    if (c == 0) {
+        gs.R[m] = dw0;                 // (+ the positional-encoding term: ptf_gru_inputs_bwd adds it)
+        atomicAdd(&g_rho_i[p], dw1);
     }
 }
 
@@ -613,7 +711,7 @@ FS_API int fs_ptf_write_state(int32_t n_keep, int32_t n_fuse, int32_t n_app, con
     PtfState s{const_cast<float*>(G), const_cast<float*>(X), const_cast<float*>(R), const_cast<float*>(O),
                const_cast<float*>(E), const_cast<float*>(D)};
     PtfState o{oG, oX, oR, oO, oE, oD};
-    hipLaunchKernelGGL(ptf_write_state_kernel, dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
+    hipLaunchKernelGGL(ptf_write_state_kernel<false>, dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
                        n_app, (const int32_t*)nullptr, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
                        (const long long*)append_pix, s, g_i, x_i, rho_i, om_i, d_i, E_i, fused, o);
     FS_CHECK_LAUNCH("ptf_write_state");
@@ -678,9 +776,20 @@ static int fold_step_impl(int32_t M_max, const int32_t* M_dev, int32_t h, int32_
                 const_cast<float*>(E), const_cast<float*>(D)};
     PtfState so{oG, oX, oR, oO, oE, oD};
     const long long n_out_max = (long long)M_max + P;
-    hipLaunchKernelGGL(ptf_write_state_kernel, dim3((unsigned)((n_out_max + 15) / 16)), dim3(256), 0, st, 0, 0, 0,
-                       (const int32_t*)counts, (const long long*)keep, (const long long*)fuse, (const long long*)fpix,
-                       (const long long*)app, si, g_i, x_i, rho_i, om_i, d_i, E_i, (const float*)nullptr, so);
+    // (the counts are on the device: both grids cover their worst case, workgroups past the rows that exist leave at once)
+    static const bool split = [] { const char* e = getenv("FS_PTF_WS_SPLIT"); return !(e && atoi(e) == 0); }();
+    if (split) {
+        const unsigned cap = 256 * 8 * 4;        // 8 workgroups per CU resident, four rounds of them: enough to balance, few enough to be cheap when empty
+        hipLaunchKernelGGL(ptf_write_state_kernel<true>, dim3(std::min<unsigned>((unsigned)((n_out_max + 15) / 16), cap)), dim3(256), 0, st, 0, 0, 0,
+                           (const int32_t*)counts, (const long long*)keep, (const long long*)fuse, (const long long*)fpix,
+                           (const long long*)app, si, g_i, x_i, rho_i, om_i, d_i, E_i, (const float*)nullptr, so);
+        hipLaunchKernelGGL(ptf_write_state_fused_kernel, dim3(std::min<unsigned>((unsigned)((nf_max + 63) / 64), cap)), dim3(256), 0, st, 0, 0,
+                           (const int32_t*)counts, (const long long*)fuse, (const long long*)fpix, si, x_i, rho_i, om_i, d_i, E_i, so);
+    } else {
+        hipLaunchKernelGGL(ptf_write_state_kernel<false>, dim3((unsigned)((n_out_max + 15) / 16)), dim3(256), 0, st, 0, 0, 0,
+                           (const int32_t*)counts, (const long long*)keep, (const long long*)fuse, (const long long*)fpix,
+                           (const long long*)app, si, g_i, x_i, rho_i, om_i, d_i, E_i, (const float*)nullptr, so);
+    }
     FS_CHECK_LAUNCH("ptf_write_state");
     return FS_OK;
 }
@@ -842,9 +951,23 @@ FS_API int fs_ptf_write_state_backward(int32_t n_keep, int32_t n_fuse, int32_t n
     PtfState s{nullptr, const_cast<float*>(X), const_cast<float*>(R), nullptr, const_cast<float*>(E), const_cast<float*>(D)};
     PtfGrad go{g_out[0], g_out[1], g_out[2], g_out[3], g_out[4], g_out[5]};
     PtfGrad gs{g_in[0], g_in[1], g_in[2], g_in[3], g_in[4], g_in[5]};
-    hipLaunchKernelGGL(ptf_write_state_bwd_kernel, dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
-                       n_app, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
-                       (const long long*)append_pix, s, x_i, rho_i, d_i, E_i, go, gs, g_lat_i, g_x_i, g_rho_i, g_om_i, g_d_i);
+    // FS_PTF_WS_BWD_SPLIT=0: one launch, 16 lanes per row for every row (rounds 2 - 5; A/B)
+    static const bool split = [] { const char* e = getenv("FS_PTF_WS_BWD_SPLIT"); return !(e && atoi(e) == 0); }();
+    if (split) {
+        const long long n_ka = (long long)n_keep + n_app;
+        if (n_ka > 0)
+            hipLaunchKernelGGL(ptf_write_state_bwd_kernel<true>, dim3((unsigned)((n_ka + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
+                               n_app, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
+                               (const long long*)append_pix, s, x_i, rho_i, d_i, E_i, go, gs, g_lat_i, g_x_i, g_rho_i, g_om_i, g_d_i);
+        if (n_fuse > 0)
+            hipLaunchKernelGGL(ptf_write_state_bwd_fused_kernel, dim3((unsigned)((n_fuse + 63) / 64)), dim3(256), 0, st, n_keep, n_fuse,
+                               (const long long*)fuse_idx, (const long long*)fuse_pix, s, x_i, rho_i, d_i, E_i, go, gs, g_x_i, g_rho_i,
+                               g_om_i, g_d_i);
+    } else {
+        hipLaunchKernelGGL(ptf_write_state_bwd_kernel<false>, dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
+                           n_app, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
+                           (const long long*)append_pix, s, x_i, rho_i, d_i, E_i, go, gs, g_lat_i, g_x_i, g_rho_i, g_om_i, g_d_i);
+    }
     FS_CHECK_LAUNCH("ptf_write_state_bwd");
     return FS_OK;
 }
