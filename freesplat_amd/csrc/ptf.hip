@@ -321,10 +321,51 @@ __global__ __launch_bounds__(256) void ptf_write_state_kernel(
     const int n_out = n_keep + n_fuse + n_app;
     // (grid-stride: with the counts on the device the fold sizes its grid for the worst case -- 235 k workgroups at 968x1296 of
     //  which 34 k have rows -- so the grid is capped and the workgroups walk)
+    if constexpr (SPLIT) {
+        // kept + appended rows only, FOUR rows per 16-lane group in flight: index loads, then the rows' loads, then the stores -- a
+        // group that moved one row per trip exposed the index -> row -> store chain once per 688 bytes
+        constexpr int U = 4;
+        const long long n_ka = (long long)n_keep + n_app, G = (long long)gridDim.x * 16;
+        for (long long r0 = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); r0 < n_ka; r0 += U * G) {
+            long long src[U];
+            bool kept[U], live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long r = r0 + u * G;
+                live[u] = r < n_ka; kept[u] = r < n_keep;
+                src[u] = 0;
+                if (live[u]) src[u] = kept[u] ? keep_idx[r] : app_pix[r - n_keep];
+            }
+            float4 g[U], e[U];
+            float x[U], q[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long m = src[u];
+                g[u] = e[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); x[u] = q[u] = 0.0f;
+                if (!live[u]) continue;       // (no loads for rows that do not exist: thousands of groups reading row 0 make one L2 channel the bottleneck)
+                g[u] = ((const float4*)((kept[u] ? s.G : g_i) + m * 64))[c];
+                if (c < 4) e[u] = ((const float4*)(kept[u] ? s.E + m * 16 : E_i))[c];
+                if (c >= 4 && c < 7) x[u] = (kept[u] ? s.X : x_i)[3 * m + (c - 4)];
+                if (c >= 7 && c < 10) q[u] = (c == 7 ? (kept[u] ? s.R : rho_i) : (c == 8 ? (kept[u] ? s.O : om_i) : (kept[u] ? s.D : d_i)))[m];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!live[u]) continue;
+                const long long r = r0 + u * G;
+                const size_t row = (size_t)(r < n_keep ? r : r + n_fuse);
+                ((float4*)(o.G + row * 64))[c] = g[u];
+                if (c < 4) ((float4*)(o.E + row * 16))[c] = e[u];
+                if (c >= 4 && c < 7) o.X[3 * row + (c - 4)] = x[u];
+                if (c == 7) o.R[row] = q[u];
+                if (c == 8) o.O[row] = q[u];
+                if (c == 9) o.D[row] = q[u];
+            }
+        }
+        return;
+    }
     for (long long r0 = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);; r0 += (long long)gridDim.x * 16) {
-    int row = (int)r0;
-    if (SPLIT && row >= n_keep) row += n_fuse;          // (this launch: kept + appended rows)
-    if (r0 >= n_out || row >= n_out) return;
+    const int row = (int)r0;
+    if (r0 >= n_out) return;
     float4* oG = (float4*)(o.G + (size_t)row * 64);
     if (row < n_keep) {                                                     // global[~mask]          :492
         const long long m = keep_idx[row];
@@ -406,12 +447,67 @@ __global__ __launch_bounds__(256) void ptf_write_state_bwd_kernel(
     const float* __restrict__ E_i, PtfGrad go, PtfGrad gs, float* __restrict__ g_lat_i, float* __restrict__ g_x_i,
     float* __restrict__ g_rho_i, float* __restrict__ g_om_i, float* __restrict__ g_d_i)
 {
-    int row = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int c = threadIdx.x & 15;
     const int n_out = n_keep + n_fuse + n_app;
-    if (SPLIT && row >= n_keep) row += n_fuse;          // (the grid covers n_keep + n_app rows)
-    if (row >= n_out) return;
     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (SPLIT) {
+        // kept + appended rows only (the grid covers a quarter of them): FOUR rows per 16-lane group in flight -- indices, then every
+        // load (the out row's gradient; an appended pixel's accumulated values), then the stores.  Lane c: float4 c of the latent row;
+        // lanes 0 - 3 the extrinsics, 4 - 6 the position, 7 - 9 the scalars R, O, D.
+        constexpr int U = 4;
+        const long long n_ka = (long long)n_keep + n_app, G = (long long)gridDim.x * 16;
+        const long long r0 = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+        long long dst[U];
+        bool kept[U], live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = r0 + u * G;
+            live[u] = r < n_ka; kept[u] = r < n_keep;
+            dst[u] = 0;
+            if (live[u]) dst[u] = kept[u] ? keep_idx[r] : app_pix[r - n_keep];
+        }
+        float4 g[U], e[U], acc[U];
+        float x[U], q[U], ax[U], aq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            g[u] = e[u] = acc[u] = z4; x[u] = q[u] = ax[u] = aq[u] = 0.0f;
+            if (!live[u]) continue;            // (no loads for rows that do not exist)
+            const long long r = r0 + u * G;
+            const size_t row = (size_t)(kept[u] ? r : r + n_fuse);
+            const long long m = dst[u];
+            if (go.G) g[u] = ((const float4*)(go.G + row * 64))[c];
+            if (c < 4 && go.E && kept[u]) e[u] = ((const float4*)(go.E + row * 16))[c];
+            if (c >= 4 && c < 7 && go.X) x[u] = go.X[3 * row + (c - 4)];
+            if (c >= 7 && c < 10) { const float* gp = c == 7 ? go.R : (c == 8 ? go.O : go.D); if (gp) q[u] = gp[row]; }
+            if (!kept[u]) {                    // an appended pixel is appended once and never fused: plain read-modify-write
+                acc[u] = ((const float4*)(g_lat_i + m * 64))[c];
+                if (c >= 4 && c < 7) ax[u] = g_x_i[3 * m + (c - 4)];
+                if (c >= 7 && c < 10) aq[u] = (c == 7 ? g_rho_i : (c == 8 ? g_om_i : g_d_i))[m];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            const long long m = dst[u];
+            if (kept[u]) {
+                ((float4*)(gs.G + m * 64))[c] = g[u];
+                if (c < 4) ((float4*)(gs.E + m * 16))[c] = e[u];
+                if (c >= 4 && c < 7) gs.X[3 * m + (c - 4)] = x[u];
+                if (c == 7) gs.R[m] = q[u];
+                if (c == 8) gs.O[m] = q[u];
+                if (c == 9) gs.D[m] = q[u];
+            } else {
+                ((float4*)(g_lat_i + m * 64))[c] = make_float4(acc[u].x + g[u].x, acc[u].y + g[u].y, acc[u].z + g[u].z, acc[u].w + g[u].w);
+                if (c >= 4 && c < 7 && go.X) g_x_i[3 * m + (c - 4)] = ax[u] + x[u];
+                if (c == 7 && go.R) g_rho_i[m] = aq[u] + q[u];
+                if (c == 8 && go.O) g_om_i[m] = aq[u] + q[u];
+                if (c == 9 && go.D) g_d_i[m] = aq[u] + q[u];
+            }
+        }
+        return;
+    }
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= n_out) return;
     const float4 dG = go.G ? ((const float4*)(go.G + (size_t)row * 64))[c] : z4;
     if (row < n_keep) {
         const long long m = keep_idx[row];
@@ -956,7 +1052,7 @@ FS_API int fs_ptf_write_state_backward(int32_t n_keep, int32_t n_fuse, int32_t n
     if (split) {
         const long long n_ka = (long long)n_keep + n_app;
         if (n_ka > 0)
-            hipLaunchKernelGGL(ptf_write_state_bwd_kernel<true>, dim3((unsigned)((n_ka + 15) / 16)), dim3(256), 0, st, n_keep, n_fuse,
+            hipLaunchKernelGGL(ptf_write_state_bwd_kernel<true>, dim3((unsigned)((n_ka + 63) / 64)), dim3(256), 0, st, n_keep, n_fuse,
                                n_app, (const long long*)keep_idx, (const long long*)fuse_idx, (const long long*)fuse_pix,
                                (const long long*)append_pix, s, x_i, rho_i, d_i, E_i, go, gs, g_lat_i, g_x_i, g_rho_i, g_om_i, g_d_i);
         if (n_fuse > 0)
