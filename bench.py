@@ -643,6 +643,8 @@ def headline(full: dict) -> dict:
                 e["frac"] = _num(o["roofline"].get("frac"), 3)
                 if isinstance(o["roofline"].get("l1_tap_roofline"), dict):
                     e["l1_frac"] = _num(o["roofline"]["l1_tap_roofline"]["frac"], 3)
+            if isinstance(o.get("roofline_mfma"), dict):      # (the fold's GRU on the fp32 matrix pipe: the ruler that binds it)
+                e["mfma_frac"] = _num(o["roofline_mfma"].get("frac"), 3)
             t = o.get("train_fwd_bwd") or {}
             tm = t.get("ms", t.get("hip_ms"))
             if tm is not None:

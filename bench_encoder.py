@@ -330,7 +330,14 @@ def bench_ptf(dev, steps, warmup, V=2, h=384, w=512, cpu=True, cpu_steps=None, t
                               "frac": alg / (kern_ms * 1e-3) / 8e12, "algorithmic_bytes_per_fold": alg,
                               "kernel_ms_per_fold": kern_ms, "kernel_ms_per_fold_event_timed": kern_ms_events,
                               "launches": cnt // max(steps, 1),
-                              "traffic": _traffic(f"ptf_{V}_views")[0], "traffic_source": _traffic(f"ptf_{V}_views")[1]}}, **extra)
+                              "traffic": _traffic(f"ptf_{V}_views")[0], "traffic_source": _traffic(f"ptf_{V}_views")[1]},
+                 # the other ruler of the same fold (round 6): its GRU -- 44 928 MACs per fused pair on v_mfma_f32_16x16x4_f32 -- is three
+                 # quarters of the fold's GPU time (profiles/r6_gru_bwd_waves_ab.txt) and sits on the fp32 matrix pipe, not on HBM
+                 "roofline_mfma": {"bound": "mfma", "kernel": "ptf_gru16_kernel<true> inside the fold (the whole fold's kernel time in the denominator)",
+                                   "algorithmic_flops_per_fold": 2 * 44928 * sum(c[1] for c in steps_counts[1:]),
+                                   "achieved": 2 * 44928 * sum(c[1] for c in steps_counts[1:]) / (kern_ms * 1e-3) / 1e12,
+                                   "peak": 157.3, "unit": "TFLOP/s",
+                                   "frac": 2 * 44928 * sum(c[1] for c in steps_counts[1:]) / (kern_ms * 1e-3) / 1e12 / 157.3}}, **extra)
 
 
 def bench_depth_tail(dev, steps, warmup, V=2, D=128, h2=192, w2=256):
